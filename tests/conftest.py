@@ -1,0 +1,48 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def manifest():
+    with open(os.path.join(GOLDEN, "manifest.json")) as fh:
+        return json.load(fh)
+
+
+@pytest.fixture(scope="session")
+def golden_steps():
+    return dict(np.load(os.path.join(GOLDEN, "steps.npz")))
+
+
+@pytest.fixture(scope="session")
+def golden_errors():
+    return dict(np.load(os.path.join(GOLDEN, "errors.npz")))
+
+
+@pytest.fixture(scope="session")
+def golden_traj():
+    return dict(np.load(os.path.join(GOLDEN, "trajectories.npz")))
+
+
+def step_case(arrays, case):
+    """Inputs/outputs of one golden step case as a dict."""
+    tag = "c%03d_" % case["id"]
+    return {k[len(tag):]: v for k, v in arrays.items() if k.startswith(tag)}
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
