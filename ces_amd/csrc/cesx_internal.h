@@ -1,0 +1,232 @@
+// Internal declarations shared by the HIP translation units of libcesx.so.
+// gfx950 (MI355X / CDNA4) only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/cesx.h"
+
+namespace cesx {
+
+constexpr int WAVE = 64;
+
+// ---------------------------------------------------------------------------
+// MFMA traits.  A/B operand lane map for both shapes: index within the tile =
+// lane % TILE, k within the instruction = lane / TILE (one element per lane).
+// ---------------------------------------------------------------------------
+template <typename T> struct Mfma;
+
+template <> struct Mfma<float> {
+    static constexpr int TILE = 32;   // v_mfma_f32_32x32x2_f32
+    static constexpr int KSTEP = 2;   // k values consumed per instruction
+    static constexpr int NACC = 16;   // accumulator elements per lane
+    static constexpr int VEC = 4;     // elements per 16-byte LDS read
+    using acc_t = float __attribute__((ext_vector_type(16)));
+    using vec_t = float __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+    // C/D map: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    static __device__ __forceinline__ int crow(int lane, int reg) {
+        return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+    }
+    static __device__ __forceinline__ int ccol(int lane) { return lane & 31; }
+};
+
+template <> struct Mfma<double> {
+    static constexpr int TILE = 16;   // v_mfma_f64_16x16x4_f64
+    static constexpr int KSTEP = 4;
+    static constexpr int NACC = 4;
+    static constexpr int VEC = 2;
+    using acc_t = double __attribute__((ext_vector_type(4)));
+    using vec_t = double __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    // f64 C/D map differs from the f32 family: col = lane & 15, row = (lane >> 4) + 4 * reg
+    static __device__ __forceinline__ int crow(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+    static __device__ __forceinline__ int ccol(int lane) { return lane & 15; }
+};
+
+// j (or k) values covered by one 16-byte fragment read of every lane: the
+// KSTEP lane groups each take VEC consecutive values -> KSTEP * VEC = 8.
+constexpr int GROUP = 8;
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011).  counter = (particle_lo, particle_hi,
+// row_quad, step), key = seed.  oracle/philox.py restates this in numpy.
+// ---------------------------------------------------------------------------
+struct uint4x { uint32_t x, y, z, w; };
+
+__host__ __device__ __forceinline__ uint4x philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2,
+                                                         uint32_t c3, uint32_t k0, uint32_t k1) {
+    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    return {c0, c1, c2, c3};
+}
+
+// Four N(0,1) draws for rows 4q..4q+3 of one particle (Box-Muller on two pairs).
+__device__ __forceinline__ void normal4(uint4x r, float out[4]) {
+    const float s = 5.9604644775390625e-08f;   // 2^-24
+    float u0 = ((float)(r.x >> 8) + 0.5f) * s, u1 = ((float)(r.y >> 8) + 0.5f) * s;
+    float u2 = ((float)(r.z >> 8) + 0.5f) * s, u3 = ((float)(r.w >> 8) + 0.5f) * s;
+    float ra = __builtin_sqrtf(-2.0f * __logf(u0)), rb = __builtin_sqrtf(-2.0f * __logf(u2));
+    // v_sin_f32 / v_cos_f32 take their argument in revolutions
+    out[0] = ra * __builtin_amdgcn_cosf(u1);
+    out[1] = ra * __builtin_amdgcn_sinf(u1);
+    out[2] = rb * __builtin_amdgcn_cosf(u3);
+    out[3] = rb * __builtin_amdgcn_sinf(u3);
+}
+__device__ __forceinline__ void normal4(uint4x r, double out[4]) {
+    const double s = 2.3283064365386963e-10;   // 2^-32
+    const double twopi = 6.283185307179586476925286766559;
+    double u0 = ((double)r.x + 0.5) * s, u1 = ((double)r.y + 0.5) * s;
+    double u2 = ((double)r.z + 0.5) * s, u3 = ((double)r.w + 0.5) * s;
+    double ra = sqrt(-2.0 * log(u0)), rb = sqrt(-2.0 * log(u2));
+    double sa, ca, sb, cb;
+    sincos(twopi * u1, &sa, &ca);
+    sincos(twopi * u3, &sb, &cb);
+    out[0] = ra * ca; out[1] = ra * sa; out[2] = rb * cb; out[3] = rb * sb;
+}
+
+// ---------------------------------------------------------------------------
+// Gram work partition (host builds it once per engine).
+// ---------------------------------------------------------------------------
+struct GramPlan {
+    int tile;            // Mfma<T>::TILE
+    int nbr;             // block rows = ceil((p+n)/tile)
+    int nblocks;         // lower-triangular blocks
+    int ntypes;          // workgroup types
+    int max_rb;          // max staged row blocks over types
+    int nbw;             // per-wave block capacity (compile-time constant of the kernel)
+    // flattened tables uploaded to the device:
+    //  type_hdr[type*4 + {0: nrb, 1: rows_off, 2: blocks_off, 3: unused}]
+    //  rows[rows_off + i]            = global block row of compact row i
+    //  wblk[(blocks_off + wave*nbw + b)*3 + {0,1,2}] = {ia, ib, out block id} or ia = -1
+    //  blk_rc[out*2 + {0,1}] = (R, C) of output block
+    std::vector<int> type_hdr, rows, wblk, blk_rc;
+};
+GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds);
+
+// ---------------------------------------------------------------------------
+// Engine state
+// ---------------------------------------------------------------------------
+struct Scalars {              // device-resident fp64 scalars written by K2
+    double hk, t_new, sqrt2hk, alpha;
+    double self_bias, self_bias_data, bias_data, bias;
+    double radspec, frob2, tr_suu, absmax;
+    double spare[4];
+    int    status, pad;
+};
+
+struct Engine {
+    cesx_config cfg{};
+    std::string err;
+    bool problem_set = false, shift_valid = false;
+    int p = 0, n = 0, P = 0;
+    int64_t J = 0, Jg = 0;
+    size_t esz = 4;               // sizeof(T)
+    bool diag_gamma = false, diag_sigma = false;
+
+    // problem data (fp64) on device
+    double *d_y = nullptr, *d_mu = nullptr, *d_ustar = nullptr;
+    double *d_Gamma = nullptr, *d_Ginv = nullptr, *d_gw = nullptr;    // gw = diag(Gamma^{-1}) if diagonal
+    double *d_Sigma = nullptr, *d_Sinv = nullptr, *d_sw = nullptr;
+    // centring shift
+    double* d_shift64 = nullptr;   // [p+n]
+    void*   d_shiftT = nullptr;    // [p+n] engine dtype
+    void*   d_yT = nullptr;        // y in engine dtype
+    void*   d_gwT = nullptr;       // diag(Gamma^{-1}) in engine dtype
+    void*   d_GinvT = nullptr;     // dense Gamma^{-1} in engine dtype (n x n)
+    // gram
+    GramPlan plan;
+    int *d_type_hdr = nullptr, *d_rows = nullptr, *d_wblk = nullptr, *d_blk_rc = nullptr;
+    int nslices = 0;
+    void* d_slabs = nullptr;       // [nslices][nblocks][tile*tile] engine dtype
+    // stats partials
+    int stats_blocks = 0;
+    double* d_stat_part = nullptr; // [stats_blocks][stat_len]
+    int colsum_slices = 0;
+    double* d_colsum_part = nullptr;
+    // moments
+    size_t mom_len = 0;
+    double* d_mom = nullptr;
+    double* d_sums = nullptr;      // [1+p+n]
+    // dense workspace (fp64)
+    double *d_ubar = nullptr, *d_gbar = nullptr, *d_m = nullptr, *d_wdel = nullptr;
+    double *d_C = nullptr, *d_L = nullptr, *d_Cug = nullptr, *d_See = nullptr, *d_Srr = nullptr;
+    double *d_dg = nullptr;
+    double *d_K = nullptr, *d_Kp = nullptr, *d_M = nullptr, *d_P = nullptr, *d_PK = nullptr;
+    double *d_t1 = nullptr, *d_t2 = nullptr, *d_t3 = nullptr, *d_t4 = nullptr;   // max(p,n)^2 each
+    double *d_Wh = nullptr;        // chol(Gamma)^{-1} (dense Gamma, spectral rule)
+    double *d_lanczos = nullptr;
+    int lanczos_steps = 96;
+    double *d_absmax = nullptr;    // [1]
+    double *d_c0 = nullptr;        // [1]
+    void   *d_qe = nullptr;        // [J] per-particle q^e (engine dtype)
+    void   *d_wdT = nullptr;       // [n] Ginv (s_g - y) in engine dtype (dense Gamma)
+    double *d_colsum_partq = nullptr;
+    double *d_mv = nullptr;        // matvec results [6][max(p,n)]
+    double *d_part = nullptr;      // reduction partials
+    Scalars* d_scal = nullptr;
+    double* d_absmax_part = nullptr;
+    // update coefficients (engine dtype)
+    int bk = 16, kp = 0, kn = 0, ktot = 0, rpad = 0;
+    void* d_W = nullptr;           // [rpad][ktot]
+    void* d_bias = nullptr;        // [rpad]
+    void* d_Wfwd = nullptr;        // forward-map staging [npad][kp]
+    // results
+    cesx_step_result* h_res = nullptr;   // pinned
+    Scalars* h_scal = nullptr;           // pinned
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+    cesx_step_params last_prm{};
+};
+
+// ---------------------------------------------------------------------------
+// kernel launchers (defined in the .hip files)
+// ---------------------------------------------------------------------------
+struct UpdateSrc {            // one K-segment of the update GEMM
+    const void* ptr;          // (rows x J) array, or nullptr for on-device noise
+    int rows;                 // real rows
+    int kind;                 // 0 = memory, 1 = philox noise
+};
+
+int launch_colsum(Engine& e, const void* U, const void* G, double* sums, hipStream_t s);
+int launch_set_shift(Engine& e, const double* sums, hipStream_t s);
+int launch_stats(Engine& e, const void* U, const void* G, double* mom, hipStream_t s);
+int launch_gram(Engine& e, const void* U, const void* G, double* mom, hipStream_t s);
+int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int phase, hipStream_t s);
+int launch_update(Engine& e, int out_rows, const void* W, int ktot, const void* bias,
+                  const UpdateSrc* src, int nsrc,
+                  const void* add1, const double* c1, double c1_imm,
+                  const void* add2, const double* c2, double c2_imm,
+                  void* out, double* absmax_part, uint64_t step_index, hipStream_t s);
+int update_grid_blocks(Engine& e, int out_rows);
+int launch_absmax_final(Engine& e, int nparts, double* absmax_out, hipStream_t s);
+int gram_nbw(int dtype);
+int gram_tile(int dtype);
+int gram_kt(int dtype);
+int gram_max_stage_rows();
+int launch_noise(Engine& e, uint64_t step_index, void* xi, hipStream_t s);
+
+#define CESX_HIP(call)                                                              \
+    do {                                                                            \
+        hipError_t _e = (call);                                                     \
+        if (_e != hipSuccess) {                                                     \
+            e.err = std::string(#call) + ": " + hipGetErrorString(_e);              \
+            return CESX_EHIP;                                                       \
+        }                                                                           \
+    } while (0)
+
+}  // namespace cesx

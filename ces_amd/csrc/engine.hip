@@ -1,0 +1,408 @@
+// C ABI of libcesx.so (include/cesx.h): handle lifetime, problem set-up and
+// the host-side sequencing of K1 (moments) -> K2 (dense) -> K3 (update).
+#include "cesx_internal.h"
+#include <cmath>
+#include <cstring>
+#include <new>
+
+using namespace cesx;
+
+namespace {
+
+std::string g_create_err;
+
+// ---- tiny host-side dense helpers (set-up only: Gamma and Sigma are factorised once) ----
+bool host_chol(int n, const double* A, std::vector<double>& L) {
+    L.assign((size_t)n * n, 0.0);
+    for (int j = 0; j < n; ++j) {
+        double d = A[(size_t)j * n + j];
+        for (int k = 0; k < j; ++k) d -= L[(size_t)j * n + k] * L[(size_t)j * n + k];
+        if (!(d > 0.0)) return false;
+        const double ljj = std::sqrt(d);
+        L[(size_t)j * n + j] = ljj;
+        for (int i = j + 1; i < n; ++i) {
+            double s = A[(size_t)i * n + j];
+            for (int k = 0; k < j; ++k) s -= L[(size_t)i * n + k] * L[(size_t)j * n + k];
+            L[(size_t)i * n + j] = s / ljj;
+        }
+    }
+    return true;
+}
+void host_tri_inverse(int n, const std::vector<double>& L, std::vector<double>& Li) {
+    Li.assign((size_t)n * n, 0.0);
+    for (int j = 0; j < n; ++j)
+        for (int i = j; i < n; ++i) {
+            double s = (i == j) ? 1.0 : 0.0;
+            for (int k = j; k < i; ++k) s -= L[(size_t)i * n + k] * Li[(size_t)k * n + j];
+            Li[(size_t)i * n + j] = s / L[(size_t)i * n + i];
+        }
+}
+// Ainv = Li^T Li
+void host_spd_inverse(int n, const std::vector<double>& Li, std::vector<double>& Ainv) {
+    Ainv.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double s = 0.0;
+            for (int k = i; k < n; ++k) s += Li[(size_t)k * n + i] * Li[(size_t)k * n + j];
+            Ainv[(size_t)i * n + j] = Ainv[(size_t)j * n + i] = s;
+        }
+}
+bool is_diagonal(int n, const double* A) {
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j)
+            if (i != j && A[(size_t)i * n + j] != 0.0) return false;
+    return true;
+}
+
+template <typename P> int dmalloc(Engine& e, P** ptr, size_t bytes) {
+    CESX_HIP(hipMalloc(reinterpret_cast<void**>(ptr), bytes ? bytes : 8));
+    CESX_HIP(hipMemset(*ptr, 0, bytes ? bytes : 8));
+    return CESX_OK;
+}
+int upload(Engine& e, void* dst, const void* src, size_t bytes) {
+    CESX_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return CESX_OK;
+}
+// fp64 host vector -> engine dtype on device
+int upload_T(Engine& e, void* dst, const double* src, size_t len) {
+    if (e.cfg.dtype == CESX_F64) return upload(e, dst, src, len * 8);
+    std::vector<float> tmp(len);
+    for (size_t i = 0; i < len; ++i) tmp[i] = (float)src[i];
+    return upload(e, dst, tmp.data(), len * 4);
+}
+
+#define TRY(x) do { int _rc = (x); if (_rc != CESX_OK) return _rc; } while (0)
+
+int set_device(Engine& e) {
+    CESX_HIP(hipSetDevice(e.cfg.device));
+    return CESX_OK;
+}
+
+int check_prm(Engine& e, const cesx_step_params* prm) {
+    if (!prm || prm->struct_bytes != sizeof(cesx_step_params)) { e.err = "bad cesx_step_params"; return CESX_EINVAL; }
+    if (prm->update < 0 || prm->update > 2) { e.err = "unknown update rule"; return CESX_EINVAL; }
+    if (prm->update != CESX_UPDATE_ALDI_CONSTANT) {
+        if (prm->time_step == CESX_TS_ADAPTIVE) {
+            e.err = "time_step='adaptive' needs LM_procedure, which the reference never defines (ces/calibrate.py:255)";
+            return CESX_EUNSUPPORTED;
+        }
+        if (prm->time_step < 0 || prm->time_step > 4) { e.err = "unknown time_step rule"; return CESX_EINVAL; }
+    }
+    if (!e.problem_set) { e.err = "cesx_set_problem has not been called"; return CESX_ESTATE; }
+    return CESX_OK;
+}
+
+int finish_step(Engine& e, const cesx_step_params& prm, hipStream_t s) {
+    CESX_HIP(hipMemcpyAsync(e.h_scal, e.d_scal, sizeof(Scalars), hipMemcpyDeviceToHost, s));
+    CESX_HIP(hipEventRecord(e.ev, s));
+    e.pending = true;
+    e.last_prm = prm;
+    return CESX_OK;
+}
+
+int run_update_main(Engine& e, const cesx_step_params& prm, const void* U, const void* G, const void* xi,
+                    void* Unext, hipStream_t s) {
+    UpdateSrc src[3] = {{U, e.p, 0}, {G, e.n, 0}, {xi, e.p, xi ? 0 : 1}};
+    return launch_update(e, e.p, e.d_W, e.ktot, e.d_bias, src, 3, nullptr, nullptr, 0.0, nullptr, nullptr, 0.0,
+                         Unext, nullptr, prm.step_index, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int cesx_abi_version(void) { return CESX_ABI_VERSION; }
+
+const char* cesx_last_error(cesx_handle h) {
+    if (!h) return g_create_err.c_str();
+    return reinterpret_cast<Engine*>(h)->err.c_str();
+}
+
+int cesx_create(const cesx_config* cfg, cesx_handle* out) {
+    if (out) *out = nullptr;
+    if (!cfg || !out || cfg->struct_bytes != sizeof(cesx_config)) { g_create_err = "bad cesx_config"; return CESX_EINVAL; }
+    if (cfg->p < 1 || cfg->n_obs < 1 || cfg->J_local < 1 || cfg->J_global < cfg->J_local || cfg->j_offset < 0 ||
+        (cfg->dtype != CESX_F32 && cfg->dtype != CESX_F64)) {
+        g_create_err = "cesx_create: invalid shape or dtype";
+        return CESX_EINVAL;
+    }
+    Engine* ep = new (std::nothrow) Engine();
+    if (!ep) { g_create_err = "out of host memory"; return CESX_EINVAL; }
+    Engine& e = *ep;
+    e.cfg = *cfg;
+    e.p = cfg->p; e.n = cfg->n_obs; e.P = e.p + e.n;
+    e.J = cfg->J_local; e.Jg = cfg->J_global;
+    e.esz = cfg->dtype == CESX_F32 ? 4 : 8;
+    auto fail = [&](int rc) { g_create_err = e.err; cesx_destroy(reinterpret_cast<cesx_handle>(ep)); return rc; };
+    int rc;
+    if ((rc = set_device(e))) return fail(rc);
+    const int p = e.p, n = e.n, P = e.P, mx = p > n ? p : n;
+    const size_t pp = (size_t)p * p, pn = (size_t)p * n, nn = (size_t)n * n, mm = (size_t)mx * mx;
+
+    // gram plan
+    e.plan = make_gram_plan(P, gram_tile(cfg->dtype), gram_nbw(cfg->dtype), gram_max_stage_rows());
+    if (e.plan.max_rb * e.plan.tile > gram_max_stage_rows()) { e.err = "gram plan exceeds LDS"; return fail(CESX_EINVAL); }
+    const long long ntiles = (e.J + gram_kt(cfg->dtype) - 1) / gram_kt(cfg->dtype);
+    int nsl = 256 / e.plan.ntypes;
+    if (nsl < 1) nsl = 1;
+    if (nsl > 8) nsl -= nsl % 8;
+    if (nsl > ntiles) nsl = (int)ntiles;
+    e.nslices = nsl;
+    e.colsum_slices = (int)std::min<long long>(16, (e.J + 1023) / 1024);
+    if (e.colsum_slices < 1) e.colsum_slices = 1;
+    e.stats_blocks = (int)((e.J + 63) / 64);
+    e.mom_len = 1 + P + pp + pn + nn + 3 + n;
+    e.kp = (p + 15) / 16 * 16; e.kn = (n + 15) / 16 * 16; e.ktot = 2 * e.kp + e.kn;
+    e.rpad = (mx + 255) / 256 * 256;
+
+#define DM(ptr, bytes) if ((rc = dmalloc(e, &ptr, (bytes)))) return fail(rc)
+    DM(e.d_y, n * 8); DM(e.d_mu, p * 8); DM(e.d_ustar, p * 8);
+    DM(e.d_Gamma, nn * 8); DM(e.d_Ginv, nn * 8); DM(e.d_gw, n * 8); DM(e.d_Wh, nn * 8);
+    DM(e.d_Sigma, pp * 8); DM(e.d_Sinv, pp * 8); DM(e.d_sw, p * 8);
+    DM(e.d_shift64, P * 8);
+    {
+        char* t;
+        DM(t, P * e.esz); e.d_shiftT = t;
+        DM(t, n * e.esz); e.d_yT = t;
+        DM(t, n * e.esz); e.d_gwT = t;
+        DM(t, nn * e.esz); e.d_GinvT = t;
+        DM(t, n * e.esz); e.d_wdT = t;
+        DM(t, (size_t)e.J * e.esz); e.d_qe = t;
+        DM(t, (size_t)e.nslices * e.plan.nblocks * e.plan.tile * e.plan.tile * e.esz); e.d_slabs = t;
+        DM(t, (size_t)e.rpad * e.ktot * e.esz); e.d_W = t;
+        DM(t, (size_t)e.rpad * e.esz); e.d_bias = t;
+        DM(t, (size_t)e.rpad * e.kp * e.esz); e.d_Wfwd = t;
+    }
+    DM(e.d_type_hdr, e.plan.type_hdr.size() * 4); DM(e.d_rows, e.plan.rows.size() * 4);
+    DM(e.d_wblk, e.plan.wblk.size() * 4); DM(e.d_blk_rc, e.plan.blk_rc.size() * 4);
+    if ((rc = upload(e, e.d_type_hdr, e.plan.type_hdr.data(), e.plan.type_hdr.size() * 4))) return fail(rc);
+    if ((rc = upload(e, e.d_rows, e.plan.rows.data(), e.plan.rows.size() * 4))) return fail(rc);
+    if ((rc = upload(e, e.d_wblk, e.plan.wblk.data(), e.plan.wblk.size() * 4))) return fail(rc);
+    if ((rc = upload(e, e.d_blk_rc, e.plan.blk_rc.data(), e.plan.blk_rc.size() * 4))) return fail(rc);
+    DM(e.d_stat_part, (size_t)e.stats_blocks * 3 * 8 + (size_t)((e.J + 255) / 256) * 3 * 8);
+    DM(e.d_colsum_part, (size_t)P * e.colsum_slices * 8);
+    DM(e.d_colsum_partq, (size_t)P * e.colsum_slices * 8);
+    DM(e.d_mom, e.mom_len * 8); DM(e.d_sums, (1 + P) * 8);
+    DM(e.d_ubar, p * 8); DM(e.d_gbar, n * 8); DM(e.d_m, n * 8); DM(e.d_dg, n * 8); DM(e.d_wdel, n * 8);
+    DM(e.d_C, pp * 8); DM(e.d_L, pp * 8); DM(e.d_Cug, pn * 8); DM(e.d_See, nn * 8); DM(e.d_Srr, nn * 8);
+    DM(e.d_K, pn * 8); DM(e.d_Kp, pn * 8); DM(e.d_M, pp * 8); DM(e.d_P, pp * 8); DM(e.d_PK, pn * 8);
+    DM(e.d_t1, mm * 8); DM(e.d_t2, mm * 8); DM(e.d_t3, mm * 8); DM(e.d_t4, mm * 8);
+    DM(e.d_lanczos, ((size_t)(e.lanczos_steps + 1) * n + 2 * e.lanczos_steps) * 8);
+    DM(e.d_mv, (size_t)6 * mx * 8); DM(e.d_part, 64 * 4 * 8);
+    DM(e.d_scal, sizeof(Scalars)); DM(e.d_absmax, 8); DM(e.d_c0, 8);
+    DM(e.d_absmax_part, (size_t)update_grid_blocks(e, p) * 8);
+#undef DM
+    if (hipHostMalloc(reinterpret_cast<void**>(&e.h_scal), sizeof(Scalars), hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&e.ev, hipEventDisableTiming) != hipSuccess) {
+        e.err = "pinned host buffer / event creation failed";
+        return fail(CESX_EHIP);
+    }
+    std::memset(e.h_scal, 0, sizeof(Scalars));
+    *out = reinterpret_cast<cesx_handle>(ep);
+    return CESX_OK;
+}
+
+void cesx_destroy(cesx_handle h) {
+    if (!h) return;
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    (void)hipSetDevice(e.cfg.device);
+    void* ptrs[] = {e.d_y, e.d_mu, e.d_ustar, e.d_Gamma, e.d_Ginv, e.d_gw, e.d_Wh, e.d_Sigma, e.d_Sinv, e.d_sw,
+                    e.d_shift64, e.d_shiftT, e.d_yT, e.d_gwT, e.d_GinvT, e.d_wdT, e.d_qe, e.d_slabs, e.d_W,
+                    e.d_bias, e.d_Wfwd, e.d_type_hdr, e.d_rows, e.d_wblk, e.d_blk_rc, e.d_stat_part,
+                    e.d_colsum_part, e.d_colsum_partq, e.d_mom, e.d_sums, e.d_ubar, e.d_gbar, e.d_m, e.d_dg,
+                    e.d_wdel, e.d_C, e.d_L, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_Kp, e.d_M, e.d_P, e.d_PK,
+                    e.d_t1, e.d_t2, e.d_t3, e.d_t4, e.d_lanczos, e.d_mv, e.d_part, e.d_scal, e.d_absmax,
+                    e.d_c0, e.d_absmax_part};
+    for (void* q : ptrs)
+        if (q) (void)hipFree(q);
+    if (e.h_scal) (void)hipHostFree(e.h_scal);
+    if (e.ev) (void)hipEventDestroy(e.ev);
+    delete &e;
+}
+
+int cesx_set_problem(cesx_handle h, const double* y, const double* Gamma, const double* mu,
+                     const double* Sigma, const double* ustar) {
+    if (!h) return CESX_EINVAL;
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    if (!y || !Gamma || !mu || !Sigma || !ustar) { e.err = "cesx_set_problem: null pointer"; return CESX_EINVAL; }
+    TRY(set_device(e));
+    const int p = e.p, n = e.n;
+    std::vector<double> L, Li, inv;
+    if (!host_chol(n, Gamma, L)) { e.err = "Gamma is not symmetric positive definite"; return CESX_ENOTPD; }
+    host_tri_inverse(n, L, Li);
+    host_spd_inverse(n, Li, inv);
+    e.diag_gamma = is_diagonal(n, Gamma);
+    std::vector<double> gw(n);
+    for (int i = 0; i < n; ++i) gw[i] = 1.0 / Gamma[(size_t)i * n + i];
+    TRY(upload(e, e.d_y, y, n * 8)); TRY(upload(e, e.d_Gamma, Gamma, (size_t)n * n * 8));
+    TRY(upload(e, e.d_Ginv, inv.data(), (size_t)n * n * 8)); TRY(upload(e, e.d_gw, gw.data(), n * 8));
+    TRY(upload(e, e.d_Wh, Li.data(), (size_t)n * n * 8));
+    TRY(upload_T(e, e.d_yT, y, n)); TRY(upload_T(e, e.d_gwT, gw.data(), n));
+    TRY(upload_T(e, e.d_GinvT, inv.data(), (size_t)n * n));
+    if (!host_chol(p, Sigma, L)) { e.err = "Sigma is not symmetric positive definite"; return CESX_ENOTPD; }
+    host_tri_inverse(p, L, Li);
+    host_spd_inverse(p, Li, inv);
+    e.diag_sigma = is_diagonal(p, Sigma);
+    std::vector<double> sw(p);
+    for (int i = 0; i < p; ++i) sw[i] = 1.0 / Sigma[(size_t)i * p + i];
+    TRY(upload(e, e.d_mu, mu, p * 8)); TRY(upload(e, e.d_ustar, ustar, p * 8));
+    TRY(upload(e, e.d_Sigma, Sigma, (size_t)p * p * 8)); TRY(upload(e, e.d_Sinv, inv.data(), (size_t)p * p * 8));
+    TRY(upload(e, e.d_sw, sw.data(), p * 8));
+    e.problem_set = true;
+    e.shift_valid = false;
+    return CESX_OK;
+}
+
+size_t cesx_moments_len(cesx_handle h) { return h ? reinterpret_cast<Engine*>(h)->mom_len : 0; }
+
+int cesx_colsum(cesx_handle h, const void* U, const void* G, double* sums, void* stream) {
+    if (!h) return CESX_EINVAL;
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    if (!U || !G || !sums) { e.err = "cesx_colsum: null pointer"; return CESX_EINVAL; }
+    TRY(set_device(e));
+    return launch_colsum(e, U, G, sums, (hipStream_t)stream);
+}
+
+int cesx_set_shift(cesx_handle h, const double* sums, void* stream) {
+    if (!h) return CESX_EINVAL;
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    if (!sums) { e.err = "cesx_set_shift: null pointer"; return CESX_EINVAL; }
+    TRY(set_device(e));
+    return launch_set_shift(e, sums, (hipStream_t)stream);
+}
+
+int cesx_moments(cesx_handle h, const void* U, const void* G, double* mom, void* stream) {
+    if (!h) return CESX_EINVAL;
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    if (!U || !G || !mom) { e.err = "cesx_moments: null pointer"; return CESX_EINVAL; }
+    if (!e.problem_set) { e.err = "cesx_set_problem has not been called"; return CESX_ESTATE; }
+    if (!e.shift_valid) { e.err = "no centring shift: call cesx_colsum + cesx_set_shift (or cesx_step with recenter) first"; return CESX_ESTATE; }
+    TRY(set_device(e));
+    hipStream_t s = (hipStream_t)stream;
+    TRY(launch_stats(e, U, G, mom, s));
+    return launch_gram(e, U, G, mom, s);
+}
+
+int cesx_apply_drift(cesx_handle h, const cesx_step_params* prm, const double* mom, const void* U,
+                     const void* G, void* Unext, double* absmax, void* stream) {
+    if (!h) return CESX_EINVAL;
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    TRY(check_prm(e, prm));
+    if (!mom || !U || !G || !Unext || !absmax) { e.err = "cesx_apply_drift: null pointer"; return CESX_EINVAL; }
+    TRY(set_device(e));
+    hipStream_t s = (hipStream_t)stream;
+    TRY(launch_dense(e, *prm, mom, 1, s));
+    UpdateSrc src[2] = {{U, e.p, 0}, {G, e.n, 0}};
+    TRY(launch_update(e, e.p, e.d_W, e.kp + e.kn, e.d_bias, src, 2, nullptr, nullptr, 0.0, nullptr, nullptr, 0.0,
+                      Unext, e.d_absmax_part, prm->step_index, s));
+    return launch_absmax_final(e, update_grid_blocks(e, e.p), absmax, s);
+}
+
+int cesx_apply_finish(cesx_handle h, const cesx_step_params* prm, const double* absmax, const void* U,
+                      const void* xi, void* Unext, void* stream) {
+    if (!h) return CESX_EINVAL;
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    TRY(check_prm(e, prm));
+    if (!absmax || !U || !Unext) { e.err = "cesx_apply_finish: null pointer"; return CESX_EINVAL; }
+    TRY(set_device(e));
+    hipStream_t s = (hipStream_t)stream;
+    if (absmax != e.d_absmax) CESX_HIP(hipMemcpyAsync(e.d_absmax, absmax, 8, hipMemcpyDeviceToDevice, s));
+    TRY(launch_dense(e, *prm, nullptr, 2, s));
+    // U_next = sqrt(2hk) L xi + 1 * U + hk * drift   (drift currently lives in U_next)
+    UpdateSrc src[1] = {{xi, e.p, xi ? 0 : 1}};
+    TRY(launch_update(e, e.p, e.d_W, e.kp, nullptr, src, 1, U, nullptr, 1.0, Unext, &e.d_scal->hk, 1.0, Unext,
+                      nullptr, prm->step_index, s));
+    return finish_step(e, *prm, s);
+}
+
+int cesx_apply(cesx_handle h, const cesx_step_params* prm, const double* mom, const void* U, const void* G,
+               const void* xi, void* Unext, void* stream) {
+    if (!h) return CESX_EINVAL;
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    TRY(check_prm(e, prm));
+    if (!mom || !U || !G || !Unext) { e.err = "cesx_apply: null pointer"; return CESX_EINVAL; }
+    if (U == Unext) { e.err = "U_next must not alias U (ces/calibrate.py:357 keeps U0 in the trace)"; return CESX_EINVAL; }
+    if (prm->update == CESX_UPDATE_ALDI_CONSTANT) {
+        TRY(cesx_apply_drift(h, prm, mom, U, G, Unext, e.d_absmax, stream));
+        return cesx_apply_finish(h, prm, e.d_absmax, U, xi, Unext, stream);
+    }
+    TRY(set_device(e));
+    hipStream_t s = (hipStream_t)stream;
+    TRY(launch_dense(e, *prm, mom, 0, s));
+    TRY(run_update_main(e, *prm, U, G, xi, Unext, s));
+    return finish_step(e, *prm, s);
+}
+
+int cesx_step(cesx_handle h, const cesx_step_params* prm, const void* U, const void* G, const void* xi,
+              void* Unext, int recenter, void* stream) {
+    if (!h) return CESX_EINVAL;
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    TRY(check_prm(e, prm));
+    if (!U || !G || !Unext) { e.err = "cesx_step: null pointer"; return CESX_EINVAL; }
+    if (e.J != e.Jg) { e.err = "cesx_step is single-device: use cesx_moments / all-reduce / cesx_apply for a sharded ensemble"; return CESX_ESTATE; }
+    if (U == Unext) { e.err = "U_next must not alias U (ces/calibrate.py:357 keeps U0 in the trace)"; return CESX_EINVAL; }
+    if (recenter || !e.shift_valid) {
+        TRY(cesx_colsum(h, U, G, e.d_sums, stream));
+        TRY(cesx_set_shift(h, e.d_sums, stream));
+    }
+    TRY(cesx_moments(h, U, G, e.d_mom, stream));
+    return cesx_apply(h, prm, e.d_mom, U, G, xi, Unext, stream);
+}
+
+int cesx_result(cesx_handle h, cesx_step_result* out) {
+    if (!h) return CESX_EINVAL;
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    if (!out) { e.err = "cesx_result: null pointer"; return CESX_EINVAL; }
+    if (!e.pending) { e.err = "cesx_result: no step has been enqueued"; return CESX_ESTATE; }
+    CESX_HIP(hipEventSynchronize(e.ev));
+    const Scalars& sc = *e.h_scal;
+    out->hk = sc.hk; out->t_new = sc.t_new;
+    out->self_bias = sc.self_bias; out->self_bias_data = sc.self_bias_data;
+    out->bias_data = sc.bias_data; out->bias = sc.bias;
+    out->radspec = sc.radspec; out->status = sc.status; out->reserved = 0;
+    if (sc.status == CESX_ENOTPD) {
+        e.err = "ensemble covariance is not positive definite (Cholesky failed)";
+        return CESX_ENOTPD;
+    }
+    return CESX_OK;
+}
+
+int cesx_draw_noise(cesx_handle h, uint64_t step_index, void* xi, void* stream) {
+    if (!h) return CESX_EINVAL;
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    if (!xi) { e.err = "cesx_draw_noise: null pointer"; return CESX_EINVAL; }
+    TRY(set_device(e));
+    return launch_noise(e, step_index, xi, (hipStream_t)stream);
+}
+
+int cesx_forward_lineal(cesx_handle h, const void* A, const void* b, const void* U, void* G, void* stream) {
+    if (!h) return CESX_EINVAL;
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    if (!A || !U || !G) { e.err = "cesx_forward_lineal: null pointer"; return CESX_EINVAL; }
+    TRY(set_device(e));
+    hipStream_t s = (hipStream_t)stream;
+    // stage A (n x p) into the zero-padded (rpad x kp) layout the update kernel reads
+    CESX_HIP(hipMemsetAsync(e.d_Wfwd, 0, (size_t)e.rpad * e.kp * e.esz, s));
+    CESX_HIP(hipMemcpy2DAsync(e.d_Wfwd, (size_t)e.kp * e.esz, A, (size_t)e.p * e.esz, (size_t)e.p * e.esz, e.n,
+                              hipMemcpyDeviceToDevice, s));
+    UpdateSrc src[1] = {{U, e.p, 0}};
+    return launch_update(e, e.n, e.d_Wfwd, e.kp, b, src, 1, nullptr, nullptr, 0.0, nullptr, nullptr, 0.0, G,
+                         nullptr, 0, s);
+}
+
+int cesx_debug_dense(cesx_handle h, double* ubar, double* gbar, double* C, double* L, double* K, double* M) {
+    if (!h) return CESX_EINVAL;
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    TRY(set_device(e));
+    CESX_HIP(hipDeviceSynchronize());
+    const size_t p = e.p, n = e.n;
+    if (ubar) CESX_HIP(hipMemcpy(ubar, e.d_ubar, p * 8, hipMemcpyDeviceToHost));
+    if (gbar) CESX_HIP(hipMemcpy(gbar, e.d_gbar, n * 8, hipMemcpyDeviceToHost));
+    if (C) CESX_HIP(hipMemcpy(C, e.d_C, p * p * 8, hipMemcpyDeviceToHost));
+    if (L) CESX_HIP(hipMemcpy(L, e.d_L, p * p * 8, hipMemcpyDeviceToHost));
+    if (K) CESX_HIP(hipMemcpy(K, e.d_K, p * n * 8, hipMemcpyDeviceToHost));
+    if (M) CESX_HIP(hipMemcpy(M, e.d_M, p * p * 8, hipMemcpyDeviceToHost));
+    return CESX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,676 @@
+// K2 -- the small dense algebra between the two O(J) passes, all in fp64 and
+// entirely on device (no host round trip inside a step):
+//   centring of the summed moments             ces/calibrate.py:423-428, :459-460, :475-476
+//   metrics                                     :432-435 / :464-467 / :506-509
+//   time step                                   :243-267 (||D||_F and eig(D) from n x n moments)
+//   C = cov(U) + 1e-8 I, L = chol(C)            :424/:476/:512, :446/:487/:526
+//   K = C_ug Gamma^{-1} (or (hk C_gg + Gamma)^{-1})   :429/:461, :439-441/:470-473
+//   M = C Sigma^{-1},  P = (I + hk M)^{-1}      :443, :485
+//   assembly of W, b for the K3 update GEMM     :443-447, :484-488, :515-527
+// p, n are a few hundred: these kernels are latency bound, not roofline bound.
+#include "cesx_internal.h"
+
+namespace cesx {
+
+constexpr int NPB = 64;          // partial-sum blocks
+constexpr int DT = 256;
+
+__device__ __forceinline__ double dblock_sum(double v, double* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
+    return s;   // valid on every thread
+}
+
+struct MomView {
+    int p, n;
+    const double* mom;
+    __device__ double N() const { return mom[0]; }
+    __device__ const double* sa() const { return mom + 1; }
+    __device__ const double* sb() const { return mom + 1 + p; }
+    __device__ const double* Saa() const { return mom + 1 + p + n; }
+    __device__ const double* Sab() const { return Saa() + (size_t)p * p; }
+    __device__ const double* Sbb() const { return Sab() + (size_t)p * n; }
+    __device__ const double* q() const { return Sbb() + (size_t)n * n; }   // [mq_r2, mq_e2, sq_e, vqb[n]]
+};
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(DT)
+void center_kernel(MomView mv, const double* __restrict__ shift, const double* __restrict__ y,
+                   const double* __restrict__ ustar, const double* __restrict__ gw, int unbiased,
+                   double* __restrict__ ubar, double* __restrict__ gbar, double* __restrict__ mvec,
+                   double* __restrict__ dg, double* __restrict__ C, double* __restrict__ Cug,
+                   double* __restrict__ See, double* __restrict__ Srr, double* __restrict__ part) {
+    __shared__ double red[DT / 64];
+    const int p = mv.p, n = mv.n;
+    const double N = mv.N();
+    const double div = unbiased ? N - 1.0 : N;
+    const double* sa = mv.sa();
+    const double* sb = mv.sb();
+    const long long pp = (long long)p * p, pn = (long long)p * n, nn = (long long)n * n;
+    const long long gid = (long long)blockIdx.x * DT + threadIdx.x, gsz = (long long)gridDim.x * DT;
+    double tr = 0.0, b2 = 0.0, fr = 0.0;
+    for (long long idx = gid; idx < pp + pn + nn; idx += gsz) {
+        if (idx < pp) {
+            const int i = (int)(idx / p), j = (int)(idx % p);
+            const double suu = mv.Saa()[idx] - sa[i] * sa[j] / N;
+            C[idx] = suu / div + (i == j ? 1e-8 : 0.0);
+            if (i == j) tr += suu;
+        } else if (idx < pp + pn) {
+            const long long k = idx - pp;
+            const int i = (int)(k / n), j = (int)(k % n);
+            Cug[k] = (mv.Sab()[k] - sa[i] * sb[j] / N) / N;
+        } else {
+            const long long k = idx - pp - pn;
+            const int i = (int)(k / n), j = (int)(k % n);
+            const double see = mv.Sbb()[k] - sb[i] * sb[j] / N;
+            const double mi = shift[p + i] + sb[i] / N - y[i], mj = shift[p + j] + sb[j] / N - y[j];
+            const double srr = see + N * mi * mj;
+            See[k] = see;
+            Srr[k] = srr;
+            if (gw) fr += see * srr * gw[i] * gw[j];
+        }
+    }
+    for (long long i = gid; i < p + n; i += gsz) {
+        if (i < p) {
+            const double ub = shift[i] + sa[i] / N;
+            ubar[i] = ub;
+            b2 += (ub - ustar[i]) * (ub - ustar[i]);
+        } else {
+            const int k = (int)(i - p);
+            const double d = sb[k] / N;
+            gbar[k] = shift[p + k] + d;
+            dg[k] = d;
+            mvec[k] = shift[p + k] + d - y[k];
+        }
+    }
+    tr = dblock_sum(tr, red);
+    b2 = dblock_sum(b2, red);
+    fr = dblock_sum(fr, red);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 4 + 0] = tr;
+        part[blockIdx.x * 4 + 1] = b2;
+        part[blockIdx.x * 4 + 2] = fr;
+    }
+}
+
+// part[blk*4 + 2] = sum A .* B   (dense-Gamma Frobenius term)
+__global__ __launch_bounds__(DT)
+void dot_kernel(const double* __restrict__ A, const double* __restrict__ B, long long len,
+                double* __restrict__ part) {
+    __shared__ double red[DT / 64];
+    double s = 0.0;
+    for (long long i = (long long)blockIdx.x * DT + threadIdx.x; i < len; i += (long long)gridDim.x * DT)
+        s += A[i] * B[i];
+    s = dblock_sum(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x * 4 + 2] = s;
+}
+
+// out[i][j] = A[i][j] * w[j]
+__global__ void scale_cols_kernel(int rows, int cols, const double* __restrict__ A,
+                                  const double* __restrict__ w, double* __restrict__ out) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long long)rows * cols) out[idx] = A[idx] * w[idx % cols];
+}
+
+// C(m x n) = alpha * A(m x k) * B(k x n) with arbitrary element strides
+__global__ __launch_bounds__(DT)
+void gemm_kernel(int m, int n, int k, double alpha, const double* __restrict__ A, long long a0, long long a1,
+                 const double* __restrict__ B, long long b0, long long b1, double* __restrict__ Cm, int ldc) {
+    __shared__ double sA[32][33], sB[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // ty in 0..7
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    double acc[4] = {0, 0, 0, 0};
+    for (int k0 = 0; k0 < k; k0 += 32) {
+        for (int r = ty; r < 32; r += 8) {
+            const int ia = i0 + r, ka = k0 + tx;
+            sA[r][tx] = (ia < m && ka < k) ? A[ia * a0 + ka * a1] : 0.0;
+            const int kb = k0 + r, jb = j0 + tx;
+            sB[r][tx] = (kb < k && jb < n) ? B[kb * b0 + jb * b1] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int kk = 0; kk < 32; ++kk) {
+            const double b = sB[kk][tx];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] += sA[ty + 8 * r][kk] * b;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + ty + 8 * r, j = j0 + tx;
+        if (i < m && j < n) Cm[(size_t)i * ldc + j] = alpha * acc[r];
+    }
+}
+
+// out[r] = sum_c A[r][c] x[c]   (one wave per row)
+__global__ __launch_bounds__(DT)
+void matvec_kernel(int rows, int cols, const double* __restrict__ A, const double* __restrict__ x,
+                   double* __restrict__ out) {
+    const int row = blockIdx.x * (DT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    double s = 0.0;
+    for (int c = lane; c < cols; c += 64) s += A[(size_t)row * cols + c] * x[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (lane == 0) out[row] = s;
+}
+
+// ---------------------------------------------------------------------------
+// Cholesky A = L L^T of an n x n SPD matrix, one workgroup, blocked
+// right-looking with the current panel in LDS.  L gets the lower factor and a
+// zero strict upper triangle.  A non-positive pivot sets *status = CESX_ENOTPD
+// (np.linalg.LinAlgError at ces/calibrate.py:446/:487/:526).
+// ---------------------------------------------------------------------------
+constexpr int PT = 1024;   // threads
+
+__global__ __launch_bounds__(PT)
+void potrf_kernel(int n, const double* __restrict__ A, double* __restrict__ L, int nb, int* status) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ldp = nb + 1;
+    double* D = reinterpret_cast<double*>(smem);          // [nb][ldp] diagonal block
+    double* Pn = D + nb * ldp;                            // [n][ldp] panel below it
+    const int tid = threadIdx.x;
+    // L <- lower(A), upper <- 0
+    for (long long idx = tid; idx < (long long)n * n; idx += PT) {
+        const int i = (int)(idx / n), j = (int)(idx % n);
+        L[idx] = j <= i ? A[idx] : 0.0;
+    }
+    __syncthreads();
+    for (int kb = 0; kb < n; kb += nb) {
+        const int w = min(nb, n - kb);
+        const int m = n - kb - w;                         // rows below the diagonal block
+        for (int idx = tid; idx < w * w; idx += PT) {
+            const int i = idx / w, j = idx % w;
+            D[i * ldp + j] = L[(size_t)(kb + i) * n + kb + j];
+        }
+        __syncthreads();
+        // unblocked factorisation of the w x w diagonal block (first w threads, row i each)
+        for (int j = 0; j < w; ++j) {
+            if (tid == 0) {
+                double d = D[j * ldp + j];
+                if (!(d > 0.0)) { *status = CESX_ENOTPD; d = 1.0; }
+                D[j * ldp + j] = sqrt(d);
+            }
+            __syncthreads();
+            if (tid > j && tid < w) {
+                const double lij = D[tid * ldp + j] / D[j * ldp + j];
+                D[tid * ldp + j] = lij;
+            }
+            __syncthreads();
+            if (tid > j && tid < w) {
+                const double lij = D[tid * ldp + j];
+                for (int k = j + 1; k <= tid; ++k) D[tid * ldp + k] -= lij * D[k * ldp + j];
+            }
+            __syncthreads();
+        }
+        for (int idx = tid; idx < w * w; idx += PT) {
+            const int i = idx / w, j = idx % w;
+            if (j <= i) L[(size_t)(kb + i) * n + kb + j] = D[i * ldp + j];
+        }
+        // panel: rows below solve x D^T = a
+        for (int r = tid; r < m; r += PT) {
+            double* row = L + (size_t)(kb + w + r) * n + kb;
+            for (int j = 0; j < w; ++j) {
+                double s = row[j];
+                for (int k = 0; k < j; ++k) s -= Pn[r * ldp + k] * D[j * ldp + k];
+                s /= D[j * ldp + j];
+                Pn[r * ldp + j] = s;
+            }
+            for (int j = 0; j < w; ++j) row[j] = Pn[r * ldp + j];
+        }
+        __syncthreads();
+        // trailing update A22 -= Pn Pn^T (lower part), 4 x 4 patches
+        const int mb = (m + 3) / 4;
+        for (int pt = tid; pt < mb * mb; pt += PT) {
+            const int bi = pt / mb, bj = pt % mb;
+            if (bj > bi) continue;
+            double acc[4][4] = {};
+            for (int k = 0; k < w; ++k) {
+                double a[4], b[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a[e] = (bi * 4 + e < m) ? Pn[(bi * 4 + e) * ldp + k] : 0.0;
+                    b[e] = (bj * 4 + e < m) ? Pn[(bj * 4 + e) * ldp + k] : 0.0;
+                }
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int z = 0; z < 4; ++z) acc[x][z] += a[x] * b[z];
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int z = 0; z < 4; ++z) {
+                    const int i = bi * 4 + x, j = bj * 4 + z;
+                    if (i < m && j <= i) L[(size_t)(kb + w + i) * n + kb + w + j] -= acc[x][z];
+                }
+        }
+        __syncthreads();
+    }
+}
+
+// Linv = L^{-1} for lower-triangular L, one column per thread (forward substitution).
+__global__ __launch_bounds__(PT)
+void trtri_kernel(int n, const double* __restrict__ L, double* __restrict__ Linv) {
+    for (int j = threadIdx.x; j < n; j += PT) {
+        for (int i = 0; i < j; ++i) Linv[(size_t)i * n + j] = 0.0;
+        for (int i = j; i < n; ++i) {
+            double s = (i == j) ? 1.0 : 0.0;
+            for (int k = j; k < i; ++k) s -= L[(size_t)i * n + k] * Linv[(size_t)k * n + j];
+            Linv[(size_t)i * n + j] = s / L[(size_t)i * n + i];
+        }
+    }
+}
+
+// X = a * A + B with a = (*ap) / (*divp)  (both on device; divp may be null)
+__global__ void axpb_kernel(long long len, const double* __restrict__ ap, const double* __restrict__ divp,
+                            const double* __restrict__ A, const double* __restrict__ B,
+                            double* __restrict__ X) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const double a = divp ? (*ap) / (*divp) : (*ap);
+    if (i < len) X[i] = a * A[i] + B[i];
+}
+
+// K <- Kp when the device-side flag says so (constant / late-mix recompute of D,
+// ces/calibrate.py:439-441, :470-473)
+__global__ void select_kernel(long long len, const Scalars* __restrict__ sc, const double* __restrict__ Kp,
+                              double* __restrict__ K) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < len && sc->spare[0] != 0.0) K[i] = Kp[i];
+}
+
+// ---------------------------------------------------------------------------
+// lambda_max of the symmetric PSD matrix B = Wh (See / N) Wh^T (Wh = Gamma^{-1/2}
+// factor, so eig(B) = eig(Gamma^{-1} See / N) = eig(D) \ {0}):
+// Lanczos with full re-orthogonalisation (m steps, one workgroup) followed by
+// bisection on the tridiagonal matrix.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(DT)
+void lanczos_kernel(int n, const double* __restrict__ B, const double* __restrict__ divp, int msteps,
+                    double* __restrict__ V, double* __restrict__ alpha, double* __restrict__ beta,
+                    Scalars* __restrict__ sc) {
+    __shared__ double red[DT / 64];
+    __shared__ double s_val;
+    const int tid = threadIdx.x;
+    // start vector: normalised ones + small ramp (generic direction)
+    double nrm = 0.0;
+    for (int i = tid; i < n; i += DT) { const double v = 1.0 + 0.01 * i; V[i] = v; nrm += v * v; }
+    nrm = dblock_sum(nrm, red);
+    for (int i = tid; i < n; i += DT) V[i] /= sqrt(nrm);
+    __syncthreads();
+    int m = 0;
+    for (int k = 0; k < msteps; ++k) {
+        double* vk = V + (size_t)k * n;
+        double* w = V + (size_t)(k + 1) * n;
+        // w = B vk
+        for (int i = tid; i < n; i += DT) {
+            double s = 0.0;
+            for (int c = 0; c < n; ++c) s += B[(size_t)i * n + c] * vk[c];
+            w[i] = s;
+        }
+        __syncthreads();
+        double a = 0.0;
+        for (int i = tid; i < n; i += DT) a += w[i] * vk[i];
+        a = dblock_sum(a, red);
+        if (tid == 0) alpha[k] = a;
+        // full re-orthogonalisation against v_0..v_k (twice is enough)
+        for (int pass = 0; pass < 2; ++pass)
+            for (int q = 0; q <= k; ++q) {
+                const double* vq = V + (size_t)q * n;
+                double d = 0.0;
+                for (int i = tid; i < n; i += DT) d += w[i] * vq[i];
+                d = dblock_sum(d, red);
+                for (int i = tid; i < n; i += DT) w[i] -= d * vq[i];
+                __syncthreads();
+            }
+        double b = 0.0;
+        for (int i = tid; i < n; i += DT) b += w[i] * w[i];
+        b = sqrt(dblock_sum(b, red));
+        m = k + 1;
+        if (tid == 0) beta[k] = b;
+        if (!(b > 1e-14 * fabs(alpha[0]) + 1e-300)) break;      // invariant subspace found
+        for (int i = tid; i < n; i += DT) w[i] /= b;
+        __syncthreads();
+    }
+    __syncthreads();
+    // largest eigenvalue of tridiag(alpha[0..m), beta[0..m-1)) by bisection (Sturm count)
+    if (tid == 0) {
+        double lo = alpha[0], hi = alpha[0];
+        for (int i = 0; i < m; ++i) {
+            const double bl = i > 0 ? fabs(beta[i - 1]) : 0.0, br = i + 1 < m ? fabs(beta[i]) : 0.0;
+            lo = fmin(lo, alpha[i] - bl - br);
+            hi = fmax(hi, alpha[i] + bl + br);
+        }
+        for (int it = 0; it < 200; ++it) {
+            const double mid = 0.5 * (lo + hi);
+            if (mid == lo || mid == hi) break;
+            // number of eigenvalues < mid
+            int cnt = 0;
+            double d = 1.0;
+            for (int i = 0; i < m; ++i) {
+                const double b2 = i > 0 ? beta[i - 1] * beta[i - 1] : 0.0;
+                d = alpha[i] - mid - (i > 0 ? b2 / d : 0.0);
+                if (d == 0.0) d = 1e-300;
+                if (d < 0.0) ++cnt;
+            }
+            if (cnt >= m) hi = mid; else lo = mid;
+        }
+        s_val = 0.5 * (lo + hi) / (*divp);
+        sc->radspec = s_val > 0.0 ? s_val : 0.0;
+    }
+}
+
+// B = Wh See Wh^T for diagonal Gamma: B_ij = See_ij sqrt(gw_i gw_j)  (1/N applied by the caller)
+__global__ void whiten_diag_kernel(int n, const double* __restrict__ See, const double* __restrict__ gw,
+                                   double* __restrict__ B) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)n * n) return;
+    const int i = (int)(idx / n), j = (int)(idx % n);
+    B[idx] = See[idx] * sqrt(gw[i] * gw[j]);
+}
+
+// ---------------------------------------------------------------------------
+// scalars: metrics, time step, pseudo-time
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(DT)
+void scalar_kernel(MomView mv, cesx_step_params prm, const double* __restrict__ part,
+                   const double* __restrict__ dg, const double* __restrict__ gw,
+                   const double* __restrict__ wdel_dense, Scalars* __restrict__ sc) {
+    __shared__ double red[DT / 64];
+    const int n = mv.n, p = mv.p, tid = threadIdx.x;
+    const double N = mv.N();
+    double tr = 0.0, b2 = 0.0, fr = 0.0;
+    for (int i = tid; i < NPB; i += DT) { tr += part[i * 4]; b2 += part[i * 4 + 1]; fr += part[i * 4 + 2]; }
+    tr = dblock_sum(tr, red);
+    b2 = dblock_sum(b2, red);
+    fr = dblock_sum(fr, red);
+    // re-centre the e-metric from the shift s_g to the exact mean: e_j = b_j - dg,
+    // q(e_j) = q(b_j) - 2 w^T b_j + c,  w = Gamma^{-1} dg,  c = dg^T w
+    const double* Sbb = mv.Sbb();
+    const double* sb = mv.sb();
+    const double* q = mv.q();
+    double c = 0.0, wSw = 0.0, wv = 0.0, wsb = 0.0;
+    for (int i = tid; i < n; i += DT) {
+        const double wi = gw ? gw[i] * dg[i] : wdel_dense[i];
+        c += dg[i] * wi;
+        wv += wi * q[3 + i];
+        wsb += wi * sb[i];
+        double s = 0.0;
+        for (int j = 0; j < n; ++j) s += Sbb[(size_t)i * n + j] * (gw ? gw[j] * dg[j] : wdel_dense[j]);
+        wSw += wi * s;
+    }
+    c = dblock_sum(c, red);
+    wSw = dblock_sum(wSw, red);
+    wv = dblock_sum(wv, red);
+    wsb = dblock_sum(wsb, red);
+    if (tid != 0) return;
+    sc->tr_suu = tr;
+    sc->self_bias = tr / N;
+    sc->bias = tr / N + b2;
+    sc->bias_data = q[0] / N;
+    sc->self_bias_data = (q[1] + 4.0 * wSw + N * c * c - 4.0 * wv + 2.0 * c * q[2] - 4.0 * c * wsb) / N;
+    sc->frob2 = fr;
+    sc->alpha = (p + 1.0) / N;
+    const double frob = sqrt(fr > 0.0 ? fr : 0.0) / N;
+    double hk = 0.0;
+    if (prm.update != CESX_UPDATE_ALDI_CONSTANT) {
+        switch (prm.time_step) {
+            case CESX_TS_DEFAULT: hk = 1.0 / (frob + 1e-8); break;
+            case CESX_TS_SPECTRAL: hk = 1.0 / sc->radspec; break;
+            case CESX_TS_CONSTANT: hk = prm.delta_t; break;
+            case CESX_TS_MIX:
+                hk = (prm.t_len == 0 || prm.t_last < prm.spinup) ? 1.0 / (frob + 1e-8) : prm.delta_t;
+                break;
+            default: hk = 0.0;
+        }
+        sc->hk = hk;
+        sc->sqrt2hk = sqrt(2.0 * hk);
+        sc->t_new = prm.first_step ? hk : hk + prm.t_last;
+        bool kp = prm.time_step == CESX_TS_CONSTANT;
+        if (prm.update == CESX_UPDATE_ALDI && prm.time_step == CESX_TS_MIX && sc->t_new > 1.0) kp = true;
+        sc->spare[0] = kp ? 1.0 : 0.0;
+    }
+}
+
+// hk = 0.1 / max|drift| (ces/calibrate.py:519-523)
+__global__ void constant_hk_kernel(cesx_step_params prm, const double* __restrict__ absmax,
+                                   Scalars* __restrict__ sc) {
+    const double hk = 0.1 / absmax[0];
+    sc->absmax = absmax[0];
+    sc->hk = hk;
+    sc->sqrt2hk = sqrt(2.0 * hk);
+    sc->t_new = prm.first_step ? hk : hk + prm.t_last;
+}
+
+// ---------------------------------------------------------------------------
+// assembly of W (rpad x ktot, zero padded) and bias in the engine dtype
+//   mode 0 ALDI        W = [ (1 + hk a) I - hk M | -hk K | sqrt(2hk) L ],  b = hk (Ky + M mu - a ubar)
+//   mode 1 EKS         W = [ P | -hk PK | sqrt(2hk) L ],                   b = P hk (Ky + M mu)   (= Pv)
+//   mode 2 ALDI-const drift   W = [ sw a I - M | -K ],                     b = Ky + M mu - sw a ubar
+//   mode 3 ALDI-const noise   W = [ sqrt(2hk) L ]
+// and the next centring shift (predicted mean for ALDI, current mean otherwise).
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void assemble_kernel(int mode, int p, int n, int kp, int kn, int rpad, int ktot, double sw,
+                                const Scalars* __restrict__ sc, const double* __restrict__ M,
+                                const double* __restrict__ K, const double* __restrict__ L,
+                                const double* __restrict__ P, const double* __restrict__ PK,
+                                const double* __restrict__ mvs, int mx, const double* __restrict__ ubar,
+                                const double* __restrict__ gbar, T* __restrict__ W, T* __restrict__ bias,
+                                T* __restrict__ shiftT, double* __restrict__ shift64) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const double hk = sc->hk, s2 = sc->sqrt2hk, al = sc->alpha;
+    const double* Ky = mvs;            // K y
+    const double* Kg = mvs + mx;       // K gbar
+    const double* Mm = mvs + 2 * mx;   // M mu
+    const double* Mu = mvs + 3 * mx;   // M ubar
+    const double* Pv = mvs + 4 * mx;   // P (hk (Ky + M mu))
+    if (idx < (long long)rpad * ktot) {
+        const int i = (int)(idx / ktot), k = (int)(idx % ktot);
+        double v = 0.0;
+        if (i < p) {
+            if (mode == 3) {
+                if (k < p && k <= i) v = s2 * L[(size_t)i * p + k];
+            } else if (k < kp) {
+                if (k < p) {
+                    if (mode == 0) v = (i == k ? 1.0 + hk * al : 0.0) - hk * M[(size_t)i * p + k];
+                    else if (mode == 1) v = P[(size_t)i * p + k];
+                    else v = (i == k ? sw * al : 0.0) - M[(size_t)i * p + k];
+                }
+            } else if (k < kp + kn) {
+                const int c = k - kp;
+                if (c < n) {
+                    if (mode == 0) v = -hk * K[(size_t)i * n + c];
+                    else if (mode == 1) v = -hk * PK[(size_t)i * n + c];
+                    else v = -K[(size_t)i * n + c];
+                }
+            } else {
+                const int c = k - kp - kn;
+                if (c < p && c <= i && mode != 2) v = s2 * L[(size_t)i * p + c];
+            }
+        }
+        W[idx] = (T)v;
+    }
+    if (idx < rpad) {
+        const int i = (int)idx;
+        double b = 0.0;
+        if (i < p) {
+            if (mode == 0) b = hk * (Ky[i] + Mm[i] - al * ubar[i]);
+            else if (mode == 1) b = Pv[i];
+            else if (mode == 2) b = Ky[i] + Mm[i] - sw * al * ubar[i];
+        }
+        bias[i] = (T)b;
+    }
+    if (idx < p + n && mode != 3) {
+        const int i = (int)idx;
+        double s;
+        if (i < p) {
+            s = ubar[i];
+            if (mode == 0) s += -hk * (Mu[i] - Mm[i]) - hk * (Kg[i] - Ky[i]);
+        } else {
+            s = gbar[i - p];
+        }
+        const T st = (T)s;
+        shiftT[i] = st;
+        shift64[i] = (double)st;
+    }
+}
+
+// v = hk * (a + b)
+__global__ void hk_sum_kernel(int len, const Scalars* __restrict__ sc, const double* __restrict__ a,
+                              const double* __restrict__ b, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < len) out[i] = sc->hk * (a[i] + b[i]);
+}
+
+__global__ void init_scalars_kernel(Scalars* sc) {
+    sc->status = CESX_OK;
+    sc->radspec = 0.0;
+    sc->spare[0] = 0.0;
+    sc->absmax = 0.0;
+}
+
+// ---------------------------------------------------------------------------
+// host orchestration
+// ---------------------------------------------------------------------------
+static inline dim3 g1(long long len, int bs = 256) { return dim3((unsigned)((len + bs - 1) / bs)); }
+
+static int gemm(Engine& e, hipStream_t s, int m, int n, int k, double alpha, const double* A, long long a0,
+                long long a1, const double* B, long long b0, long long b1, double* C) {
+    hipLaunchKernelGGL(gemm_kernel, dim3((n + 31) / 32, (m + 31) / 32), dim3(DT), 0, s, m, n, k, alpha, A, a0,
+                       a1, B, b0, b1, C, n);
+    CESX_HIP(hipGetLastError());
+    return CESX_OK;
+}
+
+static int potrf(Engine& e, hipStream_t s, int n, const double* A, double* L) {
+    int nb = 32;
+    while (nb > 4 && (size_t)(n + nb) * (nb + 1) * 8 > 150 * 1024) nb /= 2;
+    const size_t lds = (size_t)(n + nb) * (nb + 1) * 8;
+    if (lds > 160 * 1024) { e.err = "potrf: matrix too large for the single-workgroup kernel"; return CESX_EINVAL; }
+    CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(potrf_kernel, dim3(1), dim3(PT), lds, s, n, A, L, nb, &e.d_scal->status);
+    CESX_HIP(hipGetLastError());
+    return CESX_OK;
+}
+
+// Ainv = A^{-1} for SPD A (n x n); uses t1 (chol), t2 (tri inverse)
+static int spd_inverse(Engine& e, hipStream_t s, int n, const double* A, double* Ainv) {
+    int rc;
+    if ((rc = potrf(e, s, n, A, e.d_t1))) return rc;
+    hipLaunchKernelGGL(trtri_kernel, dim3(1), dim3(PT), 0, s, n, e.d_t1, e.d_t2);
+    CESX_HIP(hipGetLastError());
+    // Ainv = Linv^T Linv : A(i,k) = Linv[k][i]
+    return gemm(e, s, n, n, n, 1.0, e.d_t2, 1, n, e.d_t2, n, 1, Ainv);
+}
+
+template <typename T>
+static int assemble(Engine& e, hipStream_t s, int mode, int ktot, double sw) {
+    const int mx = e.p > e.n ? e.p : e.n;
+    const long long len = (long long)e.rpad * ktot;
+    hipLaunchKernelGGL(assemble_kernel<T>, g1(len), dim3(256), 0, s, mode, e.p, e.n, e.kp, e.kn, e.rpad, ktot,
+                       sw, e.d_scal, e.d_M, e.d_K, e.d_L, e.d_P, e.d_PK, e.d_mv, mx, e.d_ubar, e.d_gbar,
+                       (T*)e.d_W, (T*)e.d_bias, (T*)e.d_shiftT, e.d_shift64);
+    CESX_HIP(hipGetLastError());
+    return CESX_OK;
+}
+
+// phase 0: everything for eks / aldi.  phase 1: aldi_constant drift coefficients.
+// phase 2: aldi_constant noise coefficients after hk is known.
+int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int phase, hipStream_t s) {
+    const int p = e.p, n = e.n, mx = p > n ? p : n;
+    const bool f32 = e.cfg.dtype == CESX_F32;
+    int rc;
+    if (phase == 2) {
+        hipLaunchKernelGGL(constant_hk_kernel, dim3(1), dim3(1), 0, s, prm, e.d_absmax, e.d_scal);
+        CESX_HIP(hipGetLastError());
+        return f32 ? assemble<float>(e, s, 3, e.kp, 0.0) : assemble<double>(e, s, 3, e.kp, 0.0);
+    }
+    MomView mv{p, n, mom};
+    hipLaunchKernelGGL(init_scalars_kernel, dim3(1), dim3(1), 0, s, e.d_scal);
+    const int unbiased = prm.update == CESX_UPDATE_EKS ? 0 : 1;
+    hipLaunchKernelGGL(center_kernel, dim3(NPB), dim3(DT), 0, s, mv, e.d_shift64, e.d_y, e.d_ustar,
+                       e.diag_gamma ? e.d_gw : (const double*)nullptr, unbiased, e.d_ubar, e.d_gbar, e.d_m,
+                       e.d_dg, e.d_C, e.d_Cug, e.d_See, e.d_Srr, e.d_part);
+    CESX_HIP(hipGetLastError());
+    if (!e.diag_gamma) {
+        // Frobenius term <Ginv Srr Ginv, See> and w = Ginv dg
+        if ((rc = gemm(e, s, n, n, n, 1.0, e.d_Ginv, n, 1, e.d_Srr, n, 1, e.d_t1))) return rc;
+        if ((rc = gemm(e, s, n, n, n, 1.0, e.d_t1, n, 1, e.d_Ginv, n, 1, e.d_t2))) return rc;
+        hipLaunchKernelGGL(dot_kernel, dim3(NPB), dim3(DT), 0, s, e.d_t2, e.d_See, (long long)n * n, e.d_part);
+        hipLaunchKernelGGL(matvec_kernel, g1(n, 4), dim3(DT), 0, s, n, n, e.d_Ginv, e.d_dg, e.d_wdel);
+        CESX_HIP(hipGetLastError());
+    }
+    if ((rc = potrf(e, s, p, e.d_C, e.d_L))) return rc;
+    // gain and prior coupling
+    if (e.diag_gamma)
+        hipLaunchKernelGGL(scale_cols_kernel, g1((long long)p * n), dim3(256), 0, s, p, n, e.d_Cug, e.d_gw, e.d_K);
+    else if ((rc = gemm(e, s, p, n, n, 1.0, e.d_Cug, n, 1, e.d_Ginv, n, 1, e.d_K))) return rc;
+    if (e.diag_sigma)
+        hipLaunchKernelGGL(scale_cols_kernel, g1((long long)p * p), dim3(256), 0, s, p, p, e.d_C, e.d_sw, e.d_M);
+    else if ((rc = gemm(e, s, p, p, p, 1.0, e.d_C, p, 1, e.d_Sinv, p, 1, e.d_M))) return rc;
+    CESX_HIP(hipGetLastError());
+    if (prm.time_step == CESX_TS_SPECTRAL && prm.update != CESX_UPDATE_ALDI_CONSTANT) {
+        // B = Wh (See/N) Wh^T, symmetric PSD, same non-zero spectrum as D
+        if (e.diag_gamma) {
+            hipLaunchKernelGGL(whiten_diag_kernel, g1((long long)n * n), dim3(256), 0, s, n, e.d_See, e.d_gw, e.d_t3);
+        } else {
+            // Wh = chol(Gamma)^{-1} (lower): B = Wh See Wh^T
+            if ((rc = gemm(e, s, n, n, n, 1.0, e.d_Wh, n, 1, e.d_See, n, 1, e.d_t1))) return rc;
+            if ((rc = gemm(e, s, n, n, n, 1.0, e.d_t1, n, 1, e.d_Wh, 1, n, e.d_t3))) return rc;
+        }
+        const int msteps = n < e.lanczos_steps ? n : e.lanczos_steps;
+        hipLaunchKernelGGL(lanczos_kernel, dim3(1), dim3(DT), 0, s, n, e.d_t3, mom, msteps, e.d_lanczos,
+                           e.d_lanczos + (size_t)(msteps + 1) * n, e.d_lanczos + (size_t)(msteps + 1) * n + msteps,
+                           e.d_scal);
+        CESX_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(scalar_kernel, dim3(1), dim3(DT), 0, s, mv, prm, e.d_part, e.d_dg,
+                       e.diag_gamma ? e.d_gw : (const double*)nullptr, e.d_wdel, e.d_scal);
+    CESX_HIP(hipGetLastError());
+
+    if (phase == 0 && (prm.time_step == CESX_TS_CONSTANT || (prm.time_step == CESX_TS_MIX && prm.update == CESX_UPDATE_ALDI))) {
+        // K' = C_ug (hk C_gg + Gamma)^{-1},  C_gg = See / N   (:440-441, :472-473)
+        hipLaunchKernelGGL(axpb_kernel, g1((long long)n * n), dim3(256), 0, s, (long long)n * n, &e.d_scal->hk,
+                           mom, e.d_See, e.d_Gamma, e.d_t3);
+        CESX_HIP(hipGetLastError());
+        if ((rc = spd_inverse(e, s, n, e.d_t3, e.d_t4))) return rc;
+        if ((rc = gemm(e, s, p, n, n, 1.0, e.d_Cug, n, 1, e.d_t4, n, 1, e.d_Kp))) return rc;
+        hipLaunchKernelGGL(select_kernel, g1((long long)p * n), dim3(256), 0, s, (long long)p * n, e.d_scal, e.d_Kp, e.d_K);
+        CESX_HIP(hipGetLastError());
+    }
+    // matvecs: K y, K gbar, M mu, M ubar
+    hipLaunchKernelGGL(matvec_kernel, g1(p, 4), dim3(DT), 0, s, p, n, e.d_K, e.d_y, e.d_mv);
+    hipLaunchKernelGGL(matvec_kernel, g1(p, 4), dim3(DT), 0, s, p, n, e.d_K, e.d_gbar, e.d_mv + mx);
+    hipLaunchKernelGGL(matvec_kernel, g1(p, 4), dim3(DT), 0, s, p, p, e.d_M, e.d_mu, e.d_mv + 2 * mx);
+    hipLaunchKernelGGL(matvec_kernel, g1(p, 4), dim3(DT), 0, s, p, p, e.d_M, e.d_ubar, e.d_mv + 3 * mx);
+    CESX_HIP(hipGetLastError());
+
+    int mode = 0;
+    if (phase == 1) mode = 2;
+    else if (prm.update == CESX_UPDATE_EKS) {
+        mode = 1;
+        // P = Sigma (Sigma + hk C)^{-1}  ( = (I + hk C Sigma^{-1})^{-1}, :443 )
+        hipLaunchKernelGGL(axpb_kernel, g1((long long)p * p), dim3(256), 0, s, (long long)p * p, &e.d_scal->hk,
+                           (const double*)nullptr, e.d_C, e.d_Sigma, e.d_t3);
+        CESX_HIP(hipGetLastError());
+        if ((rc = spd_inverse(e, s, p, e.d_t3, e.d_t4))) return rc;
+        if ((rc = gemm(e, s, p, p, p, 1.0, e.d_Sigma, p, 1, e.d_t4, p, 1, e.d_P))) return rc;
+        if ((rc = gemm(e, s, p, n, p, 1.0, e.d_P, p, 1, e.d_K, n, 1, e.d_PK))) return rc;
+        hipLaunchKernelGGL(hk_sum_kernel, g1(p), dim3(256), 0, s, p, e.d_scal, e.d_mv, e.d_mv + 2 * mx, e.d_mv + 5 * mx);
+        hipLaunchKernelGGL(matvec_kernel, g1(p, 4), dim3(DT), 0, s, p, p, e.d_P, e.d_mv + 5 * mx, e.d_mv + 4 * mx);
+        CESX_HIP(hipGetLastError());
+    }
+    const int ktot = mode == 2 ? e.kp + e.kn : e.ktot;
+    return f32 ? assemble<float>(e, s, mode, ktot, prm.switch_mult) : assemble<double>(e, s, mode, ktot, prm.switch_mult);
+}
+
+}  // namespace cesx

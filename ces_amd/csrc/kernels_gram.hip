@@ -1,0 +1,327 @@
+// K1 -- shifted second moments of the stacked ensemble Z = [U - s_u ; G - s_g]
+// (replaces np.cov(U0) ces/calibrate.py:424/476/512, the J x J matrix
+// D = (1/J) E^T Gamma^{-1} R of :429/:461/:503 and np.cov(Geval) :440/:472:
+// everything those lines produce factors through Z Z^T).
+//
+// Z is (P = p + n) x J, row-major, J contiguous.  The Gram Z Z^T is only
+// P x P but its contraction length is J, so the kernel is split-K over J:
+//   * the lower-triangular TILE x TILE output blocks are dealt to "workgroup
+//     types"; a type holds up to 4 * NBW blocks in the accumulators of its 4
+//     waves (1 wave per SIMD, ~270 accumulator VGPRs of the 512-entry file)
+//   * every workgroup streams its J-slice through LDS in KT-wide tiles
+//     (register-staged, double-buffered, shift subtracted on the way in) and
+//     feeds v_mfma_f32_32x32x2_f32 / v_mfma_f64_16x16x4_f64 from 16-byte LDS
+//     fragment reads (A and B operands are both "row of Z, 8 consecutive j")
+//   * per-slice partial blocks go to a slab; a second kernel sums the slabs in
+//     fp64 in a fixed order (deterministic, no float atomics).
+// Bound: MFMA (f32 MFMA issues at the f32 vector rate on gfx950).
+#include "cesx_internal.h"
+#include <algorithm>
+#include <cmath>
+
+namespace cesx {
+
+constexpr int GRAM_THREADS = 256;
+constexpr int ROW_BYTES = 128;            // one staged row of a tile: 32 f32 / 16 f64
+constexpr int ROW_STRIDE = ROW_BYTES + 16;  // +16 B pad: conflict-free ds_read_b128 over 16 rows
+constexpr int MAX_STAGE_ROWS = 512;
+constexpr int MAXCH = MAX_STAGE_ROWS * (ROW_BYTES / 16) / GRAM_THREADS;   // 16 chunks / thread
+
+template <typename T> struct GramCfg;
+template <> struct GramCfg<float>  { static constexpr int NBW = 17; };
+template <> struct GramCfg<double> { static constexpr int NBW = 34; };
+
+template <typename T, bool ALIGNED>
+__global__ __launch_bounds__(GRAM_THREADS, 1)
+void gram_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __restrict__ shift,
+                 int p, int n, long long J, const int* __restrict__ type_hdr,
+                 const int* __restrict__ rows_tab, const int* __restrict__ wblk,
+                 int nslices, int nblocks, T* __restrict__ slabs) {
+    using M = Mfma<T>;
+    using vec_t = typename M::vec_t;
+    using acc_t = typename M::acc_t;
+    constexpr int TILE = M::TILE, VEC = M::VEC, NBW = GramCfg<T>::NBW;
+    constexpr int KT = ROW_BYTES / (int)sizeof(T);       // j per tile
+    constexpr int NGROUP = KT / GROUP;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int type = blockIdx.x / nslices, slice = blockIdx.x % nslices;
+    const int nrb = type_hdr[type * 4 + 0];
+    const int rows_off = type_hdr[type * 4 + 1];
+    const int blocks_off = type_hdr[type * 4 + 2];
+    const int nrows = nrb * TILE;
+    const int P = p + n;
+    const int buf_bytes = nrows * ROW_STRIDE;
+
+    // this wave's block list (wave-uniform -> SGPRs)
+    // (compact row of A) | (compact row of B) << 8, one SGPR per block
+    int iab[NBW];
+    int nb = 0;
+#pragma unroll
+    for (int b = 0; b < NBW; ++b) {
+        const int* e = wblk + (size_t)(blocks_off + wave * NBW + b) * 3;
+        const int a = __builtin_amdgcn_readfirstlane(e[0]);
+        const int c = __builtin_amdgcn_readfirstlane(e[1]);
+        iab[b] = a | (c << 8);
+        if (a >= 0) nb = b + 1;
+    }
+    nb = __builtin_amdgcn_readfirstlane(nb);
+
+    acc_t acc[NBW];
+#pragma unroll
+    for (int b = 0; b < NBW; ++b)
+#pragma unroll
+        for (int r = 0; r < M::NACC; ++r) acc[b][r] = 0;
+
+    // J-slice of this workgroup, in tiles
+    const long long ntiles = (J + KT - 1) / KT;
+    const long long tps = (ntiles + nslices - 1) / nslices;
+    const long long t0 = (long long)slice * tps;
+    const long long t1 = t0 + tps < ntiles ? t0 + tps : ntiles;
+
+    // staging: thread handles 16-byte chunk `part` of rows (tid/8 + 32*i)
+    const int part = tid & 7, row0 = tid >> 3;
+    const int nch = (nrows + 31) / 32;                 // chunks this thread handles
+    vec_t stage[MAXCH];
+    // per staged row: source pointer (null = zero row) and shift, kept in LDS
+    const T** rowptr = reinterpret_cast<const T**>(smem + 2 * buf_bytes);
+    T* rowshift = reinterpret_cast<T*>(smem + 2 * buf_bytes + nrows * 8);
+    for (int row = tid; row < nrows; row += GRAM_THREADS) {
+        const int gr = rows_tab[rows_off + row / TILE] * TILE + row % TILE;
+        const T* ptr = nullptr;
+        T sh = 0;
+        if (gr < P) {
+            ptr = gr < p ? U + (size_t)gr * J : G + (size_t)(gr - p) * J;
+            sh = shift[gr];
+        }
+        rowptr[row] = ptr;
+        rowshift[row] = sh;
+    }
+    __syncthreads();
+
+    auto load_tile = [&](long long t) {
+        const long long j = t * KT + part * VEC;
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) {
+            const int row = row0 + 32 * i;
+            if (i < nch && row < nrows) {
+                vec_t v;
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) v[c] = 0;
+                const T* ptr = rowptr[row];
+                if (ptr != nullptr) {
+                    if (ALIGNED && j + VEC <= J) {
+                        v = *reinterpret_cast<const vec_t*>(ptr + j);
+                    } else {
+                        // out-of-range particles must contribute (x - s) = 0: load the shift
+                        const T sh = rowshift[row];
+#pragma unroll
+                        for (int c = 0; c < VEC; ++c) v[c] = j + c < J ? ptr[j + c] : sh;
+                    }
+                }
+                stage[i] = v;
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char* base = smem + buf * buf_bytes;
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) {
+            const int row = row0 + 32 * i;
+            if (i < nch && row < nrows) {
+                vec_t v = stage[i];
+                const T sh = rowshift[row];
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) v[c] -= sh;
+                *reinterpret_cast<vec_t*>(base + row * ROW_STRIDE + part * 16) = v;
+            }
+        }
+    };
+
+    const int laneoff = (lane % TILE) * ROW_STRIDE + (lane / TILE) * 16;
+
+    if (t0 < t1) {
+        load_tile(t0);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (long long t = t0; t < t1; ++t) {
+        const int cur = (int)((t - t0) & 1);
+        if (t + 1 < t1) load_tile(t + 1);
+        const char* base = smem + cur * buf_bytes + laneoff;
+#pragma unroll 1
+        for (int g = 0; g < NGROUP; ++g) {
+#pragma unroll
+            for (int b = 0; b < NBW; ++b) {
+                if (b < nb) {
+                    const vec_t a = *reinterpret_cast<const vec_t*>(
+                        base + (iab[b] & 0xff) * (TILE * ROW_STRIDE) + g * (GROUP * (int)sizeof(T)));
+                    const vec_t c = *reinterpret_cast<const vec_t*>(
+                        base + (iab[b] >> 8) * (TILE * ROW_STRIDE) + g * (GROUP * (int)sizeof(T)));
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[b] = M::mma(a[v], c[v], acc[b]);
+                }
+            }
+        }
+        if (t + 1 < t1) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // partial blocks of this slice
+#pragma unroll
+    for (int b = 0; b < NBW; ++b) {
+        if (b < nb) {
+            const int ob = __builtin_amdgcn_readfirstlane(wblk[(size_t)(blocks_off + wave * NBW + b) * 3 + 2]);
+            T* out = slabs + ((size_t)slice * nblocks + ob) * (TILE * TILE);
+#pragma unroll
+            for (int r = 0; r < M::NACC; ++r)
+                out[M::crow(lane, r) * TILE + M::ccol(lane)] = acc[b][r];
+        }
+    }
+}
+
+// Sum the per-slice partial blocks in fp64 (fixed order) and scatter them into
+// the packed moment buffer as full symmetric S_aa, S_ab, S_bb.
+template <typename T>
+__global__ void gram_reduce_kernel(const T* __restrict__ slabs, const int* __restrict__ blk_rc,
+                                   int nslices, int nblocks, int tile, int p, int n,
+                                   double* __restrict__ mom) {
+    const int tt = tile * tile;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)nblocks * tt) return;
+    const int blk = (int)(idx / tt), e = (int)(idx % tt);
+    const int R = blk_rc[blk * 2], C = blk_rc[blk * 2 + 1];
+    const int gr = R * tile + e / tile, gc = C * tile + e % tile;
+    const int P = p + n;
+    if (gr >= P || gc >= P) return;
+    if (R == C && gc > gr) return;            // diagonal block: lower half, mirrored below
+    double s = 0.0;
+    for (int k = 0; k < nslices; ++k) s += (double)slabs[((size_t)k * nblocks + blk) * tt + e];
+    double* Saa = mom + 1 + p + n;
+    double* Sab = Saa + (size_t)p * p;
+    double* Sbb = Sab + (size_t)p * n;
+    // gr >= gc here
+    if (gr < p) {                              // both in U
+        Saa[(size_t)gr * p + gc] = s;
+        Saa[(size_t)gc * p + gr] = s;
+    } else if (gc < p) {                       // gr in G, gc in U
+        Sab[(size_t)gc * n + (gr - p)] = s;
+    } else {
+        Sbb[(size_t)(gr - p) * n + (gc - p)] = s;
+        Sbb[(size_t)(gc - p) * n + (gr - p)] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host: work partition
+// ---------------------------------------------------------------------------
+GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds) {
+    GramPlan pl;
+    pl.tile = tile;
+    pl.nbw = nbw;
+    pl.nbr = (P + tile - 1) / tile;
+    const int cap = 4 * nbw;
+    std::vector<std::vector<std::pair<int, int>>> types;   // blocks (R, C) per type
+    if (pl.nbr * tile <= max_rows_lds) {
+        // all rows fit in LDS: chop the row-major lower triangle into equal runs
+        std::vector<std::pair<int, int>> all;
+        for (int R = 0; R < pl.nbr; ++R)
+            for (int C = 0; C <= R; ++C) all.push_back({R, C});
+        const int nt = ((int)all.size() + cap - 1) / cap;
+        const int per = ((int)all.size() + nt - 1) / nt;
+        for (int t = 0; t < nt; ++t) {
+            std::vector<std::pair<int, int>> v(all.begin() + std::min<size_t>(all.size(), (size_t)t * per),
+                                               all.begin() + std::min<size_t>(all.size(), (size_t)(t + 1) * per));
+            if (!v.empty()) types.push_back(v);
+        }
+    } else {
+        // rectangles a x b of blocks with (a + b) * tile rows staged
+        int a = std::max(1, (int)std::floor(std::sqrt((double)cap)));
+        int b = std::max(1, cap / a);
+        while ((a + b) * tile > max_rows_lds && (a > 1 || b > 1)) {
+            if (a >= b) --a; else --b;
+        }
+        for (int R0 = 0; R0 < pl.nbr; R0 += a)
+            for (int C0 = 0; C0 <= R0 + a - 1 && C0 < pl.nbr; C0 += b) {
+                std::vector<std::pair<int, int>> v;
+                for (int R = R0; R < std::min(R0 + a, pl.nbr); ++R)
+                    for (int C = C0; C < std::min(C0 + b, pl.nbr); ++C)
+                        if (C <= R) v.push_back({R, C});
+                if (!v.empty()) types.push_back(v);
+            }
+    }
+    pl.ntypes = (int)types.size();
+    pl.max_rb = 0;
+    // output block ids in row-major lower-triangular order
+    auto out_id = [](int R, int C) { return R * (R + 1) / 2 + C; };
+    pl.nblocks = pl.nbr * (pl.nbr + 1) / 2;
+    pl.blk_rc.assign((size_t)pl.nblocks * 2, 0);
+    for (int R = 0; R < pl.nbr; ++R)
+        for (int C = 0; C <= R; ++C) {
+            pl.blk_rc[(size_t)out_id(R, C) * 2] = R;
+            pl.blk_rc[(size_t)out_id(R, C) * 2 + 1] = C;
+        }
+    for (int t = 0; t < pl.ntypes; ++t) {
+        const auto& v = types[t];
+        std::vector<int> rows;
+        for (auto& rc : v) { rows.push_back(rc.first); rows.push_back(rc.second); }
+        std::sort(rows.begin(), rows.end());
+        rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
+        auto compact = [&](int r) { return (int)(std::lower_bound(rows.begin(), rows.end(), r) - rows.begin()); };
+        pl.max_rb = std::max(pl.max_rb, (int)rows.size());
+        pl.type_hdr.push_back((int)rows.size());
+        pl.type_hdr.push_back((int)pl.rows.size());
+        pl.type_hdr.push_back((int)(pl.wblk.size() / 3));
+        pl.type_hdr.push_back((int)v.size());
+        pl.rows.insert(pl.rows.end(), rows.begin(), rows.end());
+        const int nv = (int)v.size();
+        for (int w = 0; w < 4; ++w) {
+            const int lo = (int)((long long)nv * w / 4), hi = (int)((long long)nv * (w + 1) / 4);
+            for (int b = 0; b < nbw; ++b) {
+                if (lo + b < hi) {
+                    pl.wblk.push_back(compact(v[lo + b].first));
+                    pl.wblk.push_back(compact(v[lo + b].second));
+                    pl.wblk.push_back(out_id(v[lo + b].first, v[lo + b].second));
+                } else {
+                    pl.wblk.push_back(-1); pl.wblk.push_back(-1); pl.wblk.push_back(-1);
+                }
+            }
+        }
+    }
+    return pl;
+}
+
+template <typename T>
+static int launch_gram_t(Engine& e, const void* U, const void* G, double* mom, hipStream_t s) {
+    const GramPlan& pl = e.plan;
+    const int lds = 2 * pl.max_rb * pl.tile * ROW_STRIDE + pl.max_rb * pl.tile * 16;
+    const bool aligned = (e.J % Mfma<T>::VEC == 0) && ((uintptr_t)U % 16 == 0) && ((uintptr_t)G % 16 == 0);
+    dim3 grid(pl.ntypes * e.nslices), block(GRAM_THREADS);
+    auto kern = aligned ? gram_kernel<T, true> : gram_kernel<T, false>;
+    CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(kern, grid, block, lds, s, (const T*)U, (const T*)G, (const T*)e.d_shiftT,
+                       e.p, e.n, (long long)e.J, e.d_type_hdr, e.d_rows, e.d_wblk, e.nslices,
+                       pl.nblocks, (T*)e.d_slabs);
+    CESX_HIP(hipGetLastError());
+    const long long total = (long long)pl.nblocks * pl.tile * pl.tile;
+    hipLaunchKernelGGL(gram_reduce_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                       (const T*)e.d_slabs, e.d_blk_rc, e.nslices, pl.nblocks, pl.tile, e.p, e.n, mom);
+    CESX_HIP(hipGetLastError());
+    return CESX_OK;
+}
+
+int launch_gram(Engine& e, const void* U, const void* G, double* mom, hipStream_t s) {
+    return e.cfg.dtype == CESX_F32 ? launch_gram_t<float>(e, U, G, mom, s)
+                                   : launch_gram_t<double>(e, U, G, mom, s);
+}
+
+int gram_nbw(int dtype) { return dtype == CESX_F32 ? GramCfg<float>::NBW : GramCfg<double>::NBW; }
+int gram_tile(int dtype) { return dtype == CESX_F32 ? Mfma<float>::TILE : Mfma<double>::TILE; }
+int gram_kt(int dtype) { return dtype == CESX_F32 ? ROW_BYTES / 4 : ROW_BYTES / 8; }
+int gram_max_stage_rows() { return MAX_STAGE_ROWS; }
+
+}  // namespace cesx

@@ -1,0 +1,356 @@
+// K3 -- fused drift + diffusion update of the ensemble shard as ONE GEMM
+// (replaces ces/calibrate.py:443-447, :484-488, :515-527):
+//
+//     U_next = W . [U ; G ; xi] + b 1^T          W in R^{p x (2p+n)}
+//
+// with, for ALDI,  W = [ (1 + hk a_J) I - hk C Sigma^{-1} | -hk K | sqrt(2 hk) L ],
+// K = C_ug Gamma^{-1}, L = chol(C), b = hk (K y + C Sigma^{-1} mu - a_J ubar)
+// (W and b are assembled by K2 in kernels_dense.hip).  The
+// J x J product (U0 - Umean) @ D of :484 never appears.
+//
+// One workgroup = 4 waves = all (up to 256) output rows x BN particles; the
+// K-loop walks the stacked rows of [U; G; xi] in 16-row tiles, staged through
+// LDS (register-staged double buffer).  xi tiles are either read from memory
+// (parity runs inject the reference's np.random.normal block, :447/:488/:527)
+// or drawn in-kernel with Philox4x32-10 + Box-Muller keyed by the GLOBAL
+// particle index, so a particle's noise does not depend on how the ensemble
+// is sharded.  MFMA: v_mfma_f32_32x32x2_f32 / v_mfma_f64_16x16x4_f64.
+// The same kernel evaluates the linear forward map G = A U + b
+// (ces/utils.py:25-31) with a single K-segment.
+// Bound: MFMA.
+#include "cesx_internal.h"
+
+namespace cesx {
+
+constexpr int UPD_THREADS = 256;
+constexpr int BK = 16;
+
+template <typename T> struct UpdCfg;
+template <> struct UpdCfg<float> {
+    static constexpr int WR = 2, WC = 4;          // 32x32 blocks per wave: 64 rows x 128 particles
+    static constexpr int STRIDE_W = BK + 4;       // floats; conflict-free ds_read_b128
+    static constexpr int XPAD = 0;
+};
+template <> struct UpdCfg<double> {
+    static constexpr int WR = 4, WC = 4;          // 16x16 blocks per wave: 64 rows x 64 particles
+    static constexpr int STRIDE_W = BK + 2;
+    static constexpr int XPAD = 8;
+};
+
+template <typename T>
+struct UpdArgs {
+    const T* W; int ktot; const T* bias; int out_rows;
+    const T* src[3]; int src_rows[3]; int src_k0[3]; int src_kind[3]; int nsrc;
+    long long J, j_offset;
+    T* out;
+    const T* add1; const double* c1p; double c1i;
+    const T* add2; const double* c2p; double c2i;
+    double* absmax_part;
+    unsigned int seed_lo, seed_hi, step;
+};
+
+template <typename T, bool ALIGNED>
+__global__ __launch_bounds__(UPD_THREADS, sizeof(T) == 4 ? 2 : 1)
+void update_kernel(const UpdArgs<T> a) {
+    using M = Mfma<T>;
+    using vec_t = typename M::vec_t;
+    using acc_t = typename M::acc_t;
+    using C = UpdCfg<T>;
+    constexpr int TILE = M::TILE, VEC = M::VEC, WR = C::WR, WC = C::WC;
+    constexpr int RC = 4 * WR * TILE;                 // output rows per workgroup (256)
+    constexpr int BN = WC * TILE;                     // particles per workgroup
+    constexpr int SW = C::STRIDE_W, SX = BN + C::XPAD;
+    constexpr int WCH = RC * BK / VEC / UPD_THREADS;  // W chunks per thread
+    constexpr int XCH = BK * BN / VEC / UPD_THREADS;  // X chunks per thread (2)
+    constexpr int CPR = BN / VEC;                     // X chunks per row (32)
+    constexpr int WPR = BK / VEC;                     // W chunks per row
+    constexpr int NQ = 4 * BN / UPD_THREADS;          // philox items per thread
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T (*sW)[RC * SW] = reinterpret_cast<T (*)[RC * SW]>(smem);
+    T (*sX)[BK * SX] = reinterpret_cast<T (*)[BK * SX]>(smem + 2 * RC * SW * sizeof(T));
+    double* red = reinterpret_cast<double*>(smem + 2 * (RC * SW + BK * SX) * sizeof(T));
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long jt0 = (long long)blockIdx.x * BN;
+    const int rc0 = blockIdx.y * RC;
+    const int wrow0 = rc0 + wave * WR * TILE;
+    const int nkt = a.ktot / BK;
+
+    acc_t acc[WR][WC];
+#pragma unroll
+    for (int r = 0; r < WR; ++r)
+#pragma unroll
+        for (int c = 0; c < WC; ++c)
+#pragma unroll
+            for (int e = 0; e < M::NACC; ++e) acc[r][c][e] = 0;
+
+    vec_t wst[WCH], xst[XCH];
+    int xkind = 0, xq0 = 0;
+
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
+        // W tile: rows rc0 .. rc0+RC-1, columns k0 .. k0+15 (W is zero padded)
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int c = tid + UPD_THREADS * i;
+            const int row = c / WPR, part = c % WPR;
+            wst[i] = *reinterpret_cast<const vec_t*>(a.W + (size_t)(rc0 + row) * a.ktot + k0 + part * VEC);
+        }
+        // which K-segment does this tile belong to?
+        int s = 0;
+#pragma unroll
+        for (int q = 1; q < 3; ++q)
+            if (q < a.nsrc && k0 >= a.src_k0[q]) s = q;
+        xkind = a.src_kind[s];
+        if (xkind == 0) {
+            const int r0 = k0 - a.src_k0[s];
+#pragma unroll
+            for (int i = 0; i < XCH; ++i) {
+                const int c = tid + UPD_THREADS * i;
+                const int row = r0 + c / CPR;
+                const long long j = jt0 + (c % CPR) * VEC;
+                vec_t v;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[e] = 0;
+                if (row < a.src_rows[s]) {
+                    const T* ptr = a.src[s] + (size_t)row * a.J;
+                    if (ALIGNED && j + VEC <= a.J) {
+                        v = *reinterpret_cast<const vec_t*>(ptr + j);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e)
+                            if (j + e < a.J) v[e] = ptr[j + e];
+                    }
+                }
+                xst[i] = v;
+            }
+        } else {
+            xq0 = (k0 - a.src_k0[s]) / 4;      // first row quad of this noise tile
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int c = tid + UPD_THREADS * i;
+            const int row = c / WPR, part = c % WPR;
+            *reinterpret_cast<vec_t*>(&sW[buf][row * SW + part * VEC]) = wst[i];
+        }
+        if (xkind == 0) {
+#pragma unroll
+            for (int i = 0; i < XCH; ++i) {
+                const int c = tid + UPD_THREADS * i;
+                *reinterpret_cast<vec_t*>(&sX[buf][(c / CPR) * SX + (c % CPR) * VEC]) = xst[i];
+            }
+        } else {
+            const unsigned q0 = (unsigned)xq0;
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const int item = tid + UPD_THREADS * i;
+                const int jl = item % BN, ql = item / BN;
+                const unsigned long long gj = (unsigned long long)(a.j_offset + jt0 + jl);
+                const uint4x r = philox4x32_10((uint32_t)gj, (uint32_t)(gj >> 32), q0 + ql, a.step,
+                                               a.seed_lo, a.seed_hi);
+                T z[4];
+                normal4(r, z);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sX[buf][(4 * ql + e) * SX + jl] = z[e];
+            }
+        }
+    };
+
+    // skip row blocks that are entirely padding (small p)
+    bool rb_on[WR];
+#pragma unroll
+    for (int r = 0; r < WR; ++r) rb_on[r] = (wrow0 + r * TILE) < a.out_rows;
+
+    const int li = lane % TILE, lh = lane / TILE;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) load_tile(kt + 1);
+        if (rb_on[0]) {
+#pragma unroll
+            for (int g = 0; g < BK / GROUP; ++g) {
+                vec_t af[WR];
+#pragma unroll
+                for (int r = 0; r < WR; ++r)
+                    af[r] = *reinterpret_cast<const vec_t*>(
+                        &sW[cur][(wave * WR * TILE + r * TILE + li) * SW + g * GROUP + lh * VEC]);
+                T xf[WC][VEC];
+#pragma unroll
+                for (int c = 0; c < WC; ++c)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v)
+                        xf[c][v] = sX[cur][(g * GROUP + lh * VEC + v) * SX + c * TILE + li];
+#pragma unroll
+                for (int r = 0; r < WR; ++r) {
+                    if (rb_on[r]) {
+#pragma unroll
+                        for (int c = 0; c < WC; ++c)
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v)
+                                acc[r][c] = M::mma(af[r][v], xf[c][v], acc[r][c]);
+                    }
+                }
+            }
+        }
+        if (kt + 1 < nkt) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue
+    const double c1 = a.add1 ? (a.c1p ? *a.c1p * a.c1i : a.c1i) : 0.0;
+    const double c2 = a.add2 ? (a.c2p ? *a.c2p * a.c2i : a.c2i) : 0.0;
+    T amax = 0;
+#pragma unroll
+    for (int r = 0; r < WR; ++r) {
+#pragma unroll
+        for (int e = 0; e < M::NACC; ++e) {
+            const int i = wrow0 + r * TILE + M::crow(lane, e);
+            if (i < a.out_rows) {
+                const T bi = a.bias ? a.bias[i] : (T)0;
+#pragma unroll
+                for (int c = 0; c < WC; ++c) {
+                    const long long j = jt0 + c * TILE + M::ccol(lane);
+                    if (j < a.J) {
+                        T v = acc[r][c][e] + bi;
+                        const size_t o = (size_t)i * a.J + j;
+                        if (a.add1) v += (T)c1 * a.add1[o];
+                        if (a.add2) v += (T)c2 * a.add2[o];
+                        a.out[o] = v;
+                        const T av = v < 0 ? -v : v;
+                        amax = av > amax ? av : amax;
+                    }
+                }
+            }
+        }
+    }
+    if (a.absmax_part) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const T other = __shfl_down(amax, o, 64);
+            amax = other > amax ? other : amax;
+        }
+        if (lane == 0) red[wave] = (double)amax;
+        __syncthreads();
+        if (tid == 0) {
+            double m = red[0];
+            for (int w = 1; w < UPD_THREADS / 64; ++w) m = red[w] > m ? red[w] : m;
+            a.absmax_part[blockIdx.y * gridDim.x + blockIdx.x] = m;
+        }
+    }
+}
+
+__global__ void absmax_final_kernel(const double* __restrict__ part, int nparts, double* __restrict__ out) {
+    __shared__ double red[256];
+    double m = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) m = part[i] > m ? part[i] : m;
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = red[threadIdx.x + s] > red[threadIdx.x] ? red[threadIdx.x + s] : red[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+// xi block alone (tests of the generator): xi[r][j] for r < p
+template <typename T>
+__global__ void noise_kernel(T* __restrict__ xi, int p, long long J, long long j_offset, unsigned seed_lo,
+                             unsigned seed_hi, unsigned step) {
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = blockIdx.y;
+    if (j >= J) return;
+    const unsigned long long gj = (unsigned long long)(j_offset + j);
+    const uint4x r = philox4x32_10((uint32_t)gj, (uint32_t)(gj >> 32), (uint32_t)q, step, seed_lo, seed_hi);
+    T z[4];
+    normal4(r, z);
+    for (int e = 0; e < 4; ++e)
+        if (4 * q + e < p) xi[(size_t)(4 * q + e) * J + j] = z[e];
+}
+
+// ---------------------------------------------------------------------------
+template <typename T>
+static int update_t(Engine& e, int out_rows, const void* W, int ktot, const void* bias,
+                    const UpdateSrc* src, int nsrc, const void* add1, const double* c1, double c1_imm,
+                    const void* add2, const double* c2, double c2_imm, void* out, double* absmax_part,
+                    uint64_t step_index, hipStream_t s) {
+    using C = UpdCfg<T>;
+    constexpr int RC = 4 * C::WR * Mfma<T>::TILE, BN = C::WC * Mfma<T>::TILE;
+    UpdArgs<T> a{};
+    a.W = (const T*)W; a.ktot = ktot; a.bias = (const T*)bias; a.out_rows = out_rows;
+    int k0 = 0;
+    bool aligned = (e.J % Mfma<T>::VEC == 0);
+    for (int i = 0; i < 3; ++i) {
+        a.src[i] = nullptr; a.src_rows[i] = 0; a.src_k0[i] = 0x7fffffff; a.src_kind[i] = 0;
+    }
+    for (int i = 0; i < nsrc; ++i) {
+        a.src[i] = (const T*)src[i].ptr;
+        a.src_rows[i] = src[i].rows;
+        a.src_k0[i] = k0;
+        a.src_kind[i] = src[i].kind;
+        k0 += (src[i].rows + BK - 1) / BK * BK;
+        if (src[i].kind == 0 && (uintptr_t)src[i].ptr % 16 != 0) aligned = false;
+    }
+    if (k0 != ktot) { e.err = "update: K segments do not add up to ktot"; return CESX_EINVAL; }
+    a.nsrc = nsrc;
+    a.J = e.J; a.j_offset = e.cfg.j_offset;
+    a.out = (T*)out;
+    a.add1 = (const T*)add1; a.c1p = c1; a.c1i = c1_imm;
+    a.add2 = (const T*)add2; a.c2p = c2; a.c2i = c2_imm;
+    a.absmax_part = absmax_part;
+    a.seed_lo = (unsigned)e.cfg.seed; a.seed_hi = (unsigned)(e.cfg.seed >> 32); a.step = (unsigned)step_index;
+    dim3 grid((unsigned)((e.J + BN - 1) / BN), (unsigned)((out_rows + RC - 1) / RC));
+    const int lds = 2 * (RC * C::STRIDE_W + BK * (BN + C::XPAD)) * (int)sizeof(T) + 64;
+    auto kern = aligned ? update_kernel<T, true> : update_kernel<T, false>;
+    CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(kern, grid, dim3(UPD_THREADS), lds, s, a);
+    CESX_HIP(hipGetLastError());
+    return CESX_OK;
+}
+
+int launch_update(Engine& e, int out_rows, const void* W, int ktot, const void* bias,
+                  const UpdateSrc* src, int nsrc, const void* add1, const double* c1, double c1_imm,
+                  const void* add2, const double* c2, double c2_imm, void* out, double* absmax_part,
+                  uint64_t step_index, hipStream_t s) {
+    return e.cfg.dtype == CESX_F32
+        ? update_t<float>(e, out_rows, W, ktot, bias, src, nsrc, add1, c1, c1_imm, add2, c2, c2_imm, out, absmax_part, step_index, s)
+        : update_t<double>(e, out_rows, W, ktot, bias, src, nsrc, add1, c1, c1_imm, add2, c2, c2_imm, out, absmax_part, step_index, s);
+}
+
+int update_grid_blocks(Engine& e, int out_rows) {
+    if (e.cfg.dtype == CESX_F32) {
+        constexpr int RC = 4 * UpdCfg<float>::WR * 32, BN = UpdCfg<float>::WC * 32;
+        return (int)((e.J + BN - 1) / BN) * ((out_rows + RC - 1) / RC);
+    }
+    constexpr int RC = 4 * UpdCfg<double>::WR * 16, BN = UpdCfg<double>::WC * 16;
+    return (int)((e.J + BN - 1) / BN) * ((out_rows + RC - 1) / RC);
+}
+
+int launch_absmax_final(Engine& e, int nparts, double* absmax_out, hipStream_t s) {
+    hipLaunchKernelGGL(absmax_final_kernel, dim3(1), dim3(256), 0, s, e.d_absmax_part, nparts, absmax_out);
+    CESX_HIP(hipGetLastError());
+    return CESX_OK;
+}
+
+int launch_noise(Engine& e, uint64_t step_index, void* xi, hipStream_t s) {
+    dim3 grid((unsigned)((e.J + 255) / 256), (unsigned)((e.p + 3) / 4));
+    if (e.cfg.dtype == CESX_F32)
+        hipLaunchKernelGGL(noise_kernel<float>, grid, dim3(256), 0, s, (float*)xi, e.p, (long long)e.J,
+                           (long long)e.cfg.j_offset, (unsigned)e.cfg.seed, (unsigned)(e.cfg.seed >> 32),
+                           (unsigned)step_index);
+    else
+        hipLaunchKernelGGL(noise_kernel<double>, grid, dim3(256), 0, s, (double*)xi, e.p, (long long)e.J,
+                           (long long)e.cfg.j_offset, (unsigned)e.cfg.seed, (unsigned)(e.cfg.seed >> 32),
+                           (unsigned)step_index);
+    CESX_HIP(hipGetLastError());
+    return CESX_OK;
+}
+
+}  // namespace cesx

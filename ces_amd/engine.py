@@ -1,0 +1,286 @@
+"""ctypes binding of ``libcesx.so`` (include/cesx.h).
+
+PyTorch-ROCm tensors are used only as device buffers and for the current HIP
+stream; every number is produced by the hand-written HIP kernels behind the C
+ABI.  There is no CPU fallback: if the library is missing or no GPU is
+present the product path raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcesx.so")
+
+OK, EINVAL, ENOTPD, EHIP, ESTATE, EUNSUPPORTED = 0, 1, 2, 3, 4, 5
+F32, F64 = 0, 1
+UPDATES = {"eks": 0, "aldi": 1, "aldi_constant": 2}
+TIME_STEPS = {None: 0, "spectral": 1, "constant": 2, "adaptive": 3, "mix": 4}
+ABI_VERSION = 1
+
+EXPORTS = ("cesx_abi_version", "cesx_create", "cesx_destroy", "cesx_last_error", "cesx_set_problem",
+           "cesx_step", "cesx_result", "cesx_moments_len", "cesx_colsum", "cesx_set_shift",
+           "cesx_moments", "cesx_apply", "cesx_apply_drift", "cesx_apply_finish", "cesx_draw_noise",
+           "cesx_forward_lineal", "cesx_debug_dense")
+
+
+class Config(C.Structure):
+    _fields_ = [("struct_bytes", C.c_uint32), ("p", C.c_int32), ("n_obs", C.c_int32), ("dtype", C.c_int32),
+                ("device", C.c_int32), ("J_local", C.c_int64), ("J_global", C.c_int64),
+                ("j_offset", C.c_int64), ("seed", C.c_uint64)]
+
+
+class StepParams(C.Structure):
+    _fields_ = [("struct_bytes", C.c_uint32), ("update", C.c_int32), ("time_step", C.c_int32),
+                ("first_step", C.c_int32), ("t_len", C.c_int32), ("reserved", C.c_int32),
+                ("t_last", C.c_double), ("delta_t", C.c_double), ("spinup", C.c_double),
+                ("switch_mult", C.c_double), ("step_index", C.c_uint64)]
+
+
+class StepResult(C.Structure):
+    _fields_ = [("hk", C.c_double), ("t_new", C.c_double), ("self_bias", C.c_double),
+                ("self_bias_data", C.c_double), ("bias_data", C.c_double), ("bias", C.c_double),
+                ("radspec", C.c_double), ("status", C.c_int32), ("reserved", C.c_int32)]
+
+
+class CesxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("cesx error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load libcesx.so and declare its prototypes.  Loud failure when absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise ImportError("%s not found: build it with `python -m ces_amd.build` "
+                          "(there is no CPU fallback for the HIP engine)" % path)
+    lib = C.CDLL(path)
+    vp, i32, u64, dp = C.c_void_p, C.c_int, C.c_uint64, C.POINTER(C.c_double)
+    lib.cesx_abi_version.restype = C.c_int
+    lib.cesx_last_error.restype = C.c_char_p
+    lib.cesx_last_error.argtypes = [vp]
+    lib.cesx_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    lib.cesx_destroy.argtypes = [vp]
+    lib.cesx_destroy.restype = None
+    lib.cesx_set_problem.argtypes = [vp, dp, dp, dp, dp, dp]
+    lib.cesx_step.argtypes = [vp, C.POINTER(StepParams), vp, vp, vp, vp, i32, vp]
+    lib.cesx_result.argtypes = [vp, C.POINTER(StepResult)]
+    lib.cesx_moments_len.argtypes = [vp]
+    lib.cesx_moments_len.restype = C.c_size_t
+    lib.cesx_colsum.argtypes = [vp, vp, vp, vp, vp]
+    lib.cesx_set_shift.argtypes = [vp, vp, vp]
+    lib.cesx_moments.argtypes = [vp, vp, vp, vp, vp]
+    lib.cesx_apply.argtypes = [vp, C.POINTER(StepParams), vp, vp, vp, vp, vp, vp]
+    lib.cesx_apply_drift.argtypes = [vp, C.POINTER(StepParams), vp, vp, vp, vp, vp, vp]
+    lib.cesx_apply_finish.argtypes = [vp, C.POINTER(StepParams), vp, vp, vp, vp, vp]
+    lib.cesx_draw_noise.argtypes = [vp, u64, vp, vp]
+    lib.cesx_forward_lineal.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.cesx_debug_dense.argtypes = [vp, dp, dp, dp, dp, dp, dp]
+    if lib.cesx_abi_version() != ABI_VERSION:
+        raise ImportError("libcesx.so ABI %d != binding ABI %d" % (lib.cesx_abi_version(), ABI_VERSION))
+    if path == LIB_PATH:
+        _lib = lib
+    return lib
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def step_params(update="aldi", time_step=None, first_step=True, t_len=0, t_last=0.0, delta_t=None,
+                spinup=4.0, switch=1.0, step_index=0, T=30):
+    """kwargs of sampling.eks_update* (ces/calibrate.py:247-260, :517) -> cesx_step_params."""
+    if update not in UPDATES:
+        raise ValueError("unknown update rule %r" % (update,))
+    if time_step not in TIME_STEPS:
+        # the reference leaves hk unbound for unknown strings (ces/calibrate.py:262)
+        raise UnboundLocalError("local variable 'hk' referenced before assignment")
+    prm = StepParams()
+    prm.struct_bytes = C.sizeof(StepParams)
+    prm.update = UPDATES[update]
+    prm.time_step = TIME_STEPS[time_step]
+    prm.first_step = int(bool(first_step))
+    prm.t_len = int(t_len)
+    prm.t_last = float(t_last)
+    prm.delta_t = float(delta_t if delta_t is not None else 1.0 / (T / 2))
+    prm.spinup = float(spinup)
+    prm.switch_mult = float(switch)
+    prm.step_index = int(step_index)
+    return prm
+
+
+class Engine:
+    """One handle = one device = one particle shard (cesx_create)."""
+
+    def __init__(self, p, n_obs, J, dtype="float32", device=0, J_global=None, j_offset=0, seed=1234):
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise RuntimeError("ces_amd needs a HIP device: the ensemble update has no CPU path")
+        self.p, self.n_obs, self.J = int(p), int(n_obs), int(J)
+        self.J_global = int(J_global if J_global is not None else J)
+        self.np_dtype = np.dtype(dtype)
+        if self.np_dtype not in (np.dtype("float32"), np.dtype("float64")):
+            raise ValueError("dtype must be float32 or float64")
+        self.torch_dtype = torch.float32 if self.np_dtype == np.dtype("float32") else torch.float64
+        self.device = torch.device("cuda", int(device))
+        cfg = Config()
+        cfg.struct_bytes = C.sizeof(Config)
+        cfg.p, cfg.n_obs = self.p, self.n_obs
+        cfg.dtype = F32 if self.np_dtype == np.dtype("float32") else F64
+        cfg.device = int(device)
+        cfg.J_local, cfg.J_global, cfg.j_offset = self.J, self.J_global, int(j_offset)
+        cfg.seed = int(seed)
+        self._h = C.c_void_p()
+        rc = self.lib.cesx_create(C.byref(cfg), C.byref(self._h))
+        if rc != OK:
+            raise CesxError(rc, self.lib.cesx_last_error(None).decode())
+        self._problem = None
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self.lib.cesx_destroy(h)
+
+    # -- helpers ---------------------------------------------------------
+    def _check(self, rc):
+        if rc == OK:
+            return
+        msg = self.lib.cesx_last_error(self._h).decode()
+        if rc == ENOTPD:
+            raise np.linalg.LinAlgError(msg or "Matrix is not positive definite")
+        if rc == EUNSUPPORTED:
+            raise AttributeError("'sampling' object has no attribute 'LM_procedure'")
+        if rc == EINVAL:
+            raise ValueError(msg)
+        raise CesxError(rc, msg)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def to_device(self, a, rows=None):
+        """Host (rows, J) array or device tensor -> contiguous device tensor of the engine dtype."""
+        if isinstance(a, torch.Tensor):
+            t = a.to(device=self.device, dtype=self.torch_dtype).contiguous()
+        else:
+            t = torch.as_tensor(np.ascontiguousarray(a, dtype=self.np_dtype), device=self.device)
+        if rows is not None and tuple(t.shape) != (rows, self.J):
+            raise ValueError("expected shape (%d, %d), got %s" % (rows, self.J, tuple(t.shape)))
+        return t
+
+    def empty(self, rows):
+        return torch.empty((rows, self.J), dtype=self.torch_dtype, device=self.device)
+
+    # -- problem ---------------------------------------------------------
+    def set_problem(self, y, Gamma, mu, sigma, ustar):
+        y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(self.n_obs))
+        Gamma = np.ascontiguousarray(np.asarray(Gamma, dtype=np.float64).reshape(self.n_obs, self.n_obs))
+        mu = np.ascontiguousarray(np.asarray(mu, dtype=np.float64).reshape(self.p))
+        sigma = np.asarray(sigma, dtype=np.float64)
+        if sigma.ndim == 0:
+            sigma = float(sigma) * np.eye(self.p)
+        sigma = np.ascontiguousarray(sigma.reshape(self.p, self.p))
+        ustar = np.ascontiguousarray(np.asarray(ustar, dtype=np.float64).reshape(self.p))
+        key = (y, Gamma, mu, sigma, ustar)
+        if self._problem is not None and all(np.array_equal(a, b) for a, b in zip(key, self._problem)):
+            return
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cesx_set_problem(self._h, _dptr(y), _dptr(Gamma), _dptr(mu), _dptr(sigma),
+                                                  _dptr(ustar)))
+        self._problem = tuple(a.copy() for a in key)
+
+    # -- single device step ------------------------------------------------
+    def step(self, prm, U, G, xi=None, out=None, recenter=True):
+        """cesx_step: returns the new (p, J) device tensor (never aliases U)."""
+        U, G = self.to_device(U, self.p), self.to_device(G, self.n_obs)
+        xi_t = None if xi is None else self.to_device(xi, self.p)
+        out = self.empty(self.p) if out is None else out
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cesx_step(self._h, C.byref(prm), U.data_ptr(), G.data_ptr(),
+                                           None if xi_t is None else xi_t.data_ptr(), out.data_ptr(),
+                                           int(bool(recenter)), self._stream()))
+        self._keep = (U, G, xi_t, out)      # keep inputs alive until the stream has consumed them
+        return out
+
+    def result(self):
+        res = StepResult()
+        rc = self.lib.cesx_result(self._h, C.byref(res))
+        self._check(rc)
+        return res
+
+    # -- split entry points -------------------------------------------------
+    def moments_len(self):
+        return int(self.lib.cesx_moments_len(self._h))
+
+    def colsum(self, U, G):
+        sums = torch.empty(1 + self.p + self.n_obs, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cesx_colsum(self._h, U.data_ptr(), G.data_ptr(), sums.data_ptr(), self._stream()))
+        return sums
+
+    def set_shift(self, sums):
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cesx_set_shift(self._h, sums.data_ptr(), self._stream()))
+
+    def moments(self, U, G, out=None):
+        mom = torch.empty(self.moments_len(), dtype=torch.float64, device=self.device) if out is None else out
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cesx_moments(self._h, U.data_ptr(), G.data_ptr(), mom.data_ptr(), self._stream()))
+        return mom
+
+    def apply(self, prm, mom, U, G, xi=None, out=None):
+        out = self.empty(self.p) if out is None else out
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cesx_apply(self._h, C.byref(prm), mom.data_ptr(), U.data_ptr(), G.data_ptr(),
+                                            None if xi is None else xi.data_ptr(), out.data_ptr(), self._stream()))
+        self._keep = (mom, U, G, xi, out)
+        return out
+
+    def apply_drift(self, prm, mom, U, G, out):
+        absmax = torch.empty(1, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cesx_apply_drift(self._h, C.byref(prm), mom.data_ptr(), U.data_ptr(),
+                                                  G.data_ptr(), out.data_ptr(), absmax.data_ptr(), self._stream()))
+        return absmax
+
+    def apply_finish(self, prm, absmax, U, xi, out):
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cesx_apply_finish(self._h, C.byref(prm), absmax.data_ptr(), U.data_ptr(),
+                                                   None if xi is None else xi.data_ptr(), out.data_ptr(),
+                                                   self._stream()))
+        self._keep = (absmax, U, xi, out)
+        return out
+
+    def draw_noise(self, step_index):
+        xi = self.empty(self.p)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cesx_draw_noise(self._h, int(step_index), xi.data_ptr(), self._stream()))
+        return xi
+
+    def forward_lineal(self, A, U, b=None, out=None):
+        A = torch.as_tensor(A).to(device=self.device, dtype=self.torch_dtype).contiguous()
+        if tuple(A.shape) != (self.n_obs, self.p):
+            raise ValueError("A must be (n_obs, p)")
+        bt = None if b is None else torch.as_tensor(b).to(device=self.device, dtype=self.torch_dtype).reshape(-1).contiguous()
+        out = self.empty(self.n_obs) if out is None else out
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cesx_forward_lineal(self._h, A.data_ptr(), None if bt is None else bt.data_ptr(),
+                                                     U.data_ptr(), out.data_ptr(), self._stream()))
+        self._keep = (A, bt, U, out)
+        return out
+
+    def debug_dense(self):
+        p, n = self.p, self.n_obs
+        out = dict(ubar=np.empty(p), gbar=np.empty(n), C=np.empty((p, p)), L=np.empty((p, p)),
+                   K=np.empty((p, n)), M=np.empty((p, p)))
+        self._check(self.lib.cesx_debug_dense(self._h, _dptr(out["ubar"]), _dptr(out["gbar"]), _dptr(out["C"]),
+                                              _dptr(out["L"]), _dptr(out["K"]), _dptr(out["M"])))
+        return out

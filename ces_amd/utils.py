@@ -1,0 +1,40 @@
+"""Forward maps of the hot-path configs (ces/utils.py:5-31).
+
+Only ``lineal`` is on the path BASELINE.json names (configs 1-3); the other toy
+models of ces/utils.py are host-side forward maps outside the scope table.
+"""
+import numpy as np
+
+
+class lineal(object):
+    """Linear forward map ``A theta + b`` (ces/utils.py:5-31): same attributes
+    (``A, b, n_obs, flag_noise, noise_sigma, model_name, type``) and call
+    convention, one parameter vector per call as enka.G_ens uses it
+    (ces/calibrate.py:123-130)."""
+
+    def __init__(self, A, b=0, flag_noise=False):
+        self.A = A
+        self.b = b
+        self.n_obs = A.shape[0]
+        self.flag_noise = flag_noise
+        self.noise_sigma = np.sqrt(0.1)
+        self.model_name = "lineal"
+        self.type = "map"
+
+    def __repr__(self):
+        return self.model_name
+
+    def __call__(self, theta):
+        out = np.matmul(self.A, theta) + self.b
+        if self.flag_noise:
+            out = out + self.noise_sigma * np.random.normal()
+        return out
+
+    # build-only hook: evaluate the whole shard on device
+    def forward_device(self, engine, U_dev, out=None):
+        if self.flag_noise:
+            raise ValueError("the device hook evaluates the noise-free map only")
+        b = None
+        if np.ndim(self.b) > 0 or self.b != 0:
+            b = np.broadcast_to(np.asarray(self.b, dtype=np.float64), (self.n_obs,))
+        return engine.forward_lineal(self.A, U_dev, b=b, out=out)

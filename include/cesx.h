@@ -1,0 +1,206 @@
+/*
+ * cesx.h -- C ABI of the MI355X-native EKS / ALDI ensemble-update engine.
+ *
+ * This is the drop-in boundary for the hot path of agarbuno/ces: the per-step
+ * ensemble update of ces/calibrate.py (sampling.eks_update :418-449,
+ * sampling.eks_update_aldi :451-490, sampling.eks_update_aldi_constant
+ * :492-529 and sampling.timestep_method :243-267).  The reference is pure
+ * Python/numpy and has no FFI of its own; each entry point
+ * below cites the reference lines whose arithmetic it replaces.  The Python
+ * binding a maintainer would add is ces_amd/engine.py (ctypes); see
+ * INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C, no C++ or torch types; all pointers are raw addresses
+ *   - "dev" pointers are device (HBM) addresses, "host" pointers host memory
+ *   - ensembles keep the reference layout: row-major (p, J), particle index
+ *     fastest (ces/calibrate.py:56, 277); a particle shard is a column range
+ *   - every call returns CESX_OK (0) or a CESX_E* status; the text of the
+ *     last failure is available from cesx_last_error()
+ *   - one handle per device, not thread-safe per handle, no global state
+ *   - the caller owns every buffer it passes; U is never written
+ *     (ces/calibrate.py:357 keeps U0 alive in the trace list)
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *     all work is enqueued asynchronously, only cesx_result() waits
+ */
+#ifndef CESX_H
+#define CESX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CESX_ABI_VERSION 1
+
+/* status codes */
+#define CESX_OK            0
+#define CESX_EINVAL        1   /* bad argument / unknown rule (ValueError)               */
+#define CESX_ENOTPD        2   /* covariance not positive definite (np.linalg.LinAlgError,
+                                  ces/calibrate.py:446, :487, :526)                      */
+#define CESX_EHIP          3   /* HIP runtime failure                                     */
+#define CESX_ESTATE        4   /* call order violated (e.g. no problem set)              */
+#define CESX_EUNSUPPORTED  5   /* time_step='adaptive': the reference calls the undefined
+                                  self.LM_procedure (ces/calibrate.py:255)               */
+
+/* arithmetic type of the O(J) passes (moments, update GEMM).  The small dense
+   algebra (covariances, Cholesky, gains, time step) always runs in fp64. */
+#define CESX_F32 0
+#define CESX_F64 1
+
+/* update rule, kwargs['update'] of sampling.run (ces/calibrate.py:304, :364-369) */
+#define CESX_UPDATE_EKS            0
+#define CESX_UPDATE_ALDI           1
+#define CESX_UPDATE_ALDI_CONSTANT  2
+
+/* kwargs['time_step'] of sampling.timestep_method (ces/calibrate.py:247-260) */
+#define CESX_TS_DEFAULT   0   /* None: hk = 1/(||D||_F + 1e-8)              :247-248 */
+#define CESX_TS_SPECTRAL  1   /* hk = 1/max Re eig(D)                        :249-251 */
+#define CESX_TS_CONSTANT  2   /* hk = delta_t                                :252-253 */
+#define CESX_TS_ADAPTIVE  3   /* undefined in the reference -> CESX_EUNSUPPORTED :254 */
+#define CESX_TS_MIX       4   /* Frobenius until t >= spinup, then delta_t   :256-260 */
+
+typedef struct cesx_engine* cesx_handle;
+
+/* Static shape of one engine = the state of enka.__init__ (ces/calibrate.py:14-22)
+   plus the particle shard this device owns. */
+typedef struct cesx_config {
+    uint32_t struct_bytes;  /* sizeof(cesx_config), for ABI checking                  */
+    int32_t  p;             /* parameter dimension            (self.p)                */
+    int32_t  n_obs;         /* data dimension                 (self.n_obs)            */
+    int32_t  dtype;         /* CESX_F32 | CESX_F64                                    */
+    int32_t  device;        /* HIP device ordinal                                     */
+    int64_t  J_local;       /* particles held by this device                          */
+    int64_t  J_global;      /* ensemble size over all devices (self.J)                */
+    int64_t  j_offset;      /* global index of local particle 0 (keys the noise RNG)  */
+    uint64_t seed;          /* Philox key for on-device noise                         */
+} cesx_config;
+
+/* Per-step options = the **kwargs of eks_update* (ces/calibrate.py:418, 451, 492)
+   plus the two pieces of object state the rules read. */
+typedef struct cesx_step_params {
+    uint32_t struct_bytes;
+    int32_t  update;        /* CESX_UPDATE_*                                          */
+    int32_t  time_step;     /* CESX_TS_*                                              */
+    int32_t  first_step;    /* len(self.Uall) == 1   (ces/calibrate.py:262, :520)     */
+    int32_t  t_len;         /* len(self.metrics['t']) before this step   (:257)       */
+    int32_t  reserved;
+    double   t_last;        /* self.metrics['t'][-1] before this step (if t_len > 0)  */
+    double   delta_t;       /* kwargs['delta_t'], default 1/(T/2)        (:253, :260) */
+    double   spinup;        /* kwargs['spinup'],  default 4.0            (:257)       */
+    double   switch_mult;   /* kwargs['switch'],  default 1.0            (:517)       */
+    uint64_t step_index;    /* noise counter: a fresh value per step                  */
+} cesx_step_params;
+
+/* What one step appends to the reference's bookkeeping lists. */
+typedef struct cesx_step_result {
+    double  hk;              /* step size                                            */
+    double  t_new;           /* value appended to metrics['t']          (:262-265)   */
+    double  self_bias;       /* metrics['self-bias']                    (:432/:464)  */
+    double  self_bias_data;  /* metrics['self-bias-data']               (:434/:466)  */
+    double  bias_data;       /* metrics['bias-data']                    (:435/:467)  */
+    double  bias;            /* metrics['bias']                         (:433/:465)  */
+    double  radspec;         /* value appended to self.radspec (spectral only, :250) */
+    int32_t status;          /* CESX_OK or CESX_ENOTPD for this step                 */
+    int32_t reserved;
+} cesx_step_result;
+
+/* ---- lifetime -------------------------------------------------------- */
+
+/* Replaces enka.__init__ (ces/calibrate.py:14-22): allocates all device
+   workspace for the given shape.  On failure *out is NULL and
+   cesx_last_error(NULL) describes why. */
+int  cesx_create(const cesx_config* cfg, cesx_handle* out);
+void cesx_destroy(cesx_handle h);
+const char* cesx_last_error(cesx_handle h);
+int  cesx_abi_version(void);
+
+/* Replaces the externally-set object state self.mu, self.sigma, self.ustar
+   (examples/scripts/darcy-flow.py:68-75) and the per-call arguments y_obs,
+   Gamma of eks_update* (ces/calibrate.py:418).  All HOST pointers to fp64
+   arrays: y (n), Gamma (n x n, SPD), mu (p), Sigma (p x p, SPD), ustar (p).
+   Factorises Gamma and Sigma once (the reference re-solves them every step,
+   ces/calibrate.py:429, :443, :485). */
+int cesx_set_problem(cesx_handle h, const double* y, const double* Gamma,
+                     const double* mu, const double* Sigma, const double* ustar);
+
+/* ---- one step, single device ----------------------------------------- */
+
+/* Replaces one call of sampling.eks_update / eks_update_aldi /
+   eks_update_aldi_constant (ces/calibrate.py:418-529) on device-resident
+   arrays: U_dev (p x J_local), G_dev (n x J_local) inputs; xi_dev
+   (p x J_local) the injected N(0,1) block standing in for
+   np.random.normal(0,1,[p,J]) (:447, :488, :527), or NULL to draw it on
+   device (Philox4x32-10 keyed by seed, step_index, global particle index);
+   U_next_dev (p x J_local) output, must not alias U_dev.  `recenter` != 0
+   recomputes the centring shift from the data (required on the first call and
+   whenever U/G are unrelated to the previous call). */
+int cesx_step(cesx_handle h, const cesx_step_params* prm, const void* U_dev, const void* G_dev,
+              const void* xi_dev, void* U_next_dev, int recenter, void* stream);
+
+/* Waits for the last step on this handle and returns what the reference would
+   have appended to self.metrics / self.radspec.  Returns CESX_ENOTPD when the
+   ensemble covariance was not positive definite (U_next is then undefined). */
+int cesx_result(cesx_handle h, cesx_step_result* out);
+
+/* ---- split entry points (multi-device, testing) ----------------------- */
+
+/* Length in doubles of the packed moment buffer that is summed across devices:
+   [N, sum(u-s_u) (p), sum(g-s_g) (n), S_aa (p x p), S_ab (p x n), S_bb (n x n),
+    sum q_r^2, sum q_e^2, sum q_e, sum q_e*(g-s_g) (n)]. */
+size_t cesx_moments_len(cesx_handle h);
+
+/* Row sums of this shard: sums_dev[0] = J_local, then sum_j U (p), sum_j G (n)
+   (fp64).  After summing over devices pass the result to cesx_set_shift. */
+int cesx_colsum(cesx_handle h, const void* U_dev, const void* G_dev, double* sums_dev, void* stream);
+int cesx_set_shift(cesx_handle h, const double* sums_dev, void* stream);
+
+/* First half of a step (ces/calibrate.py:423-429 / :459-461 / :501-503 and the
+   metric sums of :432-435): shifted first and second moments of this shard in
+   fp64 into mom_dev (cesx_moments_len doubles).  Additive over shards. */
+int cesx_moments(cesx_handle h, const void* U_dev, const void* G_dev, double* mom_dev, void* stream);
+
+/* Second half: small dense algebra on the (summed) moments -- covariance,
+   Cholesky, gain, time step (ces/calibrate.py:243-267, :437-446, :469-487) --
+   and the fused drift + diffusion update of the shard (:443-447, :484-488). */
+int cesx_apply(cesx_handle h, const cesx_step_params* prm, const double* mom_dev,
+               const void* U_dev, const void* G_dev, const void* xi_dev,
+               void* U_next_dev, void* stream);
+
+/* eks_update_aldi_constant needs max|drift| over the WHOLE ensemble
+   (ces/calibrate.py:519).  cesx_apply_drift writes the drift into U_next_dev
+   and this shard's max|drift| into absmax_dev[0]; after a max-reduction over
+   devices cesx_apply_finish completes U_next = U + hk*drift + sqrt(2hk) L xi. */
+int cesx_apply_drift(cesx_handle h, const cesx_step_params* prm, const double* mom_dev,
+                     const void* U_dev, const void* G_dev, void* U_next_dev,
+                     double* absmax_dev, void* stream);
+int cesx_apply_finish(cesx_handle h, const cesx_step_params* prm, const double* absmax_dev,
+                      const void* U_dev, const void* xi_dev, void* U_next_dev, void* stream);
+
+/* Noise block the engine would draw for (step_index, shard): fills xi_dev
+   (p x J_local).  For tests of the generator. */
+int cesx_draw_noise(cesx_handle h, uint64_t step_index, void* xi_dev, void* stream);
+
+/* ---- forward-map hook --------------------------- */
+
+/* G = A U + b for the linear map utils.lineal (ces/utils.py:25-31) evaluated on
+   the whole shard at once instead of enka.G_ens' per-particle loop
+   (ces/calibrate.py:123-130).  A_dev (n x p, row-major, engine dtype), b_dev
+   (n) or NULL. */
+int cesx_forward_lineal(cesx_handle h, const void* A_dev, const void* b_dev,
+                        const void* U_dev, void* G_dev, void* stream);
+
+/* ---- introspection ---------------------------------------------------- */
+
+/* Copies the engine's current small dense state to HOST buffers (any may be
+   NULL): ubar (p), gbar (n), C (p x p), L = chol(C) (p x p), K (p x n),
+   M = C Sigma^{-1} (p x p).  Synchronises. */
+int cesx_debug_dense(cesx_handle h, double* ubar, double* gbar, double* C, double* L,
+                     double* K, double* M);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CESX_H */

@@ -1,0 +1,255 @@
+"""GPU parity: the HIP engine (through the C ABI) against the golden fixtures
+produced by the real reference and against the CPU oracle.
+
+Tolerances are BASELINE.json's: 1e-6 relative in fp64, 1e-3 relative in fp32
+(measured errors are far below both; the tighter internal bounds used for fp64
+are stated per test).
+"""
+import numpy as np
+import pytest
+
+from conftest import step_case, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL64 = 1e-6        # north star
+TOL64_TIGHT = 1e-9  # what fp64 actually delivers on the small golden cases
+TOL32 = 1e-3
+
+
+@pytest.fixture(scope="module")
+def eng_mod():
+    import torch
+    from ces_amd import build, engine
+    build.build_lib()
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return engine
+
+
+def _run_case(engine, case, c, dtype, xi="golden"):
+    eng = engine.Engine(case["p"], case["n_obs"], case["J"], dtype=dtype)
+    eng.set_problem(c["y"], c["Gamma"], c["mu"], c["sigma"], c["ustar"])
+    kw = case["kwargs"]
+    t_prev = case["t_prev"]
+    prm = engine.step_params(update=case["update"], time_step=kw.get("time_step"),
+                             first_step=case["trace_len"] == 1, t_len=len(t_prev),
+                             t_last=t_prev[-1] if t_prev else 0.0, delta_t=kw.get("delta_t"),
+                             spinup=kw.get("spinup", 4.0), switch=kw.get("switch", 1.0), T=30)
+    out = eng.step(prm, c["U0"], c["G"], xi=c["xi"] if xi == "golden" else xi)
+    res = eng.result()
+    return out.cpu().numpy().astype(np.float64), res, eng
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", TOL64_TIGHT), ("float32", TOL32)])
+def test_golden_steps(eng_mod, manifest, golden_steps, dtype, tol):
+    """Every golden step case of the reference: all three update rules, all time
+    step rules, dense/diagonal Gamma and Sigma, linear/non-linear G, first/later step."""
+    worst = {}
+    for case in manifest["steps"]:
+        c = step_case(golden_steps, case)
+        Uk, res, _ = _run_case(eng_mod, case, c, dtype)
+        err = rel_err(Uk, c["Uk"])
+        key = (case["update"], case["time_step_case"])
+        worst[key] = max(worst.get(key, 0.0), err)
+        assert err < tol, (case, err)
+        mtol = max(tol, 1e-8) * 20 if dtype == "float32" else 1e-8
+        assert res.t_new == pytest.approx(float(c["t_new"]), rel=mtol), case
+        assert res.hk == pytest.approx(float(c["hk"]), rel=mtol, abs=1e-300), case
+        got = np.array([res.self_bias, res.self_bias_data, res.bias_data, res.bias])
+        assert np.allclose(got, c["metrics"], rtol=mtol), (case, got, c["metrics"])
+        if case["kwargs"].get("time_step") == "spectral":
+            assert res.radspec == pytest.approx(float(c["radspec"][-1]), rel=mtol), case
+    print("worst relative error per (update, time step):", worst)
+
+
+def test_update_returns_new_array_and_keeps_input(eng_mod, manifest, golden_steps):
+    import torch
+    case = manifest["steps"][0]
+    c = step_case(golden_steps, case)
+    eng = eng_mod.Engine(case["p"], case["n_obs"], case["J"], dtype="float64")
+    eng.set_problem(c["y"], c["Gamma"], c["mu"], c["sigma"], c["ustar"])
+    U = eng.to_device(c["U0"])
+    before = U.clone()
+    out = eng.step(eng_mod.step_params(update="aldi"), U, eng.to_device(c["G"]), xi=eng.to_device(c["xi"]))
+    eng.result()
+    assert out.data_ptr() != U.data_ptr() and torch.equal(U, before)     # ces/calibrate.py:357
+    with pytest.raises(ValueError):
+        eng.step(eng_mod.step_params(update="aldi"), U, eng.to_device(c["G"]), out=U)
+
+
+def test_error_paths(eng_mod, manifest, golden_errors):
+    """Rank-deficient ensemble -> LinAlgError (ces/calibrate.py:446/:487/:526);
+    'adaptive' -> AttributeError (:255); unknown rule -> UnboundLocalError (:262)."""
+    for e in manifest["errors"]:
+        c = {k.split("_", 1)[1]: v for k, v in golden_errors.items() if k.startswith("e%d_" % e["id"])}
+        expected = {"LinAlgError": np.linalg.LinAlgError, "AttributeError": AttributeError,
+                    "UnboundLocalError": UnboundLocalError}[e["error"]]
+        with pytest.raises(expected):
+            eng = eng_mod.Engine(e["p"], e["n_obs"], e["J"], dtype="float64")
+            eng.set_problem(c["y"], c["Gamma"], c["mu"], c["sigma"], c["ustar"])
+            prm = eng_mod.step_params(update=e["update"], time_step=e["kwargs"].get("time_step"))
+            eng.step(prm, c["U0"], c["G"], xi=np.zeros((e["p"], e["J"])))
+            eng.result()
+
+
+@pytest.mark.parametrize("update", ["aldi", "eks", "aldi_constant"])
+def test_trajectory_c1_drop_in(eng_mod, manifest, golden_traj, update):
+    """BASELINE.json configs[0] through the drop-in class: same seeds as the
+    reference run -> same 30-step trajectory (noise='numpy' consumes the global
+    numpy stream exactly like ces/calibrate.py:447/:488/:527)."""
+    from ces_amd.calibrate import sampling
+    from ces_amd.utils import lineal
+    info = next(t for t in manifest["trajectories"] if t["update"] == update)
+    g = golden_traj
+    eks = sampling(p=info["p"], n_obs=info["n_obs"], J=info["J"])
+    eks.T = info["T"]
+    eks.ustar, eks.mu, eks.sigma = g["ustar"], g["mu"], g["sigma"]
+    np.random.seed(info["seed_u0"])
+    U0 = np.random.normal(0, 1, [info["p"], info["J"]])
+    assert np.array_equal(U0, g[update + "_U0"])
+    np.random.seed(info["seed_run"])
+    eks.run_eks(g["y"], U0, lineal(g["A"]), g["Gamma"], np.linalg.cholesky(g["Gamma"]), update=update, t_tol=1e9)
+    assert eks.Uall.shape == g[update + "_Uall"].shape
+    assert rel_err(eks.Uall, g[update + "_Uall"]) < TOL64
+    assert rel_err(eks.Gall, g[update + "_Gall"]) < TOL64
+    for k in ("self-bias", "self-bias-data", "bias-data", "bias", "t"):
+        assert np.allclose(eks.metrics[k], g[update + "_m_" + k], rtol=1e-6), k
+    assert eks.update_rule == info["update_rule"]
+    assert np.array_equal(eks.Ustar, eks.Uall[-1]) and eks.Gstar.shape == (info["n_obs"], info["J"])
+
+
+def _synthetic(p, n, J, seed, dense=False):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((n, p)) / np.sqrt(p)
+    ustar = rng.standard_normal((p, 1))
+    if dense:
+        B = rng.standard_normal((n, n)); Gamma = 0.01 * (B @ B.T / n + np.eye(n))
+        B = rng.standard_normal((p, p)); sigma = 10.0 * (B @ B.T / p + np.eye(p))
+    else:
+        Gamma, sigma = 0.01 * np.eye(n), 100.0 * np.eye(p)
+    y = (A @ ustar).ravel() + 0.1 * rng.standard_normal(n)
+    U0 = ustar + 0.5 * rng.standard_normal((p, J))
+    G = A @ U0 + 0.05 * np.sin(A @ U0)
+    xi = rng.standard_normal((p, J))
+    return dict(A=A, ustar=ustar, Gamma=Gamma, sigma=sigma, mu=np.zeros((p, 1)), y=y, U0=U0, G=G, xi=xi)
+
+
+@pytest.mark.parametrize("p,n,J,dense", [(64, 50, 8192, False), (256, 256, 4096, False),
+                                         (100, 37, 1001, True), (256, 256, 2048, True), (33, 65, 515, False)])
+@pytest.mark.parametrize("dtype,tol", [("float64", TOL64), ("float32", TOL32)])
+@pytest.mark.parametrize("update", ["aldi", "eks", "aldi_constant"])
+def test_medium_sizes_against_oracle(eng_mod, p, n, J, dense, dtype, tol, update):
+    """Sizes the CPU oracle finishes in seconds, including ragged J (not a
+    multiple of any tile), p/n not multiples of 16/32, config C4's p=64,n=50."""
+    from oracle import ces_numpy as oc
+    d = _synthetic(p, n, J, seed=p + n + J, dense=dense)
+    st = oc.OracleState(p, n, J, d["mu"], d["sigma"], d["ustar"])
+    ref = oc.factored_step(st, d["y"], d["U0"], d["G"], d["Gamma"], d["xi"], update=update)
+    eng = eng_mod.Engine(p, n, J, dtype=dtype)
+    eng.set_problem(d["y"], d["Gamma"], d["mu"], d["sigma"], d["ustar"])
+    out = eng.step(eng_mod.step_params(update=update), d["U0"], d["G"], xi=d["xi"])
+    res = eng.result()
+    assert rel_err(out.cpu().numpy(), ref) < tol
+    mt = 1e-7 if dtype == "float64" else 2e-3
+    assert res.hk == pytest.approx(st.metrics["t"][-1], rel=mt)
+    got = np.array([res.self_bias, res.self_bias_data, res.bias_data, res.bias])
+    want = np.array([st.metrics[k][-1] for k in ("self-bias", "self-bias-data", "bias-data", "bias")])
+    assert np.allclose(got, want, rtol=mt), (got, want)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_moments_against_oracle(eng_mod, dtype):
+    """K1 alone: ubar, gbar, C, K, M from the engine vs. the oracle's moments."""
+    from oracle import ces_numpy as oc
+    p, n, J = 48, 40, 3000
+    d = _synthetic(p, n, J, seed=5, dense=True)
+    eng = eng_mod.Engine(p, n, J, dtype=dtype)
+    eng.set_problem(d["y"], d["Gamma"], d["mu"], d["sigma"], d["ustar"])
+    eng.step(eng_mod.step_params(update="aldi"), d["U0"], d["G"], xi=d["xi"])
+    eng.result()
+    dd = eng.debug_dense()
+    cast = (lambda a: a.astype(np.float32).astype(np.float64)) if dtype == "float32" else (lambda a: a)
+    ubar, gbar, S_uu, S_ug, S_ee, _, _ = oc.moments(cast(d["U0"]), cast(d["G"]))
+    tol = 1e-10 if dtype == "float64" else 2e-5
+    assert rel_err(dd["ubar"], ubar.ravel()) < tol and rel_err(dd["gbar"], gbar.ravel()) < tol
+    C = S_uu / (J - 1) + 1e-8 * np.eye(p)
+    assert rel_err(dd["C"], C) < tol
+    assert rel_err(dd["L"], np.linalg.cholesky(C)) < tol * 50
+    assert rel_err(dd["K"], np.linalg.solve(d["Gamma"].T, (S_ug / J).T).T) < tol * 50
+    assert rel_err(dd["M"], np.linalg.solve(d["sigma"].T, C.T).T) < tol * 50
+
+
+@pytest.mark.parametrize("dtype,tol", [("float32", 2e-5), ("float64", 1e-12)])
+def test_device_noise_matches_philox_oracle(eng_mod, dtype, tol):
+    from oracle import philox
+    p, n, J = 7, 3, 1000
+    eng = eng_mod.Engine(p, n, J, dtype=dtype, seed=0x1234567890, j_offset=0)
+    xi = eng.draw_noise(5).cpu().numpy().astype(np.float64)
+    want = philox.noise_block(p, J, 0x1234567890, 5, dtype=dtype)
+    assert np.max(np.abs(xi - want)) < tol * 10
+    assert abs(xi.mean()) < 0.05 and abs(xi.std() - 1.0) < 0.05
+
+
+def test_noise_does_not_depend_on_sharding(eng_mod):
+    """Philox counters use the GLOBAL particle index."""
+    p, n, J = 6, 3, 512
+    whole = eng_mod.Engine(p, n, J, dtype="float32", seed=9).draw_noise(2).cpu().numpy()
+    a = eng_mod.Engine(p, n, 200, dtype="float32", seed=9, J_global=J, j_offset=0).draw_noise(2).cpu().numpy()
+    b = eng_mod.Engine(p, n, 312, dtype="float32", seed=9, J_global=J, j_offset=200).draw_noise(2).cpu().numpy()
+    assert np.array_equal(np.concatenate([a, b], axis=1), whole)
+
+
+def test_in_kernel_noise_equals_injected_noise(eng_mod):
+    """xi drawn inside the update kernel == the same block injected from memory."""
+    p, n, J = 40, 24, 1500
+    d = _synthetic(p, n, J, seed=3)
+    eng = eng_mod.Engine(p, n, J, dtype="float32", seed=77)
+    eng.set_problem(d["y"], d["Gamma"], d["mu"], d["sigma"], d["ustar"])
+    prm = eng_mod.step_params(update="aldi", step_index=4)
+    a = eng.step(prm, d["U0"], d["G"], xi=None).cpu().numpy()
+    eng.result()
+    xi = eng.draw_noise(4)
+    b = eng.step(prm, d["U0"], d["G"], xi=xi).cpu().numpy()
+    eng.result()
+    assert rel_err(a, b) < 1e-6
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-9), ("float32", 1e-4)])
+def test_logical_shards_add_up(eng_mod, dtype, tol):
+    """moments of N column shards sum to the moments of the whole
+    ensemble, and apply() on each shard reproduces the single-device step."""
+    import torch
+    p, n, J = 24, 20, 3000
+    d = _synthetic(p, n, J, seed=8)
+    whole = eng_mod.Engine(p, n, J, dtype=dtype)
+    whole.set_problem(d["y"], d["Gamma"], d["mu"], d["sigma"], d["ustar"])
+    prm = eng_mod.step_params(update="aldi")
+    ref = whole.step(prm, d["U0"], d["G"], xi=d["xi"]).cpu().numpy()
+    whole.result()
+    cuts = [0, 1000, 1800, J]
+    shards = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        e = eng_mod.Engine(p, n, b - a, dtype=dtype, J_global=J, j_offset=a)
+        e.set_problem(d["y"], d["Gamma"], d["mu"], d["sigma"], d["ustar"])
+        shards.append((e, e.to_device(d["U0"][:, a:b]), e.to_device(d["G"][:, a:b]), e.to_device(d["xi"][:, a:b])))
+    sums = sum(e.colsum(U, G) for e, U, G, _ in shards)           # stand-in for the all-reduce
+    for e, *_ in shards:
+        e.set_shift(sums)
+    mom = sum(e.moments(U, G) for e, U, G, _ in shards)
+    outs = [e.apply(prm, mom, U, G, xi=xi).cpu().numpy() for e, U, G, xi in shards]
+    for e, *_ in shards:
+        e.result()
+    torch.cuda.synchronize()
+    assert rel_err(np.concatenate(outs, axis=1), ref) < tol
+
+
+def test_forward_lineal_hook(eng_mod):
+    """ces/utils.py:25-31 on the whole shard."""
+    from ces_amd.utils import lineal
+    rng = np.random.default_rng(2)
+    p, n, J = 37, 21, 1234
+    A, b, U = rng.standard_normal((n, p)), rng.standard_normal(n), rng.standard_normal((p, J))
+    for dtype, tol in (("float64", 1e-12), ("float32", 1e-5)):
+        eng = eng_mod.Engine(p, n, J, dtype=dtype)
+        G = lineal(A, b=b).forward_device(eng, eng.to_device(U)).cpu().numpy()
+        assert rel_err(G, A @ U + b[:, None]) < tol
