@@ -180,7 +180,7 @@ class sampling(enka):
             self.radspec = []
             self.metrics = {k: [] for k in _METRIC_KEYS}
 
-    def _device_update(self, update, y_obs, U0, Geval, Gamma, **kwargs):
+    def _device_update(self, rule, y_obs, U0, Geval, Gamma, **kwargs):
         """One ensemble update through libcesx (K1 moments -> K2 dense -> K3 update)."""
         self._ensure_metrics()
         eng = self._get_engine()
@@ -188,12 +188,12 @@ class sampling(enka):
         t = self.metrics["t"]
         if not first and len(t) == 0:
             raise IndexError("list index out of range")          # ces/calibrate.py:265 / :523
-        prm = _engine.step_params(update=update, time_step=kwargs.get("time_step", None), first_step=first,
+        prm = _engine.step_params(update=rule, time_step=kwargs.get("time_step", None), first_step=first,
                                   t_len=len(t), t_last=t[-1] if t else 0.0,
                                   delta_t=kwargs.get("delta_t", None), spinup=kwargs.get("spinup", 4.0),
                                   switch=kwargs.get("switch", 1.0), step_index=self._step_counter, T=self.T)
         eng.set_problem(y_obs, Gamma, self.mu, self.sigma, self.ustar)
-        if update != "aldi_constant" and kwargs.get("time_step", None) == "adaptive":
+        if rule != "aldi_constant" and kwargs.get("time_step", None) == "adaptive":
             # ces/calibrate.py:255 calls self.LM_procedure, which is defined nowhere
             raise AttributeError("'sampling' object has no attribute 'LM_procedure'")
         xi = kwargs.get("xi", None)
@@ -209,7 +209,7 @@ class sampling(enka):
         m["bias"].append(res.bias)
         m["self-bias-data"].append(res.self_bias_data)
         m["bias-data"].append(res.bias_data)
-        if update != "aldi_constant" and kwargs.get("time_step", None) == "spectral":
+        if rule != "aldi_constant" and kwargs.get("time_step", None) == "spectral":
             self.radspec.append(res.radspec)
         m["t"].append(res.t_new)
         self._last_hk = res.hk
