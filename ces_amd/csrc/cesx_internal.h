@@ -185,6 +185,10 @@ struct Engine {
     void* d_W = nullptr;           // [rpad][ktot]
     void* d_bias = nullptr;        // [rpad]
     void* d_Wfwd = nullptr;        // forward-map staging [npad][kp]
+    // per-kernel profiling (cesx_profile_*)
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[2];
+    std::vector<hipEvent_t> prof_pool;
     // results
     cesx_step_result* h_res = nullptr;   // pinned
     Scalars* h_scal = nullptr;           // pinned
@@ -219,6 +223,22 @@ int gram_tile(int dtype);
 int gram_kt(int dtype);
 int gram_max_stage_rows();
 int launch_noise(Engine& e, uint64_t step_index, void* xi, hipStream_t s);
+
+// RAII-less helper: records an event pair around a launch when profiling is on
+struct ProfScope {
+    Engine& e; int which; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(Engine& e_, int which_, hipStream_t s_) : e(e_), which(which_), s(s_) {
+        if (!e.profile || which < 0) return;
+        auto get = [&]() { hipEvent_t ev = nullptr; if (!e.prof_pool.empty()) { ev = e.prof_pool.back(); e.prof_pool.pop_back(); } else (void)hipEventCreate(&ev); return ev; };
+        a = get(); b = get();
+        (void)hipEventRecord(a, s);
+    }
+    ~ProfScope() {
+        if (!a) return;
+        (void)hipEventRecord(b, s);
+        e.prof_ev[which].push_back({a, b});
+    }
+};
 
 #define CESX_HIP(call)                                                              \
     do {                                                                            \

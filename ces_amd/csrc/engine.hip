@@ -215,6 +215,9 @@ void cesx_destroy(cesx_handle h) {
                     e.d_c0, e.d_absmax_part};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
+    for (int w = 0; w < 2; ++w)
+        for (auto& pr : e.prof_ev[w]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto ev : e.prof_pool) (void)hipEventDestroy(ev);
     if (e.h_scal) (void)hipHostFree(e.h_scal);
     if (e.ev) (void)hipEventDestroy(e.ev);
     delete &e;
@@ -388,6 +391,34 @@ int cesx_forward_lineal(cesx_handle h, const void* A, const void* b, const void*
     UpdateSrc src[1] = {{U, e.p, 0}};
     return launch_update(e, e.n, e.d_Wfwd, e.kp, b, src, 1, nullptr, nullptr, 0.0, nullptr, nullptr, 0.0, G,
                          nullptr, 0, s);
+}
+
+int cesx_profile_enable(cesx_handle h, int on) {
+    if (!h) return CESX_EINVAL;
+    reinterpret_cast<Engine*>(h)->profile = on != 0;
+    return CESX_OK;
+}
+
+int cesx_profile_read(cesx_handle h, int which, double* total_ms, int* launches) {
+    if (!h) return CESX_EINVAL;
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    if (which < 0 || which > 1 || !total_ms || !launches) { e.err = "cesx_profile_read: bad argument"; return CESX_EINVAL; }
+    TRY(set_device(e));
+    double tot = 0.0;
+    int cnt = 0;
+    for (auto& pr : e.prof_ev[which]) {
+        CESX_HIP(hipEventSynchronize(pr.second));
+        float ms = 0.f;
+        CESX_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+        tot += ms;
+        ++cnt;
+        e.prof_pool.push_back(pr.first);
+        e.prof_pool.push_back(pr.second);
+    }
+    e.prof_ev[which].clear();
+    *total_ms = tot;
+    *launches = cnt;
+    return CESX_OK;
 }
 
 int cesx_debug_dense(cesx_handle h, double* ubar, double* gbar, double* C, double* L, double* K, double* M) {

@@ -303,9 +303,12 @@ static int launch_gram_t(Engine& e, const void* U, const void* G, double* mom, h
     auto kern = aligned ? gram_kernel<T, true> : gram_kernel<T, false>;
     CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(kern, grid, block, lds, s, (const T*)U, (const T*)G, (const T*)e.d_shiftT,
-                       e.p, e.n, (long long)e.J, e.d_type_hdr, e.d_rows, e.d_wblk, e.nslices,
-                       pl.nblocks, (T*)e.d_slabs);
+    {
+        ProfScope prof(e, 0, s);
+        hipLaunchKernelGGL(kern, grid, block, lds, s, (const T*)U, (const T*)G, (const T*)e.d_shiftT,
+                           e.p, e.n, (long long)e.J, e.d_type_hdr, e.d_rows, e.d_wblk, e.nslices,
+                           pl.nblocks, (T*)e.d_slabs);
+    }
     CESX_HIP(hipGetLastError());
     const long long total = (long long)pl.nblocks * pl.tile * pl.tile;
     hipLaunchKernelGGL(gram_reduce_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,

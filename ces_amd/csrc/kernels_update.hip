@@ -310,7 +310,10 @@ static int update_t(Engine& e, int out_rows, const void* W, int ktot, const void
     auto kern = aligned ? update_kernel<T, true> : update_kernel<T, false>;
     CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(kern, grid, dim3(UPD_THREADS), lds, s, a);
+    {
+        ProfScope prof(e, nsrc == 3 ? 1 : -1, s);   // only the full [U; G; xi] update is K3
+        hipLaunchKernelGGL(kern, grid, dim3(UPD_THREADS), lds, s, a);
+    }
     CESX_HIP(hipGetLastError());
     return CESX_OK;
 }

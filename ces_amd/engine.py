@@ -23,7 +23,7 @@ ABI_VERSION = 1
 EXPORTS = ("cesx_abi_version", "cesx_create", "cesx_destroy", "cesx_last_error", "cesx_set_problem",
            "cesx_step", "cesx_result", "cesx_moments_len", "cesx_colsum", "cesx_set_shift",
            "cesx_moments", "cesx_apply", "cesx_apply_drift", "cesx_apply_finish", "cesx_draw_noise",
-           "cesx_forward_lineal", "cesx_debug_dense")
+           "cesx_forward_lineal", "cesx_debug_dense", "cesx_profile_enable", "cesx_profile_read")
 
 
 class Config(C.Structure):
@@ -85,6 +85,8 @@ def load_library(path=None):
     lib.cesx_draw_noise.argtypes = [vp, u64, vp, vp]
     lib.cesx_forward_lineal.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.cesx_debug_dense.argtypes = [vp, dp, dp, dp, dp, dp, dp]
+    lib.cesx_profile_enable.argtypes = [vp, i32]
+    lib.cesx_profile_read.argtypes = [vp, i32, dp, C.POINTER(C.c_int)]
     if lib.cesx_abi_version() != ABI_VERSION:
         raise ImportError("libcesx.so ABI %d != binding ABI %d" % (lib.cesx_abi_version(), ABI_VERSION))
     if path == LIB_PATH:
@@ -276,6 +278,15 @@ class Engine:
                                                      U.data_ptr(), out.data_ptr(), self._stream()))
         self._keep = (A, bt, U, out)
         return out
+
+    def profile_enable(self, on=True):
+        self._check(self.lib.cesx_profile_enable(self._h, int(bool(on))))
+
+    def profile_read(self, which):
+        """(total ms, launches) of kernel 0 = Gram (K1) or 1 = update (K3) since the last read."""
+        ms, cnt = C.c_double(), C.c_int()
+        self._check(self.lib.cesx_profile_read(self._h, int(which), C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
 
     def debug_dense(self):
         p, n = self.p, self.n_obs

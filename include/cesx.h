@@ -194,6 +194,13 @@ int cesx_forward_lineal(cesx_handle h, const void* A_dev, const void* b_dev,
 
 /* ---- introspection ---------------------------------------------------- */
 
+/* Per-kernel timing with HIP events recorded on the launch stream around the
+   two O(J) kernels (which: 0 = Gram/moments kernel K1, 1 = update kernel K3).
+   cesx_profile_read synchronises, returns the summed milliseconds and the
+   number of launches since the last read, and resets the counters. */
+int cesx_profile_enable(cesx_handle h, int on);
+int cesx_profile_read(cesx_handle h, int which, double* total_ms, int* launches);
+
 /* Copies the engine's current small dense state to HOST buffers (any may be
    NULL): ubar (p), gbar (n), C (p x p), L = chol(C) (p x p), K (p x n),
    M = C Sigma^{-1} (p x p).  Synchronises. */
