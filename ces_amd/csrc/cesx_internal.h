@@ -169,6 +169,7 @@ struct Engine {
     double *d_K = nullptr, *d_Kp = nullptr, *d_M = nullptr, *d_P = nullptr, *d_PK = nullptr;
     double *d_t1 = nullptr, *d_t2 = nullptr, *d_t3 = nullptr, *d_t4 = nullptr;   // max(p,n)^2 each
     double *d_Wh = nullptr;        // chol(Gamma)^{-1} (dense Gamma, spectral rule)
+    double *d_Lp = nullptr;        // padded Cholesky workspace (round_up(max(p,n),32))^2
     double *d_lanczos = nullptr;
     int lanczos_steps = 96;
     double *d_absmax = nullptr;    // [1]
@@ -218,6 +219,7 @@ int launch_update(Engine& e, int out_rows, const void* W, int ktot, const void* 
                   void* out, double* absmax_part, uint64_t step_index, hipStream_t s);
 int update_grid_blocks(Engine& e, int out_rows);
 int launch_absmax_final(Engine& e, int nparts, double* absmax_out, hipStream_t s);
+int potrf_ld(int n);
 int gram_nbw(int dtype);
 int gram_tile(int dtype);
 int gram_kt(int dtype);

@@ -137,7 +137,8 @@ int cesx_create(const cesx_config* cfg, cesx_handle* out) {
     int rc;
     if ((rc = set_device(e))) return fail(rc);
     const int p = e.p, n = e.n, P = e.P, mx = p > n ? p : n;
-    const size_t pp = (size_t)p * p, pn = (size_t)p * n, nn = (size_t)n * n, mm = (size_t)mx * mx;
+    const size_t pp = (size_t)p * p, pn = (size_t)p * n, nn = (size_t)n * n;
+    const size_t mm = (size_t)potrf_ld(mx) * potrf_ld(mx);     // temporaries also hold padded Cholesky factors
 
     // gram plan
     e.plan = make_gram_plan(P, gram_tile(cfg->dtype), gram_nbw(cfg->dtype), gram_max_stage_rows());
@@ -184,8 +185,9 @@ int cesx_create(const cesx_config* cfg, cesx_handle* out) {
     DM(e.d_colsum_partq, (size_t)P * e.colsum_slices * 8);
     DM(e.d_mom, e.mom_len * 8); DM(e.d_sums, (1 + P) * 8);
     DM(e.d_ubar, p * 8); DM(e.d_gbar, n * 8); DM(e.d_m, n * 8); DM(e.d_dg, n * 8); DM(e.d_wdel, n * 8);
-    DM(e.d_C, pp * 8); DM(e.d_L, pp * 8); DM(e.d_Cug, pn * 8); DM(e.d_See, nn * 8); DM(e.d_Srr, nn * 8);
+    DM(e.d_C, pp * 8); DM(e.d_L, (size_t)potrf_ld(p) * potrf_ld(p) * 8); DM(e.d_Cug, pn * 8); DM(e.d_See, nn * 8); DM(e.d_Srr, nn * 8);
     DM(e.d_K, pn * 8); DM(e.d_Kp, pn * 8); DM(e.d_M, pp * 8); DM(e.d_P, pp * 8); DM(e.d_PK, pn * 8);
+    { const size_t np_ = (size_t)(mx + 31) / 32 * 32; DM(e.d_Lp, np_ * np_ * 8); }
     DM(e.d_t1, mm * 8); DM(e.d_t2, mm * 8); DM(e.d_t3, mm * 8); DM(e.d_t4, mm * 8);
     DM(e.d_lanczos, ((size_t)(e.lanczos_steps + 1) * n + 2 * e.lanczos_steps) * 8);
     DM(e.d_mv, (size_t)6 * mx * 8); DM(e.d_part, 64 * 4 * 8);
@@ -211,7 +213,7 @@ void cesx_destroy(cesx_handle h) {
                     e.d_bias, e.d_Wfwd, e.d_type_hdr, e.d_rows, e.d_wblk, e.d_blk_rc, e.d_stat_part,
                     e.d_colsum_part, e.d_colsum_partq, e.d_mom, e.d_sums, e.d_ubar, e.d_gbar, e.d_m, e.d_dg,
                     e.d_wdel, e.d_C, e.d_L, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_Kp, e.d_M, e.d_P, e.d_PK,
-                    e.d_t1, e.d_t2, e.d_t3, e.d_t4, e.d_lanczos, e.d_mv, e.d_part, e.d_scal, e.d_absmax,
+                    e.d_t1, e.d_t2, e.d_t3, e.d_t4, e.d_Lp, e.d_lanczos, e.d_mv, e.d_part, e.d_scal, e.d_absmax,
                     e.d_c0, e.d_absmax_part};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
@@ -430,7 +432,12 @@ int cesx_debug_dense(cesx_handle h, double* ubar, double* gbar, double* C, doubl
     if (ubar) CESX_HIP(hipMemcpy(ubar, e.d_ubar, p * 8, hipMemcpyDeviceToHost));
     if (gbar) CESX_HIP(hipMemcpy(gbar, e.d_gbar, n * 8, hipMemcpyDeviceToHost));
     if (C) CESX_HIP(hipMemcpy(C, e.d_C, p * p * 8, hipMemcpyDeviceToHost));
-    if (L) CESX_HIP(hipMemcpy(L, e.d_L, p * p * 8, hipMemcpyDeviceToHost));
+    if (L) {
+        const size_t ld = potrf_ld(e.p);
+        CESX_HIP(hipMemcpy2D(L, p * 8, e.d_L, ld * 8, p * 8, p, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < p; ++i)
+            for (size_t j = i + 1; j < p; ++j) L[i * p + j] = 0.0;     // the factor's upper triangle is not stored
+    }
     if (K) CESX_HIP(hipMemcpy(K, e.d_K, p * n * 8, hipMemcpyDeviceToHost));
     if (M) CESX_HIP(hipMemcpy(M, e.d_M, p * p * 8, hipMemcpyDeviceToHost));
     return CESX_OK;

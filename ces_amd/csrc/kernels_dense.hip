@@ -13,6 +13,7 @@
 namespace cesx {
 
 constexpr int NPB = 64;          // partial-sum blocks
+int potrf_ld(int n);
 constexpr int DT = 256;
 
 __device__ __forceinline__ double dblock_sum(double v, double* red) {
@@ -168,103 +169,315 @@ void matvec_kernel(int rows, int cols, const double* __restrict__ A, const doubl
 // zero strict upper triangle.  A non-positive pivot sets *status = CESX_ENOTPD
 // (np.linalg.LinAlgError at ces/calibrate.py:446/:487/:526).
 // ---------------------------------------------------------------------------
-constexpr int PT = 1024;   // threads
+constexpr int PT = 512;    // threads (<= 256 VGPRs each: a 32-value row lives in registers)
+constexpr int PNB = 32;    // panel width
+#ifndef POTRF_S1      // dev switches of tools/potrf_bench.hip (timing ablation only)
+#define POTRF_S1 1
+#define POTRF_S2 1
+#define POTRF_S3 1
+#endif
 
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+
+// One workgroup, right-looking, 32-column panels:
+//   1. the 32 x 32 diagonal block is factored by ONE wave with row i in the
+//      registers of lane i (column values broadcast with v_readlane, no LDS
+//      round trips, no barriers inside the block)
+//   2. every row below solves x L11^T = a with its 32 values in registers
+//      (L11 read from LDS as broadcasts)
+//   3. trailing update A22 -= L21 L21^T in 4 x 4 register patches from LDS.
 __global__ __launch_bounds__(PT)
-void potrf_kernel(int n, const double* __restrict__ A, double* __restrict__ L, int nb, int* status) {
+void potrf_kernel(int n, int np, const double* __restrict__ A, double* __restrict__ Lp,
+                  double* __restrict__ L, int* status) {
+    // Lp: np x np workspace, np = n rounded up to 32; the padding is an identity
+    // block so that every panel is exactly 32 wide (no ragged-edge branches in
+    // the fully unrolled register code).
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int ldp = nb + 1;
-    double* D = reinterpret_cast<double*>(smem);          // [nb][ldp] diagonal block
-    double* Pn = D + nb * ldp;                            // [n][ldp] panel below it
+    constexpr int ldp = PNB + 1;
+    double* D = reinterpret_cast<double*>(smem);          // [32][33] diagonal block (factor)
+    double* rinv = D + PNB * ldp;                         // [32] 1 / l_jj
+    double* Pn = rinv + PNB;                              // [np][33] panel below it
     const int tid = threadIdx.x;
-    // L <- lower(A), upper <- 0
-    for (long long idx = tid; idx < (long long)n * n; idx += PT) {
-        const int i = (int)(idx / n), j = (int)(idx % n);
-        L[idx] = j <= i ? A[idx] : 0.0;
+    for (long long idx = tid; idx < (long long)np * np; idx += PT) {
+        const int i = (int)(idx / np), j = (int)(idx % np);
+        Lp[idx] = (i < n && j <= i) ? A[(size_t)i * n + j] : ((i == j) ? 1.0 : 0.0);
     }
     __syncthreads();
-    for (int kb = 0; kb < n; kb += nb) {
-        const int w = min(nb, n - kb);
-        const int m = n - kb - w;                         // rows below the diagonal block
-        for (int idx = tid; idx < w * w; idx += PT) {
-            const int i = idx / w, j = idx % w;
-            D[i * ldp + j] = L[(size_t)(kb + i) * n + kb + j];
+    for (int kb = 0; kb < np; kb += PNB) {
+        const int m = np - kb - PNB;
+        // ---- 1. diagonal block, wave 0, lane = row
+        if (POTRF_S1 && tid < 64) {
+            const int i = tid & 31;
+            const double* src = Lp + (size_t)(kb + i) * np + kb;
+            double d[PNB];
+#pragma clang loop unroll(full)
+            for (int j = 0; j < PNB; ++j) d[j] = src[j];
+            bool bad = false;
+#pragma clang loop unroll(full)
+            for (int j = 0; j < PNB; ++j) {
+                double djj = readlane_d(d[j], j);
+                if (!(djj > 0.0)) { bad = true; djj = 1.0; }
+                const double rs = 1.0 / sqrt(djj);
+                const double lij = (i == j) ? djj * rs : d[j] * rs;
+                d[j] = lij;
+                if (i == j) rinv[j] = rs;
+#pragma clang loop unroll(full)
+                for (int k = j + 1; k < PNB; ++k) {
+                    // no lane predicate: entries above the diagonal of a lane's row
+                    // collect garbage that nothing ever reads
+                    d[k] -= lij * readlane_d(lij, k);
+                }
+            }
+            if (bad && tid == 0) *status = CESX_ENOTPD;
+            if (tid < 32) {
+                double* dst = Lp + (size_t)(kb + i) * np + kb;
+#pragma clang loop unroll(full)
+                for (int j = 0; j < PNB; ++j) {
+                    const double v = j <= i ? d[j] : 0.0;
+                    D[i * ldp + j] = v;
+                    dst[j] = v;
+                }
+            }
         }
         __syncthreads();
-        // unblocked factorisation of the w x w diagonal block (first w threads, row i each)
-        for (int j = 0; j < w; ++j) {
-            if (tid == 0) {
-                double d = D[j * ldp + j];
-                if (!(d > 0.0)) { *status = CESX_ENOTPD; d = 1.0; }
-                D[j * ldp + j] = sqrt(d);
+        // ---- 2. panel rows: x L11^T = a, one row per thread, row in registers
+        for (int r = tid; POTRF_S2 && r < m; r += PT) {
+            double* row = Lp + (size_t)(kb + PNB + r) * np + kb;
+            double x[PNB];
+#pragma clang loop unroll(full)
+            for (int j = 0; j < PNB; ++j) x[j] = row[j];
+#pragma clang loop unroll(full)
+            for (int j = 0; j < PNB; ++j) {
+                double sacc = x[j];
+#pragma clang loop unroll(full)
+                for (int k = 0; k < j; ++k) sacc -= x[k] * D[j * ldp + k];
+                x[j] = sacc * rinv[j];
+                asm volatile("" ::: "memory");           // stop LICM from hoisting all 496 LDS reads of D
             }
-            __syncthreads();
-            if (tid > j && tid < w) {
-                const double lij = D[tid * ldp + j] / D[j * ldp + j];
-                D[tid * ldp + j] = lij;
+#pragma clang loop unroll(full)
+            for (int j = 0; j < PNB; ++j) {
+                Pn[r * ldp + j] = x[j];
+                row[j] = x[j];
             }
-            __syncthreads();
-            if (tid > j && tid < w) {
-                const double lij = D[tid * ldp + j];
-                for (int k = j + 1; k <= tid; ++k) D[tid * ldp + k] -= lij * D[k * ldp + j];
-            }
-            __syncthreads();
-        }
-        for (int idx = tid; idx < w * w; idx += PT) {
-            const int i = idx / w, j = idx % w;
-            if (j <= i) L[(size_t)(kb + i) * n + kb + j] = D[i * ldp + j];
-        }
-        // panel: rows below solve x D^T = a
-        for (int r = tid; r < m; r += PT) {
-            double* row = L + (size_t)(kb + w + r) * n + kb;
-            for (int j = 0; j < w; ++j) {
-                double s = row[j];
-                for (int k = 0; k < j; ++k) s -= Pn[r * ldp + k] * D[j * ldp + k];
-                s /= D[j * ldp + j];
-                Pn[r * ldp + j] = s;
-            }
-            for (int j = 0; j < w; ++j) row[j] = Pn[r * ldp + j];
         }
         __syncthreads();
-        // trailing update A22 -= Pn Pn^T (lower part), 4 x 4 patches
-        const int mb = (m + 3) / 4;
-        for (int pt = tid; pt < mb * mb; pt += PT) {
-            const int bi = pt / mb, bj = pt % mb;
-            if (bj > bi) continue;
+        // ---- 3. trailing update (lower part), 4 x 4 patches (m is a multiple of 32)
+        const int mb = m / 4;
+        const int npatch = mb * (mb + 1) / 2;
+        for (int pt = tid; POTRF_S3 && pt < npatch; pt += PT) {
+            int bi = (int)((sqrt(8.0 * pt + 1.0) - 1.0) * 0.5);
+            while ((bi + 1) * (bi + 2) / 2 <= pt) ++bi;
+            while (bi * (bi + 1) / 2 > pt) --bi;
+            const int bj = pt - bi * (bi + 1) / 2;
             double acc[4][4] = {};
-            for (int k = 0; k < w; ++k) {
+            const double* pa = Pn + bi * 4 * ldp;
+            const double* pb = Pn + bj * 4 * ldp;
+#pragma unroll 8
+            for (int k = 0; k < PNB; ++k) {
                 double a[4], b[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    a[e] = (bi * 4 + e < m) ? Pn[(bi * 4 + e) * ldp + k] : 0.0;
-                    b[e] = (bj * 4 + e < m) ? Pn[(bj * 4 + e) * ldp + k] : 0.0;
-                }
+                for (int e = 0; e < 4; ++e) { a[e] = pa[e * ldp + k]; b[e] = pb[e * ldp + k]; }
 #pragma unroll
                 for (int x = 0; x < 4; ++x)
 #pragma unroll
                     for (int z = 0; z < 4; ++z) acc[x][z] += a[x] * b[z];
             }
+            double* dst = Lp + (size_t)(kb + PNB + bi * 4) * np + kb + PNB + bj * 4;
 #pragma unroll
             for (int x = 0; x < 4; ++x)
 #pragma unroll
-                for (int z = 0; z < 4; ++z) {
-                    const int i = bi * 4 + x, j = bj * 4 + z;
-                    if (i < m && j <= i) L[(size_t)(kb + w + i) * n + kb + w + j] -= acc[x][z];
-                }
+                for (int z = 0; z < 4; ++z)
+                    if (bj * 4 + z <= bi * 4 + x) dst[(size_t)x * np + z] -= acc[x][z];
         }
         __syncthreads();
     }
+    if (L != nullptr)
+        for (long long idx = tid; idx < (long long)n * n; idx += PT) {
+            const int i = (int)(idx / n), j = (int)(idx % n);
+            L[idx] = j <= i ? Lp[(size_t)i * np + j] : 0.0;
+        }
+}
+
+// ---------------------------------------------------------------------------
+// Register-resident Cholesky for np <= 256 (np = n rounded up to 32).  The
+// lower triangle lives in the accumulator registers of 8 waves as 16 x 16
+// tiles in v_mfma_f64_16x16x4_f64 C/D layout (np = 256: 136 tiles, 17 per
+// wave, 136 VGPRs); only the current 8-column panel passes through LDS
+// (k-major image PnT[k][row], double buffered).  No global traffic between
+// the initial load and the store of each finished panel -- a single CU moves
+// only ~10 B/clk, which is what bounds the global-memory version above.
+// Per panel of 8 columns:
+//   (b) every wave factors the 8 x 8 diagonal block redundantly (lane & 7 =
+//       row, column broadcast by v_readlane, pivots by v_rsq_f64 + Newton):
+//       no barrier, no LDS round trip
+//   (c) each row below solves x L11^T = a with L11 in SGPRs
+//   (d) rank-8 update of every tile right of the panel with two fp64 MFMAs
+//       (operands are contiguous LDS reads), then the next panel's columns
+//       are published into the other LDS buffer.
+// Two barriers per panel.  A : n x n (lower part read); Lp : np x np, leading
+// dimension np, entries above the diagonal are left undefined.
+// ---------------------------------------------------------------------------
+constexpr int PRT = 512;
+constexpr int QNB = 8;
+using d4_t = double __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double rsqrt_nr(double a) {
+    double y = __builtin_amdgcn_rsq(a);                   // v_rsq_f64: ~26 good bits
+    y = y * (1.5 - 0.5 * a * y * y);
+    y = y * (1.5 - 0.5 * a * y * y);
+    return y;
+}
+
+template <int SLOTS>
+__global__ __launch_bounds__(PRT, 2)
+void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __restrict__ Lp, int* status,
+                      long long* dbg = nullptr) {   // dbg: per-phase cycle counts (tools/potrf_bench only)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ldt = np + 4;
+    double* PnT = reinterpret_cast<double*>(smem);        // [2][8][ldt]
+    const int tid = threadIdx.x, lane = tid & 63, i8 = lane & 7;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = np / 16;
+    const int ntile = T * (T + 1) / 2;
+    const int lc = lane & 15, lr = lane >> 4;             // C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg
+
+    d4_t Pt[SLOTS];
+    int tR[SLOTS], tC[SLOTS];
+#pragma clang loop unroll(full)
+    for (int s = 0; s < SLOTS; ++s) {
+        const int q = wave + 8 * s;                       // tiles dealt round-robin to the 8 waves
+        int R = (int)((sqrt(8.0 * q + 1.0) - 1.0) * 0.5);
+        while ((R + 1) * (R + 2) / 2 <= q) ++R;
+        while (R * (R + 1) / 2 > q) --R;
+        const int Cc = q - R * (R + 1) / 2;
+        const bool on = q < ntile;
+        tR[s] = on ? R : -1;
+        tC[s] = on ? Cc : 0;
+#pragma clang loop unroll(full)
+        for (int e = 0; e < 4; ++e) {
+            int i = R * 16 + lr + 4 * e, j = Cc * 16 + lc;
+            double v = (i == j) ? 1.0 : 0.0;              // identity padding
+            if (j > i) { const int t = i; i = j; j = t; } // diagonal tiles are kept fully symmetric
+            if (on && i < n) v = A[(size_t)i * n + j];
+            Pt[s][e] = v;
+        }
+    }
+    long long tph[5] = {0, 0, 0, 0, 0}, tl = clock64();
+#define PH(i) if (dbg) { const long long t_ = clock64(); tph[i] += t_ - tl; tl = t_; }
+    // columns kbn .. kbn+7 of tile s -> buf[col - kbn][row - kbn] (rows at or below the panel's diagonal block)
+    auto publish = [&](int s, int kbn, double* buf) {
+        const int col = tC[s] * 16 + lc - kbn;
+        if (col >= 0 && col < QNB) {
+#pragma clang loop unroll(full)
+            for (int e = 0; e < 4; ++e) {
+                const int row = tR[s] * 16 + lr + 4 * e - kbn;
+                if (row >= 0) buf[col * ldt + row] = Pt[s][e];
+            }
+        }
+    };
+#pragma clang loop unroll(full)
+    for (int s = 0; s < SLOTS; ++s)
+        if (tR[s] >= 0 && tC[s] == 0) publish(s, 0, PnT);
+    __syncthreads();
+    PH(0)
+
+    for (int kb = 0; kb < np; kb += QNB) {
+        double* cur = PnT + ((kb / QNB) & 1) * QNB * ldt;
+        double* nxt = PnT + (((kb / QNB) & 1) ^ 1) * QNB * ldt;
+        const int m = np - kb;
+        // (b) 8 x 8 diagonal block, redundantly per wave
+        double d[QNB];
+#pragma clang loop unroll(full)
+        for (int j = 0; j < QNB; ++j) d[j] = cur[j * ldt + i8];
+        double rinv[QNB];
+        bool bad = false;
+#pragma clang loop unroll(full)
+        for (int j = 0; j < QNB; ++j) {
+            double djj = readlane_d(d[j], j);
+            if (!(djj > 0.0)) { bad = true; djj = 1.0; }
+            const double rs = rsqrt_nr(djj);
+            rinv[j] = rs;
+            const double lij = (i8 == j) ? djj * rs : d[j] * rs;
+            d[j] = lij;
+#pragma clang loop unroll(full)
+            for (int k = j + 1; k < QNB; ++k) d[k] -= lij * readlane_d(lij, k);
+        }
+        if (bad && tid == 0) *status = CESX_ENOTPD;
+        // (c) rows below the block: x L11^T = a
+        const int r = QNB + tid;
+        if (r < m) {
+            double x[QNB];
+#pragma clang loop unroll(full)
+            for (int j = 0; j < QNB; ++j) x[j] = cur[j * ldt + r];
+#pragma clang loop unroll(full)
+            for (int j = 0; j < QNB; ++j) {
+                double sacc = x[j];
+#pragma clang loop unroll(full)
+                for (int k = 0; k < j; ++k) sacc -= x[k] * readlane_d(d[k], j);      // L11[j][k]
+                x[j] = sacc * rinv[j];
+            }
+            double* dst = Lp + (size_t)(kb + r) * np + kb;
+#pragma clang loop unroll(full)
+            for (int j = 0; j < QNB; ++j) {
+                cur[j * ldt + r] = x[j];
+                dst[j] = x[j];
+            }
+        }
+        if (tid < QNB) {                                   // the factored diagonal block itself
+            double* dst = Lp + (size_t)(kb + tid) * np + kb;
+#pragma clang loop unroll(full)
+            for (int j = 0; j < QNB; ++j) {
+                const double v = j <= tid ? d[j] : 0.0;
+                cur[j * ldt + tid] = v;
+                dst[j] = v;
+            }
+        }
+        __syncthreads();
+        PH(2)
+        // (d) rank-8 update of the tiles whose columns lie right of the panel (two MFMAs per
+        //     tile: A = -L21 rows of the tile, B = L21 rows of the tile's columns); the tile
+        //     that holds the next panel's columns is updated too, then published
+        const int kn = kb + QNB;                          // first column of the next panel
+#pragma clang loop unroll(full)
+        for (int s = 0; s < SLOTS; ++s) {
+            if (tR[s] >= 0 && tC[s] * 16 + 15 >= kn) {
+                const double* pa = cur + tR[s] * 16 - kb + lc;      // row index of the A operand = lane & 15
+                const double* pb = cur + tC[s] * 16 - kb + lc;
+                // rows / columns left of kn inside this tile read panel rows < 8 (or negative
+                // offsets for finished columns): those products only touch entries that are
+                // never used again, but the addresses must stay inside the buffer
+                const bool aok = tR[s] * 16 + lc >= kb, bok = tC[s] * 16 + lc >= kb;
+#pragma clang loop unroll(full)
+                for (int h = 0; h < 2; ++h) {
+                    const double av = aok ? -pa[(4 * h + lr) * ldt] : 0.0;
+                    const double bv = bok ? pb[(4 * h + lr) * ldt] : 0.0;
+                    Pt[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, Pt[s], 0, 0, 0);
+                }
+                if (kn < np && tC[s] == kn / 16) publish(s, kn, nxt);
+            }
+        }
+        __syncthreads();
+        PH(4)
+    }
+    if (dbg && tid == 0)
+        for (int i = 0; i < 5; ++i) dbg[i] = tph[i];
+#undef PH
 }
 
 // Linv = L^{-1} for lower-triangular L, one column per thread (forward substitution).
 __global__ __launch_bounds__(PT)
-void trtri_kernel(int n, const double* __restrict__ L, double* __restrict__ Linv) {
+void trtri_kernel(int n, const double* __restrict__ L, int ldl, double* __restrict__ Linv) {
     for (int j = threadIdx.x; j < n; j += PT) {
         for (int i = 0; i < j; ++i) Linv[(size_t)i * n + j] = 0.0;
         for (int i = j; i < n; ++i) {
             double s = (i == j) ? 1.0 : 0.0;
-            for (int k = j; k < i; ++k) s -= L[(size_t)i * n + k] * Linv[(size_t)k * n + j];
-            Linv[(size_t)i * n + j] = s / L[(size_t)i * n + i];
+            for (int k = j; k < i; ++k) s -= L[(size_t)i * ldl + k] * Linv[(size_t)k * n + j];
+            Linv[(size_t)i * n + j] = s / L[(size_t)i * ldl + i];
         }
     }
 }
@@ -460,7 +673,7 @@ __global__ void constant_hk_kernel(cesx_step_params prm, const double* __restric
 template <typename T>
 __global__ void assemble_kernel(int mode, int p, int n, int kp, int kn, int rpad, int ktot, double sw,
                                 const Scalars* __restrict__ sc, const double* __restrict__ M,
-                                const double* __restrict__ K, const double* __restrict__ L,
+                                const double* __restrict__ K, const double* __restrict__ L, int ldl,
                                 const double* __restrict__ P, const double* __restrict__ PK,
                                 const double* __restrict__ mvs, int mx, const double* __restrict__ ubar,
                                 const double* __restrict__ gbar, T* __restrict__ W, T* __restrict__ bias,
@@ -477,7 +690,7 @@ __global__ void assemble_kernel(int mode, int p, int n, int kp, int kn, int rpad
         double v = 0.0;
         if (i < p) {
             if (mode == 3) {
-                if (k < p && k <= i) v = s2 * L[(size_t)i * p + k];
+                if (k < p && k <= i) v = s2 * L[(size_t)i * ldl + k];
             } else if (k < kp) {
                 if (k < p) {
                     if (mode == 0) v = (i == k ? 1.0 + hk * al : 0.0) - hk * M[(size_t)i * p + k];
@@ -493,7 +706,7 @@ __global__ void assemble_kernel(int mode, int p, int n, int kp, int kn, int rpad
                 }
             } else {
                 const int c = k - kp - kn;
-                if (c < p && c <= i && mode != 2) v = s2 * L[(size_t)i * p + c];
+                if (c < p && c <= i && mode != 2) v = s2 * L[(size_t)i * ldl + c];
             }
         }
         W[idx] = (T)v;
@@ -550,14 +763,35 @@ static int gemm(Engine& e, hipStream_t s, int m, int n, int k, double alpha, con
     return CESX_OK;
 }
 
-static int potrf(Engine& e, hipStream_t s, int n, const double* A, double* L) {
-    int nb = 32;
-    while (nb > 4 && (size_t)(n + nb) * (nb + 1) * 8 > 150 * 1024) nb /= 2;
-    const size_t lds = (size_t)(n + nb) * (nb + 1) * 8;
+template <int SLOTS>
+static int potrf_reg_launch(Engine& e, hipStream_t s, int n, int np, const double* A, double* Lp) {
+    const size_t lds = (size_t)2 * QNB * (np + 4) * 8;
+    CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_reg_kernel<SLOTS>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(potrf_reg_kernel<SLOTS>, dim3(1), dim3(PRT), lds, s, n, np, A, Lp, &e.d_scal->status, (long long*)nullptr);
+    CESX_HIP(hipGetLastError());
+    return CESX_OK;
+}
+
+// Cholesky factor of the n x n SPD matrix A into Lp (leading dimension
+// potrf_ld(n) = n rounded up to 32; entries above the diagonal are undefined).
+int potrf_ld(int n) { return (n + PNB - 1) / PNB * PNB; }
+
+static int potrf(Engine& e, hipStream_t s, int n, const double* A, double* Lp) {
+    const int np = potrf_ld(n);
+    {
+        const int T = np / 16, ntile = T * (T + 1) / 2, slots = (ntile + 7) / 8;
+        if (slots <= 2) return potrf_reg_launch<2>(e, s, n, np, A, Lp);       // np <= 64
+        if (slots <= 5) return potrf_reg_launch<5>(e, s, n, np, A, Lp);       // np <= 128
+        if (slots <= 10) return potrf_reg_launch<10>(e, s, n, np, A, Lp);     // np <= 192
+        if (slots <= 17) return potrf_reg_launch<17>(e, s, n, np, A, Lp);     // np <= 256
+        // larger matrices: global-memory version below
+    }
+    const size_t lds = ((size_t)(np + PNB) * (PNB + 1) + PNB) * 8;
     if (lds > 160 * 1024) { e.err = "potrf: matrix too large for the single-workgroup kernel"; return CESX_EINVAL; }
     CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(potrf_kernel, dim3(1), dim3(PT), lds, s, n, A, L, nb, &e.d_scal->status);
+    hipLaunchKernelGGL(potrf_kernel, dim3(1), dim3(PT), lds, s, n, np, A, Lp, (double*)nullptr, &e.d_scal->status);
     CESX_HIP(hipGetLastError());
     return CESX_OK;
 }
@@ -566,7 +800,7 @@ static int potrf(Engine& e, hipStream_t s, int n, const double* A, double* L) {
 static int spd_inverse(Engine& e, hipStream_t s, int n, const double* A, double* Ainv) {
     int rc;
     if ((rc = potrf(e, s, n, A, e.d_t1))) return rc;
-    hipLaunchKernelGGL(trtri_kernel, dim3(1), dim3(PT), 0, s, n, e.d_t1, e.d_t2);
+    hipLaunchKernelGGL(trtri_kernel, dim3(1), dim3(PT), 0, s, n, e.d_t1, potrf_ld(n), e.d_t2);
     CESX_HIP(hipGetLastError());
     // Ainv = Linv^T Linv : A(i,k) = Linv[k][i]
     return gemm(e, s, n, n, n, 1.0, e.d_t2, 1, n, e.d_t2, n, 1, Ainv);
@@ -577,7 +811,7 @@ static int assemble(Engine& e, hipStream_t s, int mode, int ktot, double sw) {
     const int mx = e.p > e.n ? e.p : e.n;
     const long long len = (long long)e.rpad * ktot;
     hipLaunchKernelGGL(assemble_kernel<T>, g1(len), dim3(256), 0, s, mode, e.p, e.n, e.kp, e.kn, e.rpad, ktot,
-                       sw, e.d_scal, e.d_M, e.d_K, e.d_L, e.d_P, e.d_PK, e.d_mv, mx, e.d_ubar, e.d_gbar,
+                       sw, e.d_scal, e.d_M, e.d_K, e.d_L, potrf_ld(e.p), e.d_P, e.d_PK, e.d_mv, mx, e.d_ubar, e.d_gbar,
                        (T*)e.d_W, (T*)e.d_bias, (T*)e.d_shiftT, e.d_shift64);
     CESX_HIP(hipGetLastError());
     return CESX_OK;

@@ -1,0 +1,37 @@
+// dev tool: time potrf_kernel alone.  hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/potrf_bench.hip -o /tmp/potrf_bench
+#include "../ces_amd/csrc/kernels_dense.hip"
+#include <cstdio>
+#ifndef SLOTS
+#define SLOTS 17
+#endif
+#include <vector>
+#include <random>
+int main(int argc, char** argv) {
+    int n = argc > 1 ? atoi(argv[1]) : 256;
+    int np = (n + 31) / 32 * 32;
+    std::vector<double> B((size_t)n * n), A((size_t)n * n);
+    std::mt19937 g(1); std::normal_distribution<double> nd;
+    for (auto& v : B) v = nd(g);
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { double s = 0; for (int k = 0; k < n; ++k) s += B[i*n+k]*B[j*n+k]; A[i*n+j] = s / n + (i == j); }
+    double *dA, *dL, *dLp; int* st;
+    hipMalloc(&dA, n*n*8); hipMalloc(&dL, n*n*8); hipMalloc(&dLp, np*np*8); hipMalloc(&st, 4);
+    hipMemcpy(dA, A.data(), n*n*8, hipMemcpyHostToDevice); hipMemset(st, 0, 4);
+    size_t lds = (size_t)2 * 8 * (np + 4) * 8;
+    auto kern = cesx::potrf_reg_kernel<SLOTS>;
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    long long* dbg; hipMalloc(&dbg, 64);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(kern, dim3(1), dim3(cesx::PRT), lds, 0, n, np, dA, dLp, st, (long long*)nullptr);
+    hipEventRecord(e0);
+    for (int it = 0; it < 10; ++it) hipLaunchKernelGGL(kern, dim3(1), dim3(cesx::PRT), lds, 0, n, np, dA, dLp, st, (long long*)nullptr);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    std::vector<double> L((size_t)n * n); hipMemcpy2D(L.data(), n*8, dLp, np*8, n*8, n, hipMemcpyDeviceToHost);
+    double err = 0; for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) { double s = 0; for (int k = 0; k <= j; ++k) s += L[i*n+k]*L[j*n+k]; err = fmax(err, fabs(s - A[i*n+j])); }
+    int hst; hipMemcpy(&hst, st, 4, hipMemcpyDeviceToHost);
+    hipLaunchKernelGGL(kern, dim3(1), dim3(cesx::PRT), lds, 0, n, np, dA, dLp, st, dbg);
+    long long hd[5]; hipMemcpy(hd, dbg, 40, hipMemcpyDeviceToHost);
+    printf("cycles: load %lld publish %lld diag %lld solve %lld trailing %lld\n", hd[0], hd[1], hd[2], hd[3], hd[4]);
+    printf("n=%d potrf %.1f us/call, max |LL^T - A| = %.3e, status %d\n", n, ms * 100.0, err, hst);
+    return 0;
+}
