@@ -153,6 +153,7 @@ struct Engine {
     int *d_type_hdr = nullptr, *d_rows = nullptr, *d_wblk = nullptr, *d_blk_rc = nullptr;
     int nslices = 0;
     void* d_slabs = nullptr;       // [nslices][nblocks][tile*tile] engine dtype
+    double* d_rowsum_part = nullptr;   // [nslices][p+n] shifted first moments per slice
     // stats partials
     int stats_blocks = 0;
     double* d_stat_part = nullptr; // [stats_blocks][stat_len]
@@ -177,6 +178,10 @@ struct Engine {
     void   *d_qe = nullptr;        // [J] per-particle q^e (engine dtype)
     void   *d_wdT = nullptr;       // [n] Ginv (s_g - y) in engine dtype (dense Gamma)
     double *d_colsum_partq = nullptr;
+    void   *d_rowc = nullptr;        // [kn][4] {gbar_i, y_i, 1/Gamma_ii, 0} engine dtype (K3 data metrics)
+    double *d_metric_part = nullptr; // [blocks][2] per-workgroup {sum q_r^2, sum q_e^2}
+    double *d_metric_sums = nullptr; // [2] this shard's sums of the last apply
+    void   *d_gbarT = nullptr;       // [n] gbar in the engine dtype (dense-Gamma metrics)
     double *d_mv = nullptr;        // matvec results [6][max(p,n)]
     double *d_part = nullptr;      // reduction partials
     Scalars* d_scal = nullptr;
@@ -193,7 +198,8 @@ struct Engine {
     // results
     cesx_step_result* h_res = nullptr;   // pinned
     Scalars* h_scal = nullptr;           // pinned
-    hipEvent_t ev = nullptr;
+    hipEvent_t ev = nullptr, ev_a = nullptr, ev_b = nullptr;
+    hipStream_t side = nullptr;      // side stream: chol(C) runs beside the rest of K2
     bool pending = false;
     cesx_step_params last_prm{};
 };
@@ -209,15 +215,17 @@ struct UpdateSrc {            // one K-segment of the update GEMM
 
 int launch_colsum(Engine& e, const void* U, const void* G, double* sums, hipStream_t s);
 int launch_set_shift(Engine& e, const double* sums, hipStream_t s);
-int launch_stats(Engine& e, const void* U, const void* G, double* mom, hipStream_t s);
 int launch_gram(Engine& e, const void* U, const void* G, double* mom, hipStream_t s);
 int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int phase, hipStream_t s);
 int launch_update(Engine& e, int out_rows, const void* W, int ktot, const void* bias,
                   const UpdateSrc* src, int nsrc,
                   const void* add1, const double* c1, double c1_imm,
                   const void* add2, const double* c2, double c2_imm,
-                  void* out, double* absmax_part, uint64_t step_index, hipStream_t s);
+                  void* out, double* absmax_part, uint64_t step_index, bool metrics, hipStream_t s);
 int update_grid_blocks(Engine& e, int out_rows);
+int update_grid_x(Engine& e);
+int launch_data_metrics(Engine& e, const void* G, hipStream_t s);   // dense Gamma: separate pass
+int launch_metric_final(Engine& e, const double* mom, hipStream_t s);
 int launch_absmax_final(Engine& e, int nparts, double* absmax_out, hipStream_t s);
 int potrf_ld(int n);
 int gram_nbw(int dtype);

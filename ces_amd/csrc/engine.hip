@@ -104,7 +104,13 @@ int run_update_main(Engine& e, const cesx_step_params& prm, const void* U, const
                     void* Unext, hipStream_t s) {
     UpdateSrc src[3] = {{U, e.p, 0}, {G, e.n, 0}, {xi, e.p, xi ? 0 : 1}};
     return launch_update(e, e.p, e.d_W, e.ktot, e.d_bias, src, 3, nullptr, nullptr, 0.0, nullptr, nullptr, 0.0,
-                         Unext, nullptr, prm.step_index, s);
+                         Unext, nullptr, prm.step_index, e.diag_gamma, s);
+}
+
+// data metrics: K3 accumulated them (diagonal Gamma) or a separate pass does (dense Gamma)
+int finish_metrics(Engine& e, const double* mom, const void* G, hipStream_t s) {
+    if (!e.diag_gamma) TRY(launch_data_metrics(e, G, s));
+    return launch_metric_final(e, mom, s);
 }
 
 }  // namespace
@@ -152,9 +158,9 @@ int cesx_create(const cesx_config* cfg, cesx_handle* out) {
     e.colsum_slices = (int)std::min<long long>(16, (e.J + 1023) / 1024);
     if (e.colsum_slices < 1) e.colsum_slices = 1;
     e.stats_blocks = (int)((e.J + 63) / 64);
-    e.mom_len = 1 + P + pp + pn + nn + 3 + n;
     e.kp = (p + 15) / 16 * 16; e.kn = (n + 15) / 16 * 16; e.ktot = 2 * e.kp + e.kn;
     e.rpad = (mx + 255) / 256 * 256;
+    e.mom_len = 1 + P + pp + pn + nn + 2;        // + lagged {sum q_r^2, sum q_e^2} of the previous apply
 
 #define DM(ptr, bytes) if ((rc = dmalloc(e, &ptr, (bytes)))) return fail(rc)
     DM(e.d_y, n * 8); DM(e.d_mu, p * 8); DM(e.d_ustar, p * 8);
@@ -168,7 +174,8 @@ int cesx_create(const cesx_config* cfg, cesx_handle* out) {
         DM(t, n * e.esz); e.d_gwT = t;
         DM(t, nn * e.esz); e.d_GinvT = t;
         DM(t, n * e.esz); e.d_wdT = t;
-        DM(t, (size_t)e.J * e.esz); e.d_qe = t;
+        DM(t, n * e.esz); e.d_gbarT = t;
+        DM(t, (size_t)e.kn * 4 * e.esz); e.d_rowc = t;
         DM(t, (size_t)e.nslices * e.plan.nblocks * e.plan.tile * e.plan.tile * e.esz); e.d_slabs = t;
         DM(t, (size_t)e.rpad * e.ktot * e.esz); e.d_W = t;
         DM(t, (size_t)e.rpad * e.esz); e.d_bias = t;
@@ -180,9 +187,10 @@ int cesx_create(const cesx_config* cfg, cesx_handle* out) {
     if ((rc = upload(e, e.d_rows, e.plan.rows.data(), e.plan.rows.size() * 4))) return fail(rc);
     if ((rc = upload(e, e.d_wblk, e.plan.wblk.data(), e.plan.wblk.size() * 4))) return fail(rc);
     if ((rc = upload(e, e.d_blk_rc, e.plan.blk_rc.data(), e.plan.blk_rc.size() * 4))) return fail(rc);
-    DM(e.d_stat_part, (size_t)e.stats_blocks * 3 * 8 + (size_t)((e.J + 255) / 256) * 3 * 8);
+    DM(e.d_rowsum_part, (size_t)e.nslices * P * 8);
+    DM(e.d_metric_part, ((size_t)((e.J + 63) / 64) + 8) * 2 * 8);
+    DM(e.d_metric_sums, 2 * 8);
     DM(e.d_colsum_part, (size_t)P * e.colsum_slices * 8);
-    DM(e.d_colsum_partq, (size_t)P * e.colsum_slices * 8);
     DM(e.d_mom, e.mom_len * 8); DM(e.d_sums, (1 + P) * 8);
     DM(e.d_ubar, p * 8); DM(e.d_gbar, n * 8); DM(e.d_m, n * 8); DM(e.d_dg, n * 8); DM(e.d_wdel, n * 8);
     DM(e.d_C, pp * 8); DM(e.d_L, (size_t)potrf_ld(p) * potrf_ld(p) * 8); DM(e.d_Cug, pn * 8); DM(e.d_See, nn * 8); DM(e.d_Srr, nn * 8);
@@ -195,7 +203,10 @@ int cesx_create(const cesx_config* cfg, cesx_handle* out) {
     DM(e.d_absmax_part, (size_t)update_grid_blocks(e, p) * 8);
 #undef DM
     if (hipHostMalloc(reinterpret_cast<void**>(&e.h_scal), sizeof(Scalars), hipHostMallocDefault) != hipSuccess ||
-        hipEventCreateWithFlags(&e.ev, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&e.ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e.ev_a, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e.ev_b, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking) != hipSuccess) {
         e.err = "pinned host buffer / event creation failed";
         return fail(CESX_EHIP);
     }
@@ -209,9 +220,10 @@ void cesx_destroy(cesx_handle h) {
     Engine& e = *reinterpret_cast<Engine*>(h);
     (void)hipSetDevice(e.cfg.device);
     void* ptrs[] = {e.d_y, e.d_mu, e.d_ustar, e.d_Gamma, e.d_Ginv, e.d_gw, e.d_Wh, e.d_Sigma, e.d_Sinv, e.d_sw,
-                    e.d_shift64, e.d_shiftT, e.d_yT, e.d_gwT, e.d_GinvT, e.d_wdT, e.d_qe, e.d_slabs, e.d_W,
-                    e.d_bias, e.d_Wfwd, e.d_type_hdr, e.d_rows, e.d_wblk, e.d_blk_rc, e.d_stat_part,
-                    e.d_colsum_part, e.d_colsum_partq, e.d_mom, e.d_sums, e.d_ubar, e.d_gbar, e.d_m, e.d_dg,
+                    e.d_shift64, e.d_shiftT, e.d_yT, e.d_gwT, e.d_GinvT, e.d_wdT, e.d_slabs, e.d_W,
+                    e.d_bias, e.d_Wfwd, e.d_type_hdr, e.d_rows, e.d_wblk, e.d_blk_rc, e.d_metric_part, e.d_metric_sums,
+                    e.d_gbarT, e.d_rowc,
+                    e.d_colsum_part, e.d_rowsum_part, e.d_mom, e.d_sums, e.d_ubar, e.d_gbar, e.d_m, e.d_dg,
                     e.d_wdel, e.d_C, e.d_L, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_Kp, e.d_M, e.d_P, e.d_PK,
                     e.d_t1, e.d_t2, e.d_t3, e.d_t4, e.d_Lp, e.d_lanczos, e.d_mv, e.d_part, e.d_scal, e.d_absmax,
                     e.d_c0, e.d_absmax_part};
@@ -222,6 +234,9 @@ void cesx_destroy(cesx_handle h) {
     for (auto ev : e.prof_pool) (void)hipEventDestroy(ev);
     if (e.h_scal) (void)hipHostFree(e.h_scal);
     if (e.ev) (void)hipEventDestroy(e.ev);
+    if (e.ev_a) (void)hipEventDestroy(e.ev_a);
+    if (e.ev_b) (void)hipEventDestroy(e.ev_b);
+    if (e.side) (void)hipStreamDestroy(e.side);
     delete &e;
 }
 
@@ -284,7 +299,8 @@ int cesx_moments(cesx_handle h, const void* U, const void* G, double* mom, void*
     if (!e.shift_valid) { e.err = "no centring shift: call cesx_colsum + cesx_set_shift (or cesx_step with recenter) first"; return CESX_ESTATE; }
     TRY(set_device(e));
     hipStream_t s = (hipStream_t)stream;
-    TRY(launch_stats(e, U, G, mom, s));
+    // tail: this shard's data-metric sums of the PREVIOUS apply ride on this step's all-reduce
+    CESX_HIP(hipMemcpyAsync(mom + e.mom_len - 2, e.d_metric_sums, 16, hipMemcpyDeviceToDevice, s));
     return launch_gram(e, U, G, mom, s);
 }
 
@@ -299,7 +315,8 @@ int cesx_apply_drift(cesx_handle h, const cesx_step_params* prm, const double* m
     TRY(launch_dense(e, *prm, mom, 1, s));
     UpdateSrc src[2] = {{U, e.p, 0}, {G, e.n, 0}};
     TRY(launch_update(e, e.p, e.d_W, e.kp + e.kn, e.d_bias, src, 2, nullptr, nullptr, 0.0, nullptr, nullptr, 0.0,
-                      Unext, e.d_absmax_part, prm->step_index, s));
+                      Unext, e.d_absmax_part, prm->step_index, e.diag_gamma, s));
+    TRY(finish_metrics(e, mom, G, s));
     return launch_absmax_final(e, update_grid_blocks(e, e.p), absmax, s);
 }
 
@@ -316,7 +333,7 @@ int cesx_apply_finish(cesx_handle h, const cesx_step_params* prm, const double* 
     // U_next = sqrt(2hk) L xi + 1 * U + hk * drift   (drift currently lives in U_next)
     UpdateSrc src[1] = {{xi, e.p, xi ? 0 : 1}};
     TRY(launch_update(e, e.p, e.d_W, e.kp, nullptr, src, 1, U, nullptr, 1.0, Unext, &e.d_scal->hk, 1.0, Unext,
-                      nullptr, prm->step_index, s));
+                      nullptr, prm->step_index, false, s));
     return finish_step(e, *prm, s);
 }
 
@@ -335,6 +352,7 @@ int cesx_apply(cesx_handle h, const cesx_step_params* prm, const double* mom, co
     hipStream_t s = (hipStream_t)stream;
     TRY(launch_dense(e, *prm, mom, 0, s));
     TRY(run_update_main(e, *prm, U, G, xi, Unext, s));
+    TRY(finish_metrics(e, mom, G, s));
     return finish_step(e, *prm, s);
 }
 
@@ -365,6 +383,7 @@ int cesx_result(cesx_handle h, cesx_step_result* out) {
     out->self_bias = sc.self_bias; out->self_bias_data = sc.self_bias_data;
     out->bias_data = sc.bias_data; out->bias = sc.bias;
     out->radspec = sc.radspec; out->status = sc.status; out->reserved = 0;
+    out->lag_bias_data = sc.spare[1]; out->lag_self_bias_data = sc.spare[2];
     if (sc.status == CESX_ENOTPD) {
         e.err = "ensemble covariance is not positive definite (Cholesky failed)";
         return CESX_ENOTPD;
@@ -392,12 +411,21 @@ int cesx_forward_lineal(cesx_handle h, const void* A, const void* b, const void*
                               hipMemcpyDeviceToDevice, s));
     UpdateSrc src[1] = {{U, e.p, 0}};
     return launch_update(e, e.n, e.d_Wfwd, e.kp, b, src, 1, nullptr, nullptr, 0.0, nullptr, nullptr, 0.0, G,
-                         nullptr, 0, s);
+                         nullptr, 0, false, s);
 }
 
 int cesx_profile_enable(cesx_handle h, int on) {
     if (!h) return CESX_EINVAL;
-    reinterpret_cast<Engine*>(h)->profile = on != 0;
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    e.profile = on != 0;
+    if (e.profile) {
+        TRY(set_device(e));
+        while (e.prof_pool.size() < 512) {        // created up front: no event creation in a timed region
+            hipEvent_t ev = nullptr;
+            CESX_HIP(hipEventCreate(&ev));
+            e.prof_pool.push_back(ev);
+        }
+    }
     return CESX_OK;
 }
 

@@ -37,17 +37,24 @@ struct MomView {
     __device__ const double* Saa() const { return mom + 1 + p + n; }
     __device__ const double* Sab() const { return Saa() + (size_t)p * p; }
     __device__ const double* Sbb() const { return Sab() + (size_t)p * n; }
-    __device__ const double* q() const { return Sbb() + (size_t)n * n; }   // [mq_r2, mq_e2, sq_e, vqb[n]]
 };
 
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(DT)
 void center_kernel(MomView mv, const double* __restrict__ shift, const double* __restrict__ y,
-                   const double* __restrict__ ustar, const double* __restrict__ gw, int unbiased,
+                   const double* __restrict__ ustar, const double* __restrict__ gw,
+                   const double* __restrict__ sw, int unbiased,
                    double* __restrict__ ubar, double* __restrict__ gbar, double* __restrict__ mvec,
                    double* __restrict__ dg, double* __restrict__ C, double* __restrict__ Cug,
-                   double* __restrict__ See, double* __restrict__ Srr, double* __restrict__ part) {
+                   double* __restrict__ See, double* __restrict__ Srr, double* __restrict__ K,
+                   double* __restrict__ M, double* __restrict__ part, Scalars* __restrict__ sc) {
     __shared__ double red[DT / 64];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sc->status = CESX_OK;
+        sc->radspec = 0.0;
+        sc->spare[0] = 0.0;
+        sc->absmax = 0.0;
+    }
     const int p = mv.p, n = mv.n;
     const double N = mv.N();
     const double div = unbiased ? N - 1.0 : N;
@@ -60,12 +67,16 @@ void center_kernel(MomView mv, const double* __restrict__ shift, const double* _
         if (idx < pp) {
             const int i = (int)(idx / p), j = (int)(idx % p);
             const double suu = mv.Saa()[idx] - sa[i] * sa[j] / N;
-            C[idx] = suu / div + (i == j ? 1e-8 : 0.0);
+            const double c = suu / div + (i == j ? 1e-8 : 0.0);
+            C[idx] = c;
+            if (sw) M[idx] = c * sw[j];              // M = C Sigma^{-1}, diagonal Sigma
             if (i == j) tr += suu;
         } else if (idx < pp + pn) {
             const long long k = idx - pp;
             const int i = (int)(k / n), j = (int)(k % n);
-            Cug[k] = (mv.Sab()[k] - sa[i] * sb[j] / N) / N;
+            const double cug = (mv.Sab()[k] - sa[i] * sb[j] / N) / N;
+            Cug[k] = cug;
+            if (gw) K[k] = cug * gw[j];              // K = C_ug Gamma^{-1}, diagonal Gamma
         } else {
             const long long k = idx - pp - pn;
             const int i = (int)(k / n), j = (int)(k % n);
@@ -592,43 +603,39 @@ __global__ void whiten_diag_kernel(int n, const double* __restrict__ See, const 
 // ---------------------------------------------------------------------------
 // scalars: metrics, time step, pseudo-time
 // ---------------------------------------------------------------------------
+// block 0: scalars; blocks 1..: the four matvecs K y, K gbar, M mu, M ubar (one wave per row)
 __global__ __launch_bounds__(DT)
 void scalar_kernel(MomView mv, cesx_step_params prm, const double* __restrict__ part,
-                   const double* __restrict__ dg, const double* __restrict__ gw,
-                   const double* __restrict__ wdel_dense, Scalars* __restrict__ sc) {
+                   Scalars* __restrict__ sc, const double* __restrict__ K, const double* __restrict__ M,
+                   const double* __restrict__ y, const double* __restrict__ gbar,
+                   const double* __restrict__ mu, const double* __restrict__ ubar, int mx,
+                   double* __restrict__ mvs) {
     __shared__ double red[DT / 64];
-    const int n = mv.n, p = mv.p, tid = threadIdx.x;
+    const int p = mv.p, tid = threadIdx.x;
+    if (blockIdx.x > 0) {
+        const int item = (blockIdx.x - 1) * (DT / 64) + (tid >> 6), lane = tid & 63;
+        if (item >= 4 * p) return;
+        const int which = item / p, row = item % p;
+        const int cols = which < 2 ? mv.n : p;
+        const double* A = (which < 2 ? K : M) + (size_t)row * cols;
+        const double* x = which == 0 ? y : which == 1 ? gbar : which == 2 ? mu : ubar;
+        double s = 0.0;
+        for (int c = lane; c < cols; c += 64) s += A[c] * x[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        if (lane == 0) mvs[(size_t)which * mx + row] = s;
+        return;
+    }
     const double N = mv.N();
     double tr = 0.0, b2 = 0.0, fr = 0.0;
     for (int i = tid; i < NPB; i += DT) { tr += part[i * 4]; b2 += part[i * 4 + 1]; fr += part[i * 4 + 2]; }
     tr = dblock_sum(tr, red);
     b2 = dblock_sum(b2, red);
     fr = dblock_sum(fr, red);
-    // re-centre the e-metric from the shift s_g to the exact mean: e_j = b_j - dg,
-    // q(e_j) = q(b_j) - 2 w^T b_j + c,  w = Gamma^{-1} dg,  c = dg^T w
-    const double* Sbb = mv.Sbb();
-    const double* sb = mv.sb();
-    const double* q = mv.q();
-    double c = 0.0, wSw = 0.0, wv = 0.0, wsb = 0.0;
-    for (int i = tid; i < n; i += DT) {
-        const double wi = gw ? gw[i] * dg[i] : wdel_dense[i];
-        c += dg[i] * wi;
-        wv += wi * q[3 + i];
-        wsb += wi * sb[i];
-        double s = 0.0;
-        for (int j = 0; j < n; ++j) s += Sbb[(size_t)i * n + j] * (gw ? gw[j] * dg[j] : wdel_dense[j]);
-        wSw += wi * s;
-    }
-    c = dblock_sum(c, red);
-    wSw = dblock_sum(wSw, red);
-    wv = dblock_sum(wv, red);
-    wsb = dblock_sum(wsb, red);
     if (tid != 0) return;
     sc->tr_suu = tr;
     sc->self_bias = tr / N;
     sc->bias = tr / N + b2;
-    sc->bias_data = q[0] / N;
-    sc->self_bias_data = (q[1] + 4.0 * wSw + N * c * c - 4.0 * wv + 2.0 * c * q[2] - 4.0 * c * wsb) / N;
     sc->frob2 = fr;
     sc->alpha = (p + 1.0) / N;
     const double frob = sqrt(fr > 0.0 ? fr : 0.0) / N;
@@ -676,8 +683,10 @@ __global__ void assemble_kernel(int mode, int p, int n, int kp, int kn, int rpad
                                 const double* __restrict__ K, const double* __restrict__ L, int ldl,
                                 const double* __restrict__ P, const double* __restrict__ PK,
                                 const double* __restrict__ mvs, int mx, const double* __restrict__ ubar,
-                                const double* __restrict__ gbar, T* __restrict__ W, T* __restrict__ bias,
-                                T* __restrict__ shiftT, double* __restrict__ shift64) {
+                                const double* __restrict__ gbar, const double* __restrict__ y,
+                                const double* __restrict__ gw, T* __restrict__ W, T* __restrict__ bias,
+                                T* __restrict__ shiftT, double* __restrict__ shift64, T* __restrict__ rowc,
+                                T* __restrict__ gbarT) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const double hk = sc->hk, s2 = sc->sqrt2hk, al = sc->alpha;
     const double* Ky = mvs;            // K y
@@ -721,6 +730,15 @@ __global__ void assemble_kernel(int mode, int p, int n, int kp, int kn, int rpad
         }
         bias[i] = (T)b;
     }
+    if (idx < kn && mode != 3) {
+        // per-row constants of the K3 data metrics; padded rows get weight 0
+        const int i = (int)idx;
+        rowc[i * 4 + 0] = (T)(i < n ? gbar[i] : 0.0);
+        rowc[i * 4 + 1] = (T)(i < n ? y[i] : 0.0);
+        rowc[i * 4 + 2] = (T)((i < n && gw != nullptr) ? gw[i] : 0.0);
+        rowc[i * 4 + 3] = (T)0;
+        if (i < n) gbarT[i] = (T)gbar[i];
+    }
     if (idx < p + n && mode != 3) {
         const int i = (int)idx;
         double s;
@@ -741,13 +759,6 @@ __global__ void hk_sum_kernel(int len, const Scalars* __restrict__ sc, const dou
                               const double* __restrict__ b, double* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < len) out[i] = sc->hk * (a[i] + b[i]);
-}
-
-__global__ void init_scalars_kernel(Scalars* sc) {
-    sc->status = CESX_OK;
-    sc->radspec = 0.0;
-    sc->spare[0] = 0.0;
-    sc->absmax = 0.0;
 }
 
 // ---------------------------------------------------------------------------
@@ -812,7 +823,8 @@ static int assemble(Engine& e, hipStream_t s, int mode, int ktot, double sw) {
     const long long len = (long long)e.rpad * ktot;
     hipLaunchKernelGGL(assemble_kernel<T>, g1(len), dim3(256), 0, s, mode, e.p, e.n, e.kp, e.kn, e.rpad, ktot,
                        sw, e.d_scal, e.d_M, e.d_K, e.d_L, potrf_ld(e.p), e.d_P, e.d_PK, e.d_mv, mx, e.d_ubar, e.d_gbar,
-                       (T*)e.d_W, (T*)e.d_bias, (T*)e.d_shiftT, e.d_shift64);
+                       e.d_y, e.diag_gamma ? e.d_gw : (const double*)nullptr, (T*)e.d_W, (T*)e.d_bias,
+                       (T*)e.d_shiftT, e.d_shift64, (T*)e.d_rowc, (T*)e.d_gbarT);
     CESX_HIP(hipGetLastError());
     return CESX_OK;
 }
@@ -829,31 +841,29 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
         return f32 ? assemble<float>(e, s, 3, e.kp, 0.0) : assemble<double>(e, s, 3, e.kp, 0.0);
     }
     MomView mv{p, n, mom};
-    hipLaunchKernelGGL(init_scalars_kernel, dim3(1), dim3(1), 0, s, e.d_scal);
     const int unbiased = prm.update == CESX_UPDATE_EKS ? 0 : 1;
     hipLaunchKernelGGL(center_kernel, dim3(NPB), dim3(DT), 0, s, mv, e.d_shift64, e.d_y, e.d_ustar,
-                       e.diag_gamma ? e.d_gw : (const double*)nullptr, unbiased, e.d_ubar, e.d_gbar, e.d_m,
-                       e.d_dg, e.d_C, e.d_Cug, e.d_See, e.d_Srr, e.d_part);
+                       e.diag_gamma ? e.d_gw : (const double*)nullptr,
+                       e.diag_sigma ? e.d_sw : (const double*)nullptr, unbiased, e.d_ubar, e.d_gbar, e.d_m,
+                       e.d_dg, e.d_C, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_M, e.d_part, e.d_scal);
     CESX_HIP(hipGetLastError());
+    // the Cholesky of C runs on the engine's side stream beside the rest of K2
+    CESX_HIP(hipEventRecord(e.ev_a, s));
+    CESX_HIP(hipStreamWaitEvent(e.side, e.ev_a, 0));
+    if ((rc = potrf(e, e.side, p, e.d_C, e.d_L))) return rc;
+    CESX_HIP(hipEventRecord(e.ev_b, e.side));
     if (!e.diag_gamma) {
-        // Frobenius term <Ginv Srr Ginv, See> and w = Ginv dg
+        // Frobenius term <Ginv Srr Ginv, See>, and K = C_ug Ginv
         if ((rc = gemm(e, s, n, n, n, 1.0, e.d_Ginv, n, 1, e.d_Srr, n, 1, e.d_t1))) return rc;
         if ((rc = gemm(e, s, n, n, n, 1.0, e.d_t1, n, 1, e.d_Ginv, n, 1, e.d_t2))) return rc;
         hipLaunchKernelGGL(dot_kernel, dim3(NPB), dim3(DT), 0, s, e.d_t2, e.d_See, (long long)n * n, e.d_part);
-        hipLaunchKernelGGL(matvec_kernel, g1(n, 4), dim3(DT), 0, s, n, n, e.d_Ginv, e.d_dg, e.d_wdel);
         CESX_HIP(hipGetLastError());
+        if ((rc = gemm(e, s, p, n, n, 1.0, e.d_Cug, n, 1, e.d_Ginv, n, 1, e.d_K))) return rc;
     }
-    if ((rc = potrf(e, s, p, e.d_C, e.d_L))) return rc;
-    // gain and prior coupling
-    if (e.diag_gamma)
-        hipLaunchKernelGGL(scale_cols_kernel, g1((long long)p * n), dim3(256), 0, s, p, n, e.d_Cug, e.d_gw, e.d_K);
-    else if ((rc = gemm(e, s, p, n, n, 1.0, e.d_Cug, n, 1, e.d_Ginv, n, 1, e.d_K))) return rc;
-    if (e.diag_sigma)
-        hipLaunchKernelGGL(scale_cols_kernel, g1((long long)p * p), dim3(256), 0, s, p, p, e.d_C, e.d_sw, e.d_M);
-    else if ((rc = gemm(e, s, p, p, p, 1.0, e.d_C, p, 1, e.d_Sinv, p, 1, e.d_M))) return rc;
-    CESX_HIP(hipGetLastError());
+    if (!e.diag_sigma)
+        if ((rc = gemm(e, s, p, p, p, 1.0, e.d_C, p, 1, e.d_Sinv, p, 1, e.d_M))) return rc;
     if (prm.time_step == CESX_TS_SPECTRAL && prm.update != CESX_UPDATE_ALDI_CONSTANT) {
-        // B = Wh (See/N) Wh^T, symmetric PSD, same non-zero spectrum as D
+        // B = Wh See Wh^T, symmetric PSD, same non-zero spectrum as D (times N)
         if (e.diag_gamma) {
             hipLaunchKernelGGL(whiten_diag_kernel, g1((long long)n * n), dim3(256), 0, s, n, e.d_See, e.d_gw, e.d_t3);
         } else {
@@ -867,8 +877,11 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
                            e.d_scal);
         CESX_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(scalar_kernel, dim3(1), dim3(DT), 0, s, mv, prm, e.d_part, e.d_dg,
-                       e.diag_gamma ? e.d_gw : (const double*)nullptr, e.d_wdel, e.d_scal);
+    auto scalars_and_matvecs = [&]() {
+        hipLaunchKernelGGL(scalar_kernel, dim3(1 + (4 * p + DT / 64 - 1) / (DT / 64)), dim3(DT), 0, s, mv, prm,
+                           e.d_part, e.d_scal, e.d_K, e.d_M, e.d_y, e.d_gbar, e.d_mu, e.d_ubar, mx, e.d_mv);
+    };
+    scalars_and_matvecs();
     CESX_HIP(hipGetLastError());
 
     if (phase == 0 && (prm.time_step == CESX_TS_CONSTANT || (prm.time_step == CESX_TS_MIX && prm.update == CESX_UPDATE_ALDI))) {
@@ -880,13 +893,9 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
         if ((rc = gemm(e, s, p, n, n, 1.0, e.d_Cug, n, 1, e.d_t4, n, 1, e.d_Kp))) return rc;
         hipLaunchKernelGGL(select_kernel, g1((long long)p * n), dim3(256), 0, s, (long long)p * n, e.d_scal, e.d_Kp, e.d_K);
         CESX_HIP(hipGetLastError());
+        scalars_and_matvecs();          // K y and K gbar with the selected gain (scalars are recomputed identically)
+        CESX_HIP(hipGetLastError());
     }
-    // matvecs: K y, K gbar, M mu, M ubar
-    hipLaunchKernelGGL(matvec_kernel, g1(p, 4), dim3(DT), 0, s, p, n, e.d_K, e.d_y, e.d_mv);
-    hipLaunchKernelGGL(matvec_kernel, g1(p, 4), dim3(DT), 0, s, p, n, e.d_K, e.d_gbar, e.d_mv + mx);
-    hipLaunchKernelGGL(matvec_kernel, g1(p, 4), dim3(DT), 0, s, p, p, e.d_M, e.d_mu, e.d_mv + 2 * mx);
-    hipLaunchKernelGGL(matvec_kernel, g1(p, 4), dim3(DT), 0, s, p, p, e.d_M, e.d_ubar, e.d_mv + 3 * mx);
-    CESX_HIP(hipGetLastError());
 
     int mode = 0;
     if (phase == 1) mode = 2;
@@ -903,6 +912,7 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
         hipLaunchKernelGGL(matvec_kernel, g1(p, 4), dim3(DT), 0, s, p, p, e.d_P, e.d_mv + 5 * mx, e.d_mv + 4 * mx);
         CESX_HIP(hipGetLastError());
     }
+    CESX_HIP(hipStreamWaitEvent(s, e.ev_b, 0));      // L = chol(C) from the side stream
     const int ktot = mode == 2 ? e.kp + e.kn : e.ktot;
     return f32 ? assemble<float>(e, s, mode, ktot, prm.switch_mult) : assemble<double>(e, s, mode, ktot, prm.switch_mult);
 }

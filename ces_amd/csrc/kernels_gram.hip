@@ -18,25 +18,27 @@
 #include "cesx_internal.h"
 #include <algorithm>
 #include <cmath>
+#include <set>
 
 namespace cesx {
 
-constexpr int GRAM_THREADS = 256;
+constexpr int GRAM_THREADS = 512;          // 8 waves = 2 per SIMD: one wave's LDS latency hides behind the other's MFMAs
+constexpr int GRAM_WAVES = GRAM_THREADS / 64;
 constexpr int ROW_BYTES = 128;            // one staged row of a tile: 32 f32 / 16 f64
 constexpr int ROW_STRIDE = ROW_BYTES + 16;  // +16 B pad: conflict-free ds_read_b128 over 16 rows
 constexpr int MAX_STAGE_ROWS = 512;
 constexpr int MAXCH = MAX_STAGE_ROWS * (ROW_BYTES / 16) / GRAM_THREADS;   // 16 chunks / thread
 
 template <typename T> struct GramCfg;
-template <> struct GramCfg<float>  { static constexpr int NBW = 17; };
-template <> struct GramCfg<double> { static constexpr int NBW = 34; };
+template <> struct GramCfg<float>  { static constexpr int NBW = 9; };    // 9 x 16 accumulator VGPRs per wave
+template <> struct GramCfg<double> { static constexpr int NBW = 17; };   // 17 x 8
 
 template <typename T, bool ALIGNED>
-__global__ __launch_bounds__(GRAM_THREADS, 1)
+__global__ __launch_bounds__(GRAM_THREADS, 2)
 void gram_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __restrict__ shift,
                  int p, int n, long long J, const int* __restrict__ type_hdr,
                  const int* __restrict__ rows_tab, const int* __restrict__ wblk,
-                 int nslices, int nblocks, T* __restrict__ slabs) {
+                 int nslices, int nblocks, T* __restrict__ slabs, double* __restrict__ rowsum_part) {
     using M = Mfma<T>;
     using vec_t = typename M::vec_t;
     using acc_t = typename M::acc_t;
@@ -82,15 +84,19 @@ void gram_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __re
     const long long t0 = (long long)slice * tps;
     const long long t1 = t0 + tps < ntiles ? t0 + tps : ntiles;
 
-    // staging: thread handles 16-byte chunk `part` of rows (tid/8 + 32*i)
+    // staging: thread handles 16-byte chunk `part` of rows (tid/8 + 64*i)
     const int part = tid & 7, row0 = tid >> 3;
-    const int nch = (nrows + 31) / 32;                 // chunks this thread handles
+    constexpr int RPP = GRAM_THREADS / 8;              // rows covered per pass (64)
+    const int nch = (nrows + RPP - 1) / RPP;           // chunks this thread handles
     vec_t stage[MAXCH];
+    T rs[MAXCH];                                       // running sum of this thread's part of each staged row
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) rs[i] = 0;
     // per staged row: source pointer (null = zero row) and shift, kept in LDS
     const T** rowptr = reinterpret_cast<const T**>(smem + 2 * buf_bytes);
     T* rowshift = reinterpret_cast<T*>(smem + 2 * buf_bytes + nrows * 8);
     for (int row = tid; row < nrows; row += GRAM_THREADS) {
-        const int gr = rows_tab[rows_off + row / TILE] * TILE + row % TILE;
+        const int gr = (rows_tab[rows_off + row / TILE] & 0xffff) * TILE + row % TILE;
         const T* ptr = nullptr;
         T sh = 0;
         if (gr < P) {
@@ -106,7 +112,7 @@ void gram_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __re
         const long long j = t * KT + part * VEC;
 #pragma unroll
         for (int i = 0; i < MAXCH; ++i) {
-            const int row = row0 + 32 * i;
+            const int row = row0 + RPP * i;
             if (i < nch && row < nrows) {
                 vec_t v;
 #pragma unroll
@@ -130,12 +136,12 @@ void gram_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __re
         char* base = smem + buf * buf_bytes;
 #pragma unroll
         for (int i = 0; i < MAXCH; ++i) {
-            const int row = row0 + 32 * i;
+            const int row = row0 + RPP * i;
             if (i < nch && row < nrows) {
                 vec_t v = stage[i];
                 const T sh = rowshift[row];
 #pragma unroll
-                for (int c = 0; c < VEC; ++c) v[c] -= sh;
+                for (int c = 0; c < VEC; ++c) { v[c] -= sh; rs[i] += v[c]; }
                 *reinterpret_cast<vec_t*>(base + row * ROW_STRIDE + part * 16) = v;
             }
         }
@@ -170,6 +176,22 @@ void gram_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __re
         __syncthreads();
     }
 
+    // shifted row sums of this slice (first moments): the 8 threads that share a row
+    // are adjacent lanes; only the type that owns the block row reports it
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int row = row0 + RPP * i;
+        if (i < nch && row < nrows) {
+            double v = (double)rs[i];
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            v += __shfl_xor(v, 4, 64);
+            const int ent = rows_tab[rows_off + row / TILE];
+            const int gr = (ent & 0xffff) * TILE + row % TILE;
+            if (part == 0 && (ent >> 16) != 0 && gr < P) rowsum_part[(size_t)slice * P + gr] = v;
+        }
+    }
+
     // partial blocks of this slice
 #pragma unroll
     for (int b = 0; b < NBW; ++b) {
@@ -184,34 +206,72 @@ void gram_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __re
 }
 
 // Sum the per-slice partial blocks in fp64 (fixed order) and scatter them into
-// the packed moment buffer as full symmetric S_aa, S_ab, S_bb.
+// the packed moment buffer as full symmetric S_aa, S_ab, S_bb.  One thread per
+// 16-byte group of a block (4 f32 / 2 f64 along a block row), slices unrolled
+// by 8 so that enough loads are in flight to stream the slabs at HBM speed.
 template <typename T>
-__global__ void gram_reduce_kernel(const T* __restrict__ slabs, const int* __restrict__ blk_rc,
-                                   int nslices, int nblocks, int tile, int p, int n,
-                                   double* __restrict__ mom) {
+__global__ __launch_bounds__(256)
+void gram_reduce_kernel(const T* __restrict__ slabs, const int* __restrict__ blk_rc,
+                        int nslices, int nblocks, int tile, int p, int n, long long J,
+                        const double* __restrict__ rowsum_part, double* __restrict__ mom) {
+    using vec_t = typename Mfma<T>::vec_t;
+    constexpr int VEC = Mfma<T>::VEC;
     const int tt = tile * tile;
+    const long long ngroups = (long long)nblocks * tt / VEC;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)nblocks * tt) return;
-    const int blk = (int)(idx / tt), e = (int)(idx % tt);
+    if (idx >= ngroups) {
+        // tail threads: N and the first moments sum_j (z_ij - s_i)
+        const long long r = idx - ngroups;
+        if (r == 0) mom[0] = (double)J;
+        if (r < p + n) {
+            double s = 0.0;
+            for (int k = 0; k < nslices; ++k) s += rowsum_part[(size_t)k * (p + n) + r];
+            mom[1 + r] = s;
+        }
+        return;
+    }
+    const int blk = (int)(idx / (tt / VEC)), e0 = (int)(idx % (tt / VEC)) * VEC;
     const int R = blk_rc[blk * 2], C = blk_rc[blk * 2 + 1];
-    const int gr = R * tile + e / tile, gc = C * tile + e % tile;
     const int P = p + n;
-    if (gr >= P || gc >= P) return;
-    if (R == C && gc > gr) return;            // diagonal block: lower half, mirrored below
-    double s = 0.0;
-    for (int k = 0; k < nslices; ++k) s += (double)slabs[((size_t)k * nblocks + blk) * tt + e];
+    double acc[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) acc[c] = 0.0;
+    const T* src = slabs + (size_t)blk * tt + e0;
+    const size_t stride = (size_t)nblocks * tt;
+    int k = 0;
+    for (; k + 8 <= nslices; k += 8) {
+        vec_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const vec_t*>(src + (size_t)(k + u) * stride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) acc[c] += (double)v[u][c];
+    }
+    for (; k < nslices; ++k) {
+        const vec_t v = *reinterpret_cast<const vec_t*>(src + (size_t)k * stride);
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) acc[c] += (double)v[c];
+    }
     double* Saa = mom + 1 + p + n;
     double* Sab = Saa + (size_t)p * p;
     double* Sbb = Sab + (size_t)p * n;
-    // gr >= gc here
-    if (gr < p) {                              // both in U
-        Saa[(size_t)gr * p + gc] = s;
-        Saa[(size_t)gc * p + gr] = s;
-    } else if (gc < p) {                       // gr in G, gc in U
-        Sab[(size_t)gc * n + (gr - p)] = s;
-    } else {
-        Sbb[(size_t)(gr - p) * n + (gc - p)] = s;
-        Sbb[(size_t)(gc - p) * n + (gr - p)] = s;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+        const int e = e0 + c;
+        const int gr = R * tile + e / tile, gc = C * tile + e % tile;
+        if (gr >= P || gc >= P) continue;
+        if (R == C && gc > gr) continue;          // diagonal block: lower half, mirrored below
+        const double s = acc[c];
+        if (gr < p) {                              // both in U (gr >= gc)
+            Saa[(size_t)gr * p + gc] = s;
+            Saa[(size_t)gc * p + gr] = s;
+        } else if (gc < p) {                       // gr in G, gc in U
+            Sab[(size_t)gc * n + (gr - p)] = s;
+        } else {
+            Sbb[(size_t)(gr - p) * n + (gc - p)] = s;
+            Sbb[(size_t)(gc - p) * n + (gr - p)] = s;
+        }
     }
 }
 
@@ -223,7 +283,7 @@ GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds) {
     pl.tile = tile;
     pl.nbw = nbw;
     pl.nbr = (P + tile - 1) / tile;
-    const int cap = 4 * nbw;
+    const int cap = GRAM_WAVES * nbw;
     std::vector<std::vector<std::pair<int, int>>> types;   // blocks (R, C) per type
     if (pl.nbr * tile <= max_rows_lds) {
         // all rows fit in LDS: chop the row-major lower triangle into equal runs
@@ -264,6 +324,7 @@ GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds) {
             pl.blk_rc[(size_t)out_id(R, C) * 2] = R;
             pl.blk_rc[(size_t)out_id(R, C) * 2 + 1] = C;
         }
+    std::set<int> owned;
     for (int t = 0; t < pl.ntypes; ++t) {
         const auto& v = types[t];
         std::vector<int> rows;
@@ -276,10 +337,13 @@ GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds) {
         pl.type_hdr.push_back((int)pl.rows.size());
         pl.type_hdr.push_back((int)(pl.wblk.size() / 3));
         pl.type_hdr.push_back((int)v.size());
-        pl.rows.insert(pl.rows.end(), rows.begin(), rows.end());
+        for (int r : rows) {
+            const bool first = owned.insert(r).second;     // the first type that stages a block row reports its sums
+            pl.rows.push_back(r | (first ? 1 << 16 : 0));
+        }
         const int nv = (int)v.size();
-        for (int w = 0; w < 4; ++w) {
-            const int lo = (int)((long long)nv * w / 4), hi = (int)((long long)nv * (w + 1) / 4);
+        for (int w = 0; w < GRAM_WAVES; ++w) {
+            const int lo = (int)((long long)nv * w / GRAM_WAVES), hi = (int)((long long)nv * (w + 1) / GRAM_WAVES);
             for (int b = 0; b < nbw; ++b) {
                 if (lo + b < hi) {
                     pl.wblk.push_back(compact(v[lo + b].first));
@@ -307,12 +371,13 @@ static int launch_gram_t(Engine& e, const void* U, const void* G, double* mom, h
         ProfScope prof(e, 0, s);
         hipLaunchKernelGGL(kern, grid, block, lds, s, (const T*)U, (const T*)G, (const T*)e.d_shiftT,
                            e.p, e.n, (long long)e.J, e.d_type_hdr, e.d_rows, e.d_wblk, e.nslices,
-                           pl.nblocks, (T*)e.d_slabs);
+                           pl.nblocks, (T*)e.d_slabs, e.d_rowsum_part);
     }
     CESX_HIP(hipGetLastError());
-    const long long total = (long long)pl.nblocks * pl.tile * pl.tile;
+    const long long total = (long long)pl.nblocks * pl.tile * pl.tile / Mfma<T>::VEC + e.p + e.n;
     hipLaunchKernelGGL(gram_reduce_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
-                       (const T*)e.d_slabs, e.d_blk_rc, e.nslices, pl.nblocks, pl.tile, e.p, e.n, mom);
+                       (const T*)e.d_slabs, e.d_blk_rc, e.nslices, pl.nblocks, pl.tile, e.p, e.n,
+                       (long long)e.J, e.d_rowsum_part, mom);
     CESX_HIP(hipGetLastError());
     return CESX_OK;
 }

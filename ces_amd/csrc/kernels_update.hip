@@ -47,6 +47,9 @@ struct UpdArgs {
     const T* add2; const double* c2p; double c2i;
     double* absmax_part;
     unsigned int seed_lo, seed_hi, step;
+    // data metrics (ces/calibrate.py:434-435 / :466-467) accumulated while the G rows stream by:
+    // rowc[i] = {gbar_i, y_i, 1/Gamma_ii, 0}; metric_part[block] = {sum q_r^2, sum q_e^2}
+    const T* rowc; double* metric_part; int metric_seg;
 };
 
 template <typename T, bool ALIGNED>
@@ -88,6 +91,7 @@ void update_kernel(const UpdArgs<T> a) {
 
     vec_t wst[WCH], xst[XCH];
     int xkind = 0, xq0 = 0;
+    T mq_e = 0, mq_r = 0;          // per-particle quadratic forms (partial over this thread's rows)
 
     auto load_tile = [&](int kt) {
         const int k0 = kt * BK;
@@ -173,6 +177,26 @@ void update_kernel(const UpdArgs<T> a) {
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nkt) load_tile(kt + 1);
+        if (a.metric_part != nullptr && blockIdx.y == 0) {
+            // is the tile in sX[cur] a tile of G rows?
+            const int k0 = kt * BK;
+            const int sg = a.metric_seg;
+            const int kend = sg + 1 < a.nsrc ? a.src_k0[sg + 1] : a.ktot;
+            if (k0 >= a.src_k0[sg] && k0 < kend) {
+                const int r0 = k0 - a.src_k0[sg];
+                const int jl = tid % BN, grp = tid / BN;           // grp in [0, 256/BN)
+                constexpr int RPT = BK / (UPD_THREADS / BN);       // rows per thread per tile
+#pragma unroll
+                for (int q = 0; q < RPT; ++q) {
+                    const int rr = grp * RPT + q;
+                    const T x = sX[cur][rr * SX + jl];
+                    const T* rc = a.rowc + (size_t)(r0 + rr) * 4;
+                    const T b = x - rc[0], r = x - rc[1], w = rc[2];
+                    mq_e += w * b * b;
+                    mq_r += w * r * r;
+                }
+            }
+        }
         if (rb_on[0]) {
 #pragma unroll
             for (int g = 0; g < BK / GROUP; ++g) {
@@ -230,6 +254,33 @@ void update_kernel(const UpdArgs<T> a) {
             }
         }
     }
+    if (a.metric_part != nullptr && blockIdx.y == 0) {
+        // combine the row groups of each particle through LDS (the K loop is over), square, reduce
+        T* comb = reinterpret_cast<T*>(smem);
+        __syncthreads();
+        comb[tid] = mq_e;
+        comb[UPD_THREADS + tid] = mq_r;
+        __syncthreads();
+        double se = 0.0, sr = 0.0;
+        if (tid < BN && jt0 + tid < a.J) {
+            T qe = 0, qr = 0;
+#pragma unroll
+            for (int g = 0; g < UPD_THREADS / BN; ++g) { qe += comb[g * BN + tid]; qr += comb[UPD_THREADS + g * BN + tid]; }
+            se = (double)qe * (double)qe;
+            sr = (double)qr * (double)qr;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { se += __shfl_down(se, o, 64); sr += __shfl_down(sr, o, 64); }
+        __syncthreads();
+        double* redm = reinterpret_cast<double*>(smem);
+        if (lane == 0) { redm[wave] = sr; redm[4 + wave] = se; }
+        __syncthreads();
+        if (tid == 0) {
+            a.metric_part[blockIdx.x * 2 + 0] = redm[0] + redm[1] + redm[2] + redm[3];
+            a.metric_part[blockIdx.x * 2 + 1] = redm[4] + redm[5] + redm[6] + redm[7];
+        }
+        __syncthreads();
+    }
     if (a.absmax_part) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -279,7 +330,7 @@ template <typename T>
 static int update_t(Engine& e, int out_rows, const void* W, int ktot, const void* bias,
                     const UpdateSrc* src, int nsrc, const void* add1, const double* c1, double c1_imm,
                     const void* add2, const double* c2, double c2_imm, void* out, double* absmax_part,
-                    uint64_t step_index, hipStream_t s) {
+                    uint64_t step_index, bool metrics, hipStream_t s) {
     using C = UpdCfg<T>;
     constexpr int RC = 4 * C::WR * Mfma<T>::TILE, BN = C::WC * Mfma<T>::TILE;
     UpdArgs<T> a{};
@@ -304,9 +355,12 @@ static int update_t(Engine& e, int out_rows, const void* W, int ktot, const void
     a.add1 = (const T*)add1; a.c1p = c1; a.c1i = c1_imm;
     a.add2 = (const T*)add2; a.c2p = c2; a.c2i = c2_imm;
     a.absmax_part = absmax_part;
+    a.rowc = (const T*)e.d_rowc;
+    a.metric_part = metrics ? e.d_metric_part : nullptr;
+    a.metric_seg = 1;                    // [U; G; ...]: G is segment 1
     a.seed_lo = (unsigned)e.cfg.seed; a.seed_hi = (unsigned)(e.cfg.seed >> 32); a.step = (unsigned)step_index;
     dim3 grid((unsigned)((e.J + BN - 1) / BN), (unsigned)((out_rows + RC - 1) / RC));
-    const int lds = 2 * (RC * C::STRIDE_W + BK * (BN + C::XPAD)) * (int)sizeof(T) + 64;
+    const int lds = 2 * (RC * C::STRIDE_W + BK * (BN + C::XPAD)) * (int)sizeof(T) + 64;   // >= 2 * 256 * sizeof(T) for the metric combine
     auto kern = aligned ? update_kernel<T, true> : update_kernel<T, false>;
     CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -321,10 +375,15 @@ static int update_t(Engine& e, int out_rows, const void* W, int ktot, const void
 int launch_update(Engine& e, int out_rows, const void* W, int ktot, const void* bias,
                   const UpdateSrc* src, int nsrc, const void* add1, const double* c1, double c1_imm,
                   const void* add2, const double* c2, double c2_imm, void* out, double* absmax_part,
-                  uint64_t step_index, hipStream_t s) {
+                  uint64_t step_index, bool metrics, hipStream_t s) {
     return e.cfg.dtype == CESX_F32
-        ? update_t<float>(e, out_rows, W, ktot, bias, src, nsrc, add1, c1, c1_imm, add2, c2, c2_imm, out, absmax_part, step_index, s)
-        : update_t<double>(e, out_rows, W, ktot, bias, src, nsrc, add1, c1, c1_imm, add2, c2, c2_imm, out, absmax_part, step_index, s);
+        ? update_t<float>(e, out_rows, W, ktot, bias, src, nsrc, add1, c1, c1_imm, add2, c2, c2_imm, out, absmax_part, step_index, metrics, s)
+        : update_t<double>(e, out_rows, W, ktot, bias, src, nsrc, add1, c1, c1_imm, add2, c2, c2_imm, out, absmax_part, step_index, metrics, s);
+}
+
+int update_grid_x(Engine& e) {
+    const int BN = e.cfg.dtype == CESX_F32 ? UpdCfg<float>::WC * 32 : UpdCfg<double>::WC * 16;
+    return (int)((e.J + BN - 1) / BN);
 }
 
 int update_grid_blocks(Engine& e, int out_rows) {

@@ -42,7 +42,8 @@ class StepParams(C.Structure):
 class StepResult(C.Structure):
     _fields_ = [("hk", C.c_double), ("t_new", C.c_double), ("self_bias", C.c_double),
                 ("self_bias_data", C.c_double), ("bias_data", C.c_double), ("bias", C.c_double),
-                ("radspec", C.c_double), ("status", C.c_int32), ("reserved", C.c_int32)]
+                ("radspec", C.c_double), ("lag_bias_data", C.c_double), ("lag_self_bias_data", C.c_double),
+                ("status", C.c_int32), ("reserved", C.c_int32)]
 
 
 class CesxError(RuntimeError):

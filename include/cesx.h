@@ -103,6 +103,13 @@ typedef struct cesx_step_result {
     double  bias_data;       /* metrics['bias-data']                    (:435/:467)  */
     double  bias;            /* metrics['bias']                         (:433/:465)  */
     double  radspec;         /* value appended to self.radspec (spectral only, :250) */
+    /* Sharded ensembles: self_bias_data / bias_data above hold only THIS shard's share
+       (its sum divided by J_global; the shares of all devices add up to the metric).
+       The two fields below are the complete values of the PREVIOUS step: each shard's
+       sums ride at the tail of the next step's all-reduced moment buffer, so no second
+       collective is needed.  On one device the values above are already complete. */
+    double  lag_bias_data;
+    double  lag_self_bias_data;
     int32_t status;          /* CESX_OK or CESX_ENOTPD for this step                 */
     int32_t reserved;
 } cesx_step_result;
@@ -149,7 +156,7 @@ int cesx_result(cesx_handle h, cesx_step_result* out);
 
 /* Length in doubles of the packed moment buffer that is summed across devices:
    [N, sum(u-s_u) (p), sum(g-s_g) (n), S_aa (p x p), S_ab (p x n), S_bb (n x n),
-    sum q_r^2, sum q_e^2, sum q_e, sum q_e*(g-s_g) (n)]. */
+    lagged sum q_r^2, lagged sum q_e^2 (data-metric sums of the previous step)]. */
 size_t cesx_moments_len(cesx_handle h);
 
 /* Row sums of this shard: sums_dev[0] = J_local, then sum_j U (p), sum_j G (n)

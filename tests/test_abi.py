@@ -41,7 +41,7 @@ def test_struct_layouts_match_header():
     # sizes implied by include/cesx.h on LP64
     assert ctypes.sizeof(engine.Config) == 4 * 5 + 4 + 8 * 4      # 5 x 32-bit + pad, 4 x 64-bit
     assert ctypes.sizeof(engine.StepParams) == 4 * 6 + 8 * 5
-    assert ctypes.sizeof(engine.StepResult) == 8 * 7 + 4 * 2
+    assert ctypes.sizeof(engine.StepResult) == 8 * 9 + 4 * 2
 
 
 def test_create_rejects_bad_config_without_gpu(lib):
