@@ -127,6 +127,7 @@ struct Scalars {              // device-resident fp64 scalars written by K2
     double radspec, frob2, tr_suu, absmax;
     double spare[4];
     int    status, pad;
+    unsigned long long seq;   // host copy only: step counter written last by publish_kernel
 };
 
 struct Engine {
@@ -197,9 +198,10 @@ struct Engine {
     std::vector<hipEvent_t> prof_pool;
     // results
     cesx_step_result* h_res = nullptr;   // pinned
-    Scalars* h_scal = nullptr;           // pinned
-    hipEvent_t ev = nullptr, ev_a = nullptr, ev_b = nullptr;
-    hipStream_t side = nullptr;      // side stream: chol(C) runs beside the rest of K2
+    Scalars* h_scal = nullptr;           // pinned, device-mapped: the GPU writes results straight into it
+    Scalars* h_scal_dev = nullptr;       // device address of h_scal
+    unsigned long long seq = 0;
+    hipEvent_t ev = nullptr;
     bool pending = false;
     cesx_step_params last_prm{};
 };
@@ -226,6 +228,7 @@ int update_grid_blocks(Engine& e, int out_rows);
 int update_grid_x(Engine& e);
 int launch_data_metrics(Engine& e, const void* G, hipStream_t s);   // dense Gamma: separate pass
 int launch_metric_final(Engine& e, const double* mom, hipStream_t s);
+int launch_publish(Engine& e, hipStream_t s);
 int launch_absmax_final(Engine& e, int nparts, double* absmax_out, hipStream_t s);
 int potrf_ld(int n);
 int gram_nbw(int dtype);

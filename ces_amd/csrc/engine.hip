@@ -2,6 +2,7 @@
 // the host-side sequencing of K1 (moments) -> K2 (dense) -> K3 (update).
 #include "cesx_internal.h"
 #include <cmath>
+#include <chrono>
 #include <cstring>
 #include <new>
 
@@ -93,8 +94,7 @@ int check_prm(Engine& e, const cesx_step_params* prm) {
 }
 
 int finish_step(Engine& e, const cesx_step_params& prm, hipStream_t s) {
-    CESX_HIP(hipMemcpyAsync(e.h_scal, e.d_scal, sizeof(Scalars), hipMemcpyDeviceToHost, s));
-    CESX_HIP(hipEventRecord(e.ev, s));
+    TRY(launch_publish(e, s));
     e.pending = true;
     e.last_prm = prm;
     return CESX_OK;
@@ -202,11 +202,9 @@ int cesx_create(const cesx_config* cfg, cesx_handle* out) {
     DM(e.d_scal, sizeof(Scalars)); DM(e.d_absmax, 8); DM(e.d_c0, 8);
     DM(e.d_absmax_part, (size_t)update_grid_blocks(e, p) * 8);
 #undef DM
-    if (hipHostMalloc(reinterpret_cast<void**>(&e.h_scal), sizeof(Scalars), hipHostMallocDefault) != hipSuccess ||
-        hipEventCreateWithFlags(&e.ev, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e.ev_a, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e.ev_b, hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking) != hipSuccess) {
+    if (hipHostMalloc(reinterpret_cast<void**>(&e.h_scal), sizeof(Scalars), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void**>(&e.h_scal_dev), e.h_scal, 0) != hipSuccess ||
+        hipEventCreateWithFlags(&e.ev, hipEventDisableTiming) != hipSuccess) {
         e.err = "pinned host buffer / event creation failed";
         return fail(CESX_EHIP);
     }
@@ -234,9 +232,6 @@ void cesx_destroy(cesx_handle h) {
     for (auto ev : e.prof_pool) (void)hipEventDestroy(ev);
     if (e.h_scal) (void)hipHostFree(e.h_scal);
     if (e.ev) (void)hipEventDestroy(e.ev);
-    if (e.ev_a) (void)hipEventDestroy(e.ev_a);
-    if (e.ev_b) (void)hipEventDestroy(e.ev_b);
-    if (e.side) (void)hipStreamDestroy(e.side);
     delete &e;
 }
 
@@ -377,7 +372,21 @@ int cesx_result(cesx_handle h, cesx_step_result* out) {
     Engine& e = *reinterpret_cast<Engine*>(h);
     if (!out) { e.err = "cesx_result: null pointer"; return CESX_EINVAL; }
     if (!e.pending) { e.err = "cesx_result: no step has been enqueued"; return CESX_ESTATE; }
-    CESX_HIP(hipEventSynchronize(e.ev));
+    // spin on the sequence number the GPU writes last into pinned memory
+    {
+        volatile unsigned long long* seq = &e.h_scal->seq;
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != e.seq) {
+            if ((++spins & 0xfff) == 0) {
+                if (hipPeekAtLastError() != hipSuccess) { e.err = "HIP error while waiting for the step"; return CESX_EHIP; }
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
+                    e.err = "timed out waiting for the step result";
+                    return CESX_EHIP;
+                }
+            }
+        }
+    }
     const Scalars& sc = *e.h_scal;
     out->hk = sc.hk; out->t_new = sc.t_new;
     out->self_bias = sc.self_bias; out->self_bias_data = sc.self_bias_data;

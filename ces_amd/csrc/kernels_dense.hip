@@ -847,11 +847,9 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
                        e.diag_sigma ? e.d_sw : (const double*)nullptr, unbiased, e.d_ubar, e.d_gbar, e.d_m,
                        e.d_dg, e.d_C, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_M, e.d_part, e.d_scal);
     CESX_HIP(hipGetLastError());
-    // the Cholesky of C runs on the engine's side stream beside the rest of K2
-    CESX_HIP(hipEventRecord(e.ev_a, s));
-    CESX_HIP(hipStreamWaitEvent(e.side, e.ev_a, 0));
-    if ((rc = potrf(e, e.side, p, e.d_C, e.d_L))) return rc;
-    CESX_HIP(hipEventRecord(e.ev_b, e.side));
+    // (a side stream for the Cholesky was measured: the two cross-stream event waits cost
+    //  ~20 us, more than the ~5 us of K2 work it could overlap)
+    if ((rc = potrf(e, s, p, e.d_C, e.d_L))) return rc;
     if (!e.diag_gamma) {
         // Frobenius term <Ginv Srr Ginv, See>, and K = C_ug Ginv
         if ((rc = gemm(e, s, n, n, n, 1.0, e.d_Ginv, n, 1, e.d_Srr, n, 1, e.d_t1))) return rc;
@@ -912,7 +910,6 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
         hipLaunchKernelGGL(matvec_kernel, g1(p, 4), dim3(DT), 0, s, p, p, e.d_P, e.d_mv + 5 * mx, e.d_mv + 4 * mx);
         CESX_HIP(hipGetLastError());
     }
-    CESX_HIP(hipStreamWaitEvent(s, e.ev_b, 0));      // L = chol(C) from the side stream
     const int ktot = mode == 2 ? e.kp + e.kn : e.ktot;
     return f32 ? assemble<float>(e, s, mode, ktot, prm.switch_mult) : assemble<double>(e, s, mode, ktot, prm.switch_mult);
 }

@@ -206,9 +206,11 @@ void gram_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __re
 }
 
 // Sum the per-slice partial blocks in fp64 (fixed order) and scatter them into
-// the packed moment buffer as full symmetric S_aa, S_ab, S_bb.  One thread per
-// 16-byte group of a block (4 f32 / 2 f64 along a block row), slices unrolled
-// by 8 so that enough loads are in flight to stream the slabs at HBM speed.
+// the packed moment buffer as full symmetric S_aa, S_ab, S_bb.  A workgroup
+// handles 64 16-byte groups (4 f32 / 2 f64 along a block row); its 4 waves
+// each sum a quarter of the slices (8 loads in flight per lane), the quarters
+// are combined through LDS in a fixed order.
+constexpr int RED_G = 64;
 template <typename T>
 __global__ __launch_bounds__(256)
 void gram_reduce_kernel(const T* __restrict__ slabs, const int* __restrict__ blk_rc,
@@ -216,12 +218,14 @@ void gram_reduce_kernel(const T* __restrict__ slabs, const int* __restrict__ blk
                         const double* __restrict__ rowsum_part, double* __restrict__ mom) {
     using vec_t = typename Mfma<T>::vec_t;
     constexpr int VEC = Mfma<T>::VEC;
+    __shared__ double part[4][RED_G][VEC];
     const int tt = tile * tile;
     const long long ngroups = (long long)nblocks * tt / VEC;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= ngroups) {
-        // tail threads: N and the first moments sum_j (z_ij - s_i)
-        const long long r = idx - ngroups;
+    const int gq = threadIdx.x >> 6, gl = threadIdx.x & 63;
+    const long long idx = (long long)blockIdx.x * RED_G + gl;
+    if ((long long)blockIdx.x * RED_G >= ngroups) {
+        // tail workgroups: N and the first moments sum_j (z_ij - s_i)
+        const long long r = ((long long)blockIdx.x * RED_G - ngroups) / RED_G * 256 + threadIdx.x;
         if (r == 0) mom[0] = (double)J;
         if (r < p + n) {
             double s = 0.0;
@@ -230,29 +234,38 @@ void gram_reduce_kernel(const T* __restrict__ slabs, const int* __restrict__ blk
         }
         return;
     }
-    const int blk = (int)(idx / (tt / VEC)), e0 = (int)(idx % (tt / VEC)) * VEC;
-    const int R = blk_rc[blk * 2], C = blk_rc[blk * 2 + 1];
-    const int P = p + n;
+    const bool on = idx < ngroups;
+    const int blk = on ? (int)(idx / (tt / VEC)) : 0, e0 = on ? (int)(idx % (tt / VEC)) * VEC : 0;
     double acc[VEC];
 #pragma unroll
     for (int c = 0; c < VEC; ++c) acc[c] = 0.0;
     const T* src = slabs + (size_t)blk * tt + e0;
     const size_t stride = (size_t)nblocks * tt;
-    int k = 0;
-    for (; k + 8 <= nslices; k += 8) {
-        vec_t v[8];
+    const int per = (nslices + 3) / 4;
+    const int k1 = min(nslices, (gq + 1) * per);
+    int k = gq * per;
+    if (on) {
+        for (; k + 8 <= k1; k += 8) {
+            vec_t v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const vec_t*>(src + (size_t)(k + u) * stride);
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const vec_t*>(src + (size_t)(k + u) * stride);
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < 8; ++u)
 #pragma unroll
-            for (int c = 0; c < VEC; ++c) acc[c] += (double)v[u][c];
+                for (int c = 0; c < VEC; ++c) acc[c] += (double)v[u][c];
+        }
+        for (; k < k1; ++k) {
+            const vec_t v = *reinterpret_cast<const vec_t*>(src + (size_t)k * stride);
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) acc[c] += (double)v[c];
+        }
     }
-    for (; k < nslices; ++k) {
-        const vec_t v = *reinterpret_cast<const vec_t*>(src + (size_t)k * stride);
 #pragma unroll
-        for (int c = 0; c < VEC; ++c) acc[c] += (double)v[c];
-    }
+    for (int c = 0; c < VEC; ++c) part[gq][gl][c] = acc[c];
+    __syncthreads();
+    if (gq != 0 || !on) return;
+    const int R = blk_rc[blk * 2], C = blk_rc[blk * 2 + 1];
+    const int P = p + n;
     double* Saa = mom + 1 + p + n;
     double* Sab = Saa + (size_t)p * p;
     double* Sbb = Sab + (size_t)p * n;
@@ -262,7 +275,7 @@ void gram_reduce_kernel(const T* __restrict__ slabs, const int* __restrict__ blk
         const int gr = R * tile + e / tile, gc = C * tile + e % tile;
         if (gr >= P || gc >= P) continue;
         if (R == C && gc > gr) continue;          // diagonal block: lower half, mirrored below
-        const double s = acc[c];
+        const double s = ((part[0][gl][c] + part[1][gl][c]) + part[2][gl][c]) + part[3][gl][c];
         if (gr < p) {                              // both in U (gr >= gc)
             Saa[(size_t)gr * p + gc] = s;
             Saa[(size_t)gc * p + gr] = s;
@@ -374,8 +387,9 @@ static int launch_gram_t(Engine& e, const void* U, const void* G, double* mom, h
                            pl.nblocks, (T*)e.d_slabs, e.d_rowsum_part);
     }
     CESX_HIP(hipGetLastError());
-    const long long total = (long long)pl.nblocks * pl.tile * pl.tile / Mfma<T>::VEC + e.p + e.n;
-    hipLaunchKernelGGL(gram_reduce_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+    const long long ngroups = (long long)pl.nblocks * pl.tile * pl.tile / Mfma<T>::VEC;
+    const long long wgs = (ngroups + RED_G - 1) / RED_G + (e.p + e.n + 255) / 256;
+    hipLaunchKernelGGL(gram_reduce_kernel<T>, dim3((unsigned)wgs), dim3(256), 0, s,
                        (const T*)e.d_slabs, e.d_blk_rc, e.nslices, pl.nblocks, pl.tile, e.p, e.n,
                        (long long)e.J, e.d_rowsum_part, mom);
     CESX_HIP(hipGetLastError());

@@ -8,6 +8,7 @@
 //                      update kernel K3 accumulates them while the G rows stream by.
 //   metric_final_kernel  fixed-order fp64 sum of the per-workgroup partials.
 #include "cesx_internal.h"
+#include <cstddef>
 
 namespace cesx {
 
@@ -197,6 +198,26 @@ static int data_metrics_t(Engine& e, const void* G, hipStream_t s) {
 // dense Gamma only: fills e.d_metric_part with one entry per 64 particles
 int launch_data_metrics(Engine& e, const void* G, hipStream_t s) {
     return e.cfg.dtype == CESX_F32 ? data_metrics_t<float>(e, G, s) : data_metrics_t<double>(e, G, s);
+}
+
+// Results of a step go straight into pinned host memory; the sequence number is written
+// last (system-scope fence in between) and the host polls it -- no D2H copy, no event wake-up.
+__global__ void publish_kernel(const Scalars* __restrict__ sc, Scalars* host, unsigned long long seq) {
+    const double* src = reinterpret_cast<const double*>(sc);
+    double* dst = reinterpret_cast<double*>(host);
+    constexpr int ND = offsetof(Scalars, seq) / 8;
+    if (threadIdx.x < ND) dst[threadIdx.x] = src[threadIdx.x];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+int launch_publish(Engine& e, hipStream_t s) {
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, s, e.d_scal, e.h_scal_dev, ++e.seq);
+    CESX_HIP(hipGetLastError());
+    return CESX_OK;
 }
 
 int launch_metric_final(Engine& e, const double* mom, hipStream_t s) {
