@@ -22,7 +22,7 @@
 
 namespace cesx {
 
-constexpr int GRAM_THREADS = 512;          // 8 waves = 2 per SIMD: one wave's LDS latency hides behind the other's MFMAs
+constexpr int GRAM_THREADS = 1024;         // 16 waves = 4 per SIMD: the MFMA pipe always finds a ready wave
 constexpr int GRAM_WAVES = GRAM_THREADS / 64;
 constexpr int ROW_BYTES = 128;            // one staged row of a tile: 32 f32 / 16 f64
 constexpr int ROW_STRIDE = ROW_BYTES + 16;  // +16 B pad: conflict-free ds_read_b128 over 16 rows
@@ -30,11 +30,11 @@ constexpr int MAX_STAGE_ROWS = 512;
 constexpr int MAXCH = MAX_STAGE_ROWS * (ROW_BYTES / 16) / GRAM_THREADS;   // 16 chunks / thread
 
 template <typename T> struct GramCfg;
-template <> struct GramCfg<float>  { static constexpr int NBW = 9; };    // 9 x 16 accumulator VGPRs per wave
-template <> struct GramCfg<double> { static constexpr int NBW = 17; };   // 17 x 8
+template <> struct GramCfg<float>  { static constexpr int NBW = 5; };    // 5 x 16 accumulator VGPRs per wave
+template <> struct GramCfg<double> { static constexpr int NBW = 9; };    // 9 x 8
 
 template <typename T, bool ALIGNED>
-__global__ __launch_bounds__(GRAM_THREADS, 2)
+__global__ __launch_bounds__(GRAM_THREADS, 4)
 void gram_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __restrict__ shift,
                  int p, int n, long long J, const int* __restrict__ type_hdr,
                  const int* __restrict__ rows_tab, const int* __restrict__ wblk,
@@ -84,7 +84,7 @@ void gram_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __re
     const long long t0 = (long long)slice * tps;
     const long long t1 = t0 + tps < ntiles ? t0 + tps : ntiles;
 
-    // staging: thread handles 16-byte chunk `part` of rows (tid/8 + 64*i)
+    // staging: thread handles 16-byte chunk `part` of rows (tid/8 + 128*i)
     const int part = tid & 7, row0 = tid >> 3;
     constexpr int RPP = GRAM_THREADS / 8;              // rows covered per pass (64)
     const int nch = (nrows + RPP - 1) / RPP;           // chunks this thread handles
@@ -355,8 +355,13 @@ GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds) {
             pl.rows.push_back(r | (first ? 1 << 16 : 0));
         }
         const int nv = (int)v.size();
+        // waves w, w+4, w+8, ... share a SIMD: the first (nv % waves) waves take one extra
+        // block, which keeps the per-SIMD totals within one block of each other
+        int next = 0;
         for (int w = 0; w < GRAM_WAVES; ++w) {
-            const int lo = (int)((long long)nv * w / GRAM_WAVES), hi = (int)((long long)nv * (w + 1) / GRAM_WAVES);
+            const int cnt = nv / GRAM_WAVES + (w < nv % GRAM_WAVES ? 1 : 0);
+            const int lo = next, hi = next + cnt;
+            next = hi;
             for (int b = 0; b < nbw; ++b) {
                 if (lo + b < hi) {
                     pl.wblk.push_back(compact(v[lo + b].first));

@@ -24,6 +24,9 @@ namespace cesx {
 
 constexpr int UPD_THREADS = 256;
 constexpr int BK = 16;
+#ifndef UPD_ABL      // timing ablations of tools/update_bench.hip (results are wrong when set)
+#define UPD_ABL 0
+#endif
 
 template <typename T> struct UpdCfg;
 template <> struct UpdCfg<float> {
@@ -176,7 +179,7 @@ void update_kernel(const UpdArgs<T> a) {
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nkt) load_tile(kt + 1);
+        if (!(UPD_ABL & 1) && kt + 1 < nkt) load_tile(kt + 1);
         if (a.metric_part != nullptr && blockIdx.y == 0) {
             // is the tile in sX[cur] a tile of G rows?
             const int k0 = kt * BK;
@@ -201,16 +204,28 @@ void update_kernel(const UpdArgs<T> a) {
 #pragma unroll
             for (int g = 0; g < BK / GROUP; ++g) {
                 vec_t af[WR];
-#pragma unroll
-                for (int r = 0; r < WR; ++r)
-                    af[r] = *reinterpret_cast<const vec_t*>(
-                        &sW[cur][(wave * WR * TILE + r * TILE + li) * SW + g * GROUP + lh * VEC]);
                 T xf[WC][VEC];
+                if (UPD_ABL & 4) {
+                    // ablation: no LDS fragment reads (operands from registers)
 #pragma unroll
-                for (int c = 0; c < WC; ++c)
+                    for (int r = 0; r < WR; ++r)
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v)
-                        xf[c][v] = sX[cur][(g * GROUP + lh * VEC + v) * SX + c * TILE + li];
+                        for (int v = 0; v < VEC; ++v) af[r][v] = (T)(lane + r + v + kt);
+#pragma unroll
+                    for (int c = 0; c < WC; ++c)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) xf[c][v] = (T)(lane - c - v + kt);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < WR; ++r)
+                        af[r] = *reinterpret_cast<const vec_t*>(
+                            &sW[cur][(wave * WR * TILE + r * TILE + li) * SW + g * GROUP + lh * VEC]);
+#pragma unroll
+                    for (int c = 0; c < WC; ++c)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v)
+                            xf[c][v] = sX[cur][(g * GROUP + lh * VEC + v) * SX + c * TILE + li];
+                }
 #pragma unroll
                 for (int r = 0; r < WR; ++r) {
                     if (rb_on[r]) {
@@ -223,8 +238,8 @@ void update_kernel(const UpdArgs<T> a) {
                 }
             }
         }
-        if (kt + 1 < nkt) store_tile(cur ^ 1);
-        __syncthreads();
+        if (!(UPD_ABL & 1) && kt + 1 < nkt) store_tile(cur ^ 1);
+        if (!(UPD_ABL & 2)) __syncthreads();
     }
 
     // epilogue
