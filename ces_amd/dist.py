@@ -4,18 +4,25 @@ One process per GPU.  Rank r owns the column range ``shard_range(J, N, r)`` of
 U, G and U_next.  Particles are exchangeable and couple only through first and
 second moments, so one step needs exactly ONE collective: an
 all-reduce(sum) of the packed fp64 moment buffer between the two halves of the
-step (``cesx_moments`` -> all-reduce -> ``cesx_apply``).  Two rule-specific
-extras: a (1+p+n)-double all-reduce when the centring shift is (re)computed
-from the data (first step of a run), and a one-scalar all-reduce(max) for
+step (``cesx_moments`` -> all-reduce -> ``cesx_apply``).  Rule-specific extras:
+a (1+p+n)-double all-reduce when the centring shift is (re)computed from the
+data (first step of a run), and a one-scalar all-reduce(max) for
 ``eks_update_aldi_constant`` (ces/calibrate.py:519 takes max|drift| over the
-whole ensemble).  The collectives go through ``torch.distributed`` (backend
-"nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+whole ensemble).  The two fourth-order data metrics need the exact mean, so a
+shard can only sum them AFTER the all-reduce; its two sums ride at the tail of
+the NEXT step's moment buffer (``StepResult.lag_*``) and are flushed once at the
+end of a run -- no per-step second collective.  Collectives go through
+``torch.distributed`` (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the
+CPU tests).
 
 The engine object only needs the split entry points of the C ABI, so the same
 driver is exercised on CPU with an oracle-backed stand-in (tests/).
 """
+import numpy as np
 import torch
 import torch.distributed as dist
+
+_METRIC_KEYS = ("self-bias", "self-bias-data", "bias-data", "bias", "t")
 
 
 def shard_range(J, world, rank):
@@ -56,3 +63,81 @@ class ShardedUpdate:
             absmax = self._all_reduce(eng.apply_drift(prm, mom, U, G, out), op=dist.ReduceOp.MAX)
             return eng.apply_finish(prm, absmax, U, xi, out)
         return eng.apply(prm, mom, U, G, xi=xi, out=out)
+
+    def result(self):
+        """Result of the last step.  On more than one rank ``bias_data`` /
+        ``self_bias_data`` are this shard's share; ``lag_*`` are the complete values of
+        the previous step."""
+        return self.engine.result()
+
+    def flush_data_metrics(self, res):
+        """Complete data metrics of the LAST step (one tiny all-reduce at the end of a run)."""
+        t = torch.tensor([res.bias_data, res.self_bias_data], dtype=torch.float64)
+        if self.world > 1:
+            dev = getattr(self.engine, "device", None)
+            t = t.to(dev) if dev is not None and dist.get_backend(self.group) == "nccl" else t
+            dist.all_reduce(t, group=self.group)
+        return float(t[0]), float(t[1])
+
+
+class ShardedSampler:
+    """``sampling.run`` (ces/calibrate.py:270-416) for an ensemble sharded over ranks.
+
+    Every rank holds the columns ``shard_range(J, world, rank)`` of the ensemble
+    on its device for the whole run; the forward map is evaluated per shard
+    (``model.forward_device`` when the model offers the hook, otherwise the
+    reference's host loop over the shard's particles).  All ranks compute the
+    same hk / t / metrics (K2 runs redundantly on identical all-reduced moments),
+    so every rank takes the same ``t_tol`` decision without a broadcast.
+    """
+
+    def __init__(self, engine, p, n_obs, J, group=None):
+        self.engine, self.p, self.n_obs, self.J = engine, p, n_obs, J
+        self.sh = ShardedUpdate(engine, group)
+        self.T = 30
+        self.metrics = {k: [] for k in _METRIC_KEYS}
+        self.radspec = []
+
+    def _forward(self, model, U):
+        if hasattr(model, "forward_device"):
+            return model.forward_device(self.engine, U)
+        Uh = U.cpu().numpy().astype(np.float64)
+        Gh = np.stack([np.asarray(model(u)) for u in Uh.T], axis=1)
+        return self.engine.to_device(Gh[: self.n_obs])
+
+    def run(self, y_obs, U_shard, model, Gamma, mu, sigma, ustar, update="aldi", xis=None, **kwargs):
+        """Returns the final shard (a device tensor of the engine)."""
+        from .engine import step_params
+        eng, m = self.engine, self.metrics
+        eng.set_problem(y_obs, Gamma, mu, sigma, ustar)
+        U = eng.to_device(U_shard)
+        res = None
+        for i in range(self.T):
+            G = self._forward(model, U)
+            t = m["t"]
+            prm = step_params(update=update, time_step=kwargs.get("time_step"), first_step=(i == 0 and not t),
+                              t_len=len(t), t_last=t[-1] if t else 0.0, delta_t=kwargs.get("delta_t"),
+                              spinup=kwargs.get("spinup", 4.0), switch=kwargs.get("switch", 1.0),
+                              step_index=i, T=self.T)
+            xi = None if xis is None else eng.to_device(xis[i])
+            U = self.sh.step(prm, U, G, xi=xi, recenter=(i == 0))
+            res = self.sh.result()
+            m["self-bias"].append(res.self_bias)
+            m["bias"].append(res.bias)
+            m["t"].append(res.t_new)
+            if kwargs.get("time_step") == "spectral" and update != "aldi_constant":
+                self.radspec.append(res.radspec)
+            if self.sh.world == 1:
+                m["bias-data"].append(res.bias_data)
+                m["self-bias-data"].append(res.self_bias_data)
+            elif i > 0:                          # the previous step's complete values arrive now
+                m["bias-data"].append(res.lag_bias_data)
+                m["self-bias-data"].append(res.lag_self_bias_data)
+            if m["t"][-1] > kwargs.get("t_tol", 2.0):
+                break
+        if self.sh.world > 1 and res is not None:
+            bd, sbd = self.sh.flush_data_metrics(res)
+            m["bias-data"].append(bd)
+            m["self-bias-data"].append(sbd)
+        self.Ustar = U
+        return U

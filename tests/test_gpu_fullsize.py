@@ -1,0 +1,156 @@
+"""Full-size (BASELINE.json configs[1]/[2]) checks on the GPU through properties that
+do not need the CPU oracle at J = 65 536: agreement with an fp64 torch restatement of
+the factored step evaluated on the device (checker only), shard additivity, noise
+statistics, in-kernel vs injected noise.  p = n_obs = 256."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+P, N, J = 256, 256, 65536
+
+
+@pytest.fixture(scope="module")
+def setup():
+    import torch
+    from ces_amd import build, engine
+    build.build_lib()
+    assert torch.cuda.is_available()
+    rng = np.random.default_rng(20240)
+    A = rng.standard_normal((N, P)) / np.sqrt(P)
+    ustar = rng.standard_normal((P, 1))
+    prob = dict(A=A, ustar=ustar, Gamma=0.01 * np.eye(N), y=(A @ ustar).ravel() + 0.1 * rng.standard_normal(N),
+                mu=np.zeros((P, 1)), sigma=100.0 * np.eye(P))
+    g = torch.Generator(device="cuda").manual_seed(7)
+    U = torch.as_tensor(ustar, device="cuda") + torch.randn((P, J), generator=g, device="cuda", dtype=torch.float64)
+    G = torch.as_tensor(A, device="cuda") @ U
+    xi = torch.randn((P, J), generator=g, device="cuda", dtype=torch.float64)
+    return engine, prob, U, G, xi
+
+
+def torch_factored_aldi(prob, U, G, xi):
+    """fp64 restatement of ces/calibrate.py:451-490 in J x J-free form, on device."""
+    import torch
+    dev = U.device
+    T = lambda a: torch.as_tensor(a, device=dev, dtype=torch.float64)
+    y, Gamma, mu, sigma, ustar = T(prob["y"]).reshape(-1, 1), T(prob["Gamma"]), T(prob["mu"]), T(prob["sigma"]), T(prob["ustar"])
+    p, Jn = U.shape
+    ubar, gbar = U.mean(1, keepdim=True), G.mean(1, keepdim=True)
+    Au, E = U - ubar, G - gbar
+    S_uu, S_ug, S_ee = Au @ Au.T, Au @ E.T, E @ E.T
+    m = gbar - y
+    S_rr = S_ee + Jn * (m @ m.T)
+    Ginv = torch.linalg.inv(Gamma)
+    frob = torch.sqrt(((Ginv @ S_rr @ Ginv.T) * S_ee).sum()) / Jn
+    hk = 1.0 / (frob + 1e-8)
+    C = S_uu / (Jn - 1) + 1e-8 * torch.eye(p, device=dev, dtype=torch.float64)
+    L = torch.linalg.cholesky(C)
+    K = (S_ug / Jn) @ Ginv
+    M = C @ torch.linalg.inv(sigma)
+    alpha = (p + 1.0) / Jn
+    Uk = U - hk * (K @ (G - y)) - hk * (M @ (U - mu)) + hk * alpha * Au + torch.sqrt(2 * hk) * (L @ xi)
+    R = G - y
+    met = dict(self_bias=(torch.trace(S_uu) / Jn).item(),
+               bias=(torch.trace(S_uu) / Jn + ((ubar - ustar) ** 2).sum()).item(),
+               self_bias_data=((((Ginv @ E) * E).sum(0)) ** 2).mean().item(),
+               bias_data=((((Ginv @ R) * R).sum(0)) ** 2).mean().item())
+    return Uk, hk.item(), met
+
+
+@pytest.mark.parametrize("dtype,tol", [("float32", 1e-3), ("float64", 1e-6)])
+def test_c2_step_matches_fp64_restatement(setup, dtype, tol):
+    import torch
+    engine, prob, U, G, xi = setup
+    eng = engine.Engine(P, N, J, dtype=dtype)
+    eng.set_problem(prob["y"], prob["Gamma"], prob["mu"], prob["sigma"], prob["ustar"])
+    Ud, Gd, xid = eng.to_device(U), eng.to_device(G), eng.to_device(xi)
+    out = eng.step(engine.step_params(update="aldi"), Ud, Gd, xi=xid)
+    res = eng.result()
+    ref, hk, met = torch_factored_aldi(prob, Ud.double(), Gd.double(), xid.double())
+    err = ((out.double() - ref).abs().max() / ref.abs().max()).item()
+    assert err < tol, err
+    mt = 1e-9 if dtype == "float64" else 1e-4
+    assert res.hk == pytest.approx(hk, rel=mt)
+    for k, v in met.items():
+        assert getattr(res, k) == pytest.approx(v, rel=max(mt, 1e-8) * 10), k
+    assert torch.isfinite(out).all()
+
+
+def test_c3_logical_shards_match_whole_ensemble(setup):
+    """configs[2] arithmetic on one device: 4 column shards, moments summed on device
+    (stand-in for the RCCL all-reduce), apply per shard == single-shard step."""
+    import torch
+    engine, prob, U, G, xi = setup
+    whole = engine.Engine(P, N, J, dtype="float32")
+    whole.set_problem(prob["y"], prob["Gamma"], prob["mu"], prob["sigma"], prob["ustar"])
+    prm = engine.step_params(update="aldi", step_index=3)
+    ref = whole.step(prm, U, G, xi=None).clone()           # on-device noise keyed by the global index
+    rw = whole.result()
+    nsh = 4
+    cuts = [J * k // nsh for k in range(nsh + 1)]
+    shards = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        e = engine.Engine(P, N, b - a, dtype="float32", J_global=J, j_offset=a)
+        e.set_problem(prob["y"], prob["Gamma"], prob["mu"], prob["sigma"], prob["ustar"])
+        shards.append((e, e.to_device(U[:, a:b]), e.to_device(G[:, a:b])))
+    sums = sum(e.colsum(Us, Gs) for e, Us, Gs in shards)
+    for e, *_ in shards:
+        e.set_shift(sums)
+    mom = sum(e.moments(Us, Gs) for e, Us, Gs in shards)
+    outs = [e.apply(prm, mom, Us, Gs, xi=None) for e, Us, Gs in shards]
+    share = [e.result() for e, *_ in shards]
+    got = torch.cat(outs, dim=1)
+    err = ((got - ref).abs().max() / ref.abs().max()).item()
+    assert err < 2e-5, err
+    assert share[0].hk == pytest.approx(rw.hk, rel=1e-6)
+    # the shards' shares of the data metrics add up to the whole-ensemble values
+    assert sum(s.bias_data for s in share) == pytest.approx(rw.bias_data, rel=1e-5)
+    assert sum(s.self_bias_data for s in share) == pytest.approx(rw.self_bias_data, rel=1e-5)
+
+
+def test_device_noise_statistics_full_size(setup):
+    import torch
+    engine, prob, U, G, xi = setup
+    eng = engine.Engine(P, N, J, dtype="float32", seed=99)
+    z = eng.draw_noise(11).double()
+    assert abs(z.mean().item()) < 1e-3 and abs(z.var().item() - 1.0) < 2e-3
+    assert abs((z ** 4).mean().item() - 3.0) < 0.02                      # kurtosis of N(0,1)
+    c = (z[:, :8192] @ z[:, :8192].T) / 8192                              # rows are uncorrelated
+    off = c - torch.diag(torch.diag(c))
+    assert off.abs().max().item() < 0.08
+    z2 = eng.draw_noise(12).double()
+    assert abs((z * z2).mean().item()) < 1e-3                             # steps are independent
+
+
+def test_in_kernel_noise_equals_injected_full_size(setup):
+    engine, prob, U, G, xi = setup
+    eng = engine.Engine(P, N, J, dtype="float32", seed=5)
+    eng.set_problem(prob["y"], prob["Gamma"], prob["mu"], prob["sigma"], prob["ustar"])
+    prm = engine.step_params(update="aldi", step_index=2)
+    a = eng.step(prm, U, G, xi=None).clone()
+    eng.result()
+    b = eng.step(prm, U, G, xi=eng.draw_noise(2))
+    eng.result()
+    assert ((a - b).abs().max() / b.abs().max()).item() < 1e-5
+
+
+def test_sharded_sampler_single_rank_chain(setup):
+    """ShardedSampler (device-resident chain, device forward hook) == step-by-step drop-in class."""
+    import torch
+    from ces_amd.dist import ShardedSampler
+    from ces_amd.utils import lineal
+    engine, prob, U, G, xi = setup
+    Js, T = 4096, 4
+    eng = engine.Engine(P, N, Js, dtype="float64")
+    smp = ShardedSampler(eng, P, N, Js)
+    smp.T = T
+    xis = xi[:, : Js * T].reshape(P, T, Js).permute(1, 0, 2).contiguous()
+    Uf = smp.run(prob["y"], U[:, :Js], lineal(prob["A"]), prob["Gamma"], prob["mu"], prob["sigma"], prob["ustar"],
+                 update="aldi", xis=xis, t_tol=1e9)
+    Uc = U[:, :Js].double()
+    A = torch.as_tensor(prob["A"], device="cuda")
+    for i in range(T):
+        Uc, hk, met = torch_factored_aldi(prob, Uc, A @ Uc, xis[i].double())
+        assert smp.metrics["bias-data"][i] == pytest.approx(met["bias_data"], rel=1e-8)
+    assert ((Uf - Uc).abs().max() / Uc.abs().max()).item() < 1e-8
+    assert len(smp.metrics["t"]) == T
