@@ -76,6 +76,9 @@ void update_kernel(const UpdArgs<T> a) {
     T (*sW)[RC * SW] = reinterpret_cast<T (*)[RC * SW]>(smem);
     T (*sX)[BK * SX] = reinterpret_cast<T (*)[BK * SX]>(smem + 2 * RC * SW * sizeof(T));
     double* red = reinterpret_cast<double*>(smem + 2 * (RC * SW + BK * SX) * sizeof(T));
+    // per-row constants of the data metrics {gbar, y, 1/Gamma_ii, 0}, staged once: a global
+    // load inside the K loop would make its vmcnt wait drain the tile prefetch as well
+    T* sRowc = reinterpret_cast<T*>(smem + 2 * (RC * SW + BK * SX) * sizeof(T) + 64);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -95,6 +98,12 @@ void update_kernel(const UpdArgs<T> a) {
     vec_t wst[WCH], xst[XCH];
     int xkind = 0, xq0 = 0;
     T mq_e = 0, mq_r = 0;          // per-particle quadratic forms (partial over this thread's rows)
+    const bool do_metrics = a.metric_part != nullptr && blockIdx.y == 0;
+    if (do_metrics) {
+        const int sg = a.metric_seg;
+        const int kend = sg + 1 < a.nsrc ? a.src_k0[sg + 1] : a.ktot;
+        for (int i = tid; i < (kend - a.src_k0[sg]) * 4; i += UPD_THREADS) sRowc[i] = a.rowc[i];
+    }
 
     auto load_tile = [&](int kt) {
         const int k0 = kt * BK;
@@ -180,7 +189,7 @@ void update_kernel(const UpdArgs<T> a) {
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         if (!(UPD_ABL & 1) && kt + 1 < nkt) load_tile(kt + 1);
-        if (a.metric_part != nullptr && blockIdx.y == 0) {
+        if (do_metrics) {
             // is the tile in sX[cur] a tile of G rows?
             const int k0 = kt * BK;
             const int sg = a.metric_seg;
@@ -193,7 +202,7 @@ void update_kernel(const UpdArgs<T> a) {
                 for (int q = 0; q < RPT; ++q) {
                     const int rr = grp * RPT + q;
                     const T x = sX[cur][rr * SX + jl];
-                    const T* rc = a.rowc + (size_t)(r0 + rr) * 4;
+                    const T* rc = sRowc + (size_t)(r0 + rr) * 4;
                     const T b = x - rc[0], r = x - rc[1], w = rc[2];
                     mq_e += w * b * b;
                     mq_r += w * r * r;
@@ -269,7 +278,7 @@ void update_kernel(const UpdArgs<T> a) {
             }
         }
     }
-    if (a.metric_part != nullptr && blockIdx.y == 0) {
+    if (do_metrics) {
         // combine the row groups of each particle through LDS (the K loop is over), square, reduce
         T* comb = reinterpret_cast<T*>(smem);
         __syncthreads();
@@ -375,7 +384,7 @@ static int update_t(Engine& e, int out_rows, const void* W, int ktot, const void
     a.metric_seg = 1;                    // [U; G; ...]: G is segment 1
     a.seed_lo = (unsigned)e.cfg.seed; a.seed_hi = (unsigned)(e.cfg.seed >> 32); a.step = (unsigned)step_index;
     dim3 grid((unsigned)((e.J + BN - 1) / BN), (unsigned)((out_rows + RC - 1) / RC));
-    const int lds = 2 * (RC * C::STRIDE_W + BK * (BN + C::XPAD)) * (int)sizeof(T) + 64;   // >= 2 * 256 * sizeof(T) for the metric combine
+    const int lds = 2 * (RC * C::STRIDE_W + BK * (BN + C::XPAD)) * (int)sizeof(T) + 64 + e.kn * 4 * (int)sizeof(T);
     auto kern = aligned ? update_kernel<T, true> : update_kernel<T, false>;
     CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));

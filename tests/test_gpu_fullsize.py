@@ -154,3 +154,30 @@ def test_sharded_sampler_single_rank_chain(setup):
         assert smp.metrics["bias-data"][i] == pytest.approx(met["bias_data"], rel=1e-8)
     assert ((Uf - Uc).abs().max() / Uc.abs().max()).item() < 1e-8
     assert len(smp.metrics["t"]) == T
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-6), ("float32", 1e-3)])
+def test_c5_dimensions_p512(dtype, tol):
+    """BASELINE.json configs[4] dimensions (d = 512, n_obs = 512; ALDI, on-device Cholesky
+    through the global-memory kernel, Gram through the rectangle partition) on one shard."""
+    import torch
+    from ces_amd import engine
+    p = n = 512
+    Jn = 4096
+    rng = np.random.default_rng(1)
+    A = rng.standard_normal((n, p)) / np.sqrt(p)
+    ustar = rng.standard_normal((p, 1))
+    prob = dict(A=A, ustar=ustar, Gamma=0.01 * np.eye(n), y=(A @ ustar).ravel() + 0.1 * rng.standard_normal(n),
+                mu=np.zeros((p, 1)), sigma=100.0 * np.eye(p))
+    g = torch.Generator(device="cuda").manual_seed(3)
+    U = torch.as_tensor(ustar, device="cuda") + torch.randn((p, Jn), generator=g, device="cuda", dtype=torch.float64)
+    G = torch.as_tensor(A, device="cuda") @ U
+    xi = torch.randn((p, Jn), generator=g, device="cuda", dtype=torch.float64)
+    eng = engine.Engine(p, n, Jn, dtype=dtype)
+    eng.set_problem(prob["y"], prob["Gamma"], prob["mu"], prob["sigma"], prob["ustar"])
+    Ud, Gd, xid = eng.to_device(U), eng.to_device(G), eng.to_device(xi)
+    out = eng.step(engine.step_params(update="aldi"), Ud, Gd, xi=xid)
+    res = eng.result()
+    ref, hk, met = torch_factored_aldi(prob, Ud.double(), Gd.double(), xid.double())
+    assert ((out.double() - ref).abs().max() / ref.abs().max()).item() < tol
+    assert res.hk == pytest.approx(hk, rel=1e-4 if dtype == "float32" else 1e-9)

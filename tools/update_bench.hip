@@ -25,7 +25,7 @@ int main(int argc, char** argv) {
     using C = UpdCfg<float>;
     constexpr int RC = 4 * C::WR * 32, BN = C::WC * 32;
     dim3 grid((unsigned)((J + BN - 1) / BN), 1);
-    const int lds = 2 * (RC * C::STRIDE_W + BK * (BN + C::XPAD)) * 4 + 64;
+    const int lds = 2 * (RC * C::STRIDE_W + BK * (BN + C::XPAD)) * 4 + 64 + kn * 16;
     auto kern = update_kernel<float, true>;
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
