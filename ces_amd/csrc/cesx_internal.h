@@ -213,6 +213,7 @@ struct UpdateSrc {            // one K-segment of the update GEMM
     const void* ptr;          // (rows x J) array, or nullptr for on-device noise
     int rows;                 // real rows
     int kind;                 // 0 = memory, 1 = philox noise
+    int tri;                  // 1: the W columns of this segment are lower triangular (sqrt(2hk) L)
 };
 
 int launch_colsum(Engine& e, const void* U, const void* G, double* sums, hipStream_t s);

@@ -102,7 +102,7 @@ int finish_step(Engine& e, const cesx_step_params& prm, hipStream_t s) {
 
 int run_update_main(Engine& e, const cesx_step_params& prm, const void* U, const void* G, const void* xi,
                     void* Unext, hipStream_t s) {
-    UpdateSrc src[3] = {{U, e.p, 0}, {G, e.n, 0}, {xi, e.p, xi ? 0 : 1}};
+    UpdateSrc src[3] = {{U, e.p, 0, 0}, {G, e.n, 0, 0}, {xi, e.p, xi ? 0 : 1, 1}};
     return launch_update(e, e.p, e.d_W, e.ktot, e.d_bias, src, 3, nullptr, nullptr, 0.0, nullptr, nullptr, 0.0,
                          Unext, nullptr, prm.step_index, e.diag_gamma, s);
 }
@@ -308,7 +308,7 @@ int cesx_apply_drift(cesx_handle h, const cesx_step_params* prm, const double* m
     TRY(set_device(e));
     hipStream_t s = (hipStream_t)stream;
     TRY(launch_dense(e, *prm, mom, 1, s));
-    UpdateSrc src[2] = {{U, e.p, 0}, {G, e.n, 0}};
+    UpdateSrc src[2] = {{U, e.p, 0, 0}, {G, e.n, 0, 0}};
     TRY(launch_update(e, e.p, e.d_W, e.kp + e.kn, e.d_bias, src, 2, nullptr, nullptr, 0.0, nullptr, nullptr, 0.0,
                       Unext, e.d_absmax_part, prm->step_index, e.diag_gamma, s));
     TRY(finish_metrics(e, mom, G, s));
@@ -326,7 +326,7 @@ int cesx_apply_finish(cesx_handle h, const cesx_step_params* prm, const double* 
     if (absmax != e.d_absmax) CESX_HIP(hipMemcpyAsync(e.d_absmax, absmax, 8, hipMemcpyDeviceToDevice, s));
     TRY(launch_dense(e, *prm, nullptr, 2, s));
     // U_next = sqrt(2hk) L xi + 1 * U + hk * drift   (drift currently lives in U_next)
-    UpdateSrc src[1] = {{xi, e.p, xi ? 0 : 1}};
+    UpdateSrc src[1] = {{xi, e.p, xi ? 0 : 1, 1}};
     TRY(launch_update(e, e.p, e.d_W, e.kp, nullptr, src, 1, U, nullptr, 1.0, Unext, &e.d_scal->hk, 1.0, Unext,
                       nullptr, prm->step_index, false, s));
     return finish_step(e, *prm, s);
@@ -418,7 +418,7 @@ int cesx_forward_lineal(cesx_handle h, const void* A, const void* b, const void*
     CESX_HIP(hipMemsetAsync(e.d_Wfwd, 0, (size_t)e.rpad * e.kp * e.esz, s));
     CESX_HIP(hipMemcpy2DAsync(e.d_Wfwd, (size_t)e.kp * e.esz, A, (size_t)e.p * e.esz, (size_t)e.p * e.esz, e.n,
                               hipMemcpyDeviceToDevice, s));
-    UpdateSrc src[1] = {{U, e.p, 0}};
+    UpdateSrc src[1] = {{U, e.p, 0, 0}};
     return launch_update(e, e.n, e.d_Wfwd, e.kp, b, src, 1, nullptr, nullptr, 0.0, nullptr, nullptr, 0.0, G,
                          nullptr, 0, false, s);
 }

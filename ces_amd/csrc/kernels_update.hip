@@ -53,6 +53,7 @@ struct UpdArgs {
     // data metrics (ces/calibrate.py:434-435 / :466-467) accumulated while the G rows stream by:
     // rowc[i] = {gbar_i, y_i, 1/Gamma_ii, 0}; metric_part[block] = {sum q_r^2, sum q_e^2}
     const T* rowc; double* metric_part; int metric_seg;
+    int tri_seg;      // K-segment whose W columns are lower triangular (sqrt(2hk) L), -1 if none
 };
 
 template <typename T, bool ALIGNED>
@@ -84,7 +85,15 @@ void update_kernel(const UpdArgs<T> a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long long jt0 = (long long)blockIdx.x * BN;
     const int rc0 = blockIdx.y * RC;
-    const int wrow0 = rc0 + wave * WR * TILE;
+    // Row blocks of this wave.  Blocks are dealt in mirrored pairs (w, 2*NW-1-w) so that every
+    // wave does the same amount of work in the lower-triangular noise segment, where block rb
+    // only needs the k-tiles with k <= its last row.
+    constexpr int NW = UPD_THREADS / 64;
+    int rbk[WR];
+#pragma unroll
+    for (int r = 0; r < WR; ++r)
+        rbk[r] = (r / 2) * 2 * NW + ((r & 1) ? 2 * NW - 1 - wave : wave);
+    if (WR == 1) rbk[0] = wave;
     const int nkt = a.ktot / BK;
 
     acc_t acc[WR][WC];
@@ -179,7 +188,10 @@ void update_kernel(const UpdArgs<T> a) {
     // skip row blocks that are entirely padding (small p)
     bool rb_on[WR];
 #pragma unroll
-    for (int r = 0; r < WR; ++r) rb_on[r] = (wrow0 + r * TILE) < a.out_rows;
+    for (int r = 0; r < WR; ++r) rb_on[r] = (rc0 + rbk[r] * TILE) < a.out_rows;
+    bool any_on = false;
+#pragma unroll
+    for (int r = 0; r < WR; ++r) any_on = any_on || rb_on[r];
 
     const int li = lane % TILE, lh = lane / TILE;
 
@@ -209,7 +221,21 @@ void update_kernel(const UpdArgs<T> a) {
                 }
             }
         }
-        if (rb_on[0]) {
+        // lower-triangular segment: a row block needs this k-tile only if its last row >= k0
+        bool need[WR];
+        {
+            const int k0 = kt * BK;
+            const int ts = a.tri_seg;
+            const int tend = ts >= 0 ? (ts + 1 < a.nsrc ? a.src_k0[ts + 1] : a.ktot) : 0;
+            const bool intri = ts >= 0 && k0 >= a.src_k0[ts] && k0 < tend;
+            const int k0l = intri ? k0 - a.src_k0[ts] : 0;
+#pragma unroll
+            for (int r = 0; r < WR; ++r) need[r] = rb_on[r] && (!intri || rc0 + rbk[r] * TILE + TILE - 1 >= k0l);
+        }
+        bool any_need = false;
+#pragma unroll
+        for (int r = 0; r < WR; ++r) any_need = any_need || need[r];
+        if (any_need) {
 #pragma unroll
             for (int g = 0; g < BK / GROUP; ++g) {
                 vec_t af[WR];
@@ -228,7 +254,7 @@ void update_kernel(const UpdArgs<T> a) {
 #pragma unroll
                     for (int r = 0; r < WR; ++r)
                         af[r] = *reinterpret_cast<const vec_t*>(
-                            &sW[cur][(wave * WR * TILE + r * TILE + li) * SW + g * GROUP + lh * VEC]);
+                            &sW[cur][(rbk[r] * TILE + li) * SW + g * GROUP + lh * VEC]);
 #pragma unroll
                     for (int c = 0; c < WC; ++c)
 #pragma unroll
@@ -237,7 +263,7 @@ void update_kernel(const UpdArgs<T> a) {
                 }
 #pragma unroll
                 for (int r = 0; r < WR; ++r) {
-                    if (rb_on[r]) {
+                    if (need[r]) {
 #pragma unroll
                         for (int c = 0; c < WC; ++c)
 #pragma unroll
@@ -259,7 +285,7 @@ void update_kernel(const UpdArgs<T> a) {
     for (int r = 0; r < WR; ++r) {
 #pragma unroll
         for (int e = 0; e < M::NACC; ++e) {
-            const int i = wrow0 + r * TILE + M::crow(lane, e);
+            const int i = rc0 + rbk[r] * TILE + M::crow(lane, e);
             if (i < a.out_rows) {
                 const T bi = a.bias ? a.bias[i] : (T)0;
 #pragma unroll
@@ -270,7 +296,7 @@ void update_kernel(const UpdArgs<T> a) {
                         const size_t o = (size_t)i * a.J + j;
                         if (a.add1) v += (T)c1 * a.add1[o];
                         if (a.add2) v += (T)c2 * a.add2[o];
-                        a.out[o] = v;
+                        if (!(UPD_ABL & 8) || v == (T)123456.789) a.out[o] = v;
                         const T av = v < 0 ? -v : v;
                         amax = av > amax ? av : amax;
                     }
@@ -382,6 +408,9 @@ static int update_t(Engine& e, int out_rows, const void* W, int ktot, const void
     a.rowc = (const T*)e.d_rowc;
     a.metric_part = metrics ? e.d_metric_part : nullptr;
     a.metric_seg = 1;                    // [U; G; ...]: G is segment 1
+    a.tri_seg = -1;
+    for (int i = 0; i < nsrc; ++i)
+        if (src[i].tri) a.tri_seg = i;
     a.seed_lo = (unsigned)e.cfg.seed; a.seed_hi = (unsigned)(e.cfg.seed >> 32); a.step = (unsigned)step_index;
     dim3 grid((unsigned)((e.J + BN - 1) / BN), (unsigned)((out_rows + RC - 1) / RC));
     const int lds = 2 * (RC * C::STRIDE_W + BK * (BN + C::XPAD)) * (int)sizeof(T) + 64 + e.kn * 4 * (int)sizeof(T);

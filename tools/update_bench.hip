@@ -20,7 +20,8 @@ int main(int argc, char** argv) {
     a.src[0] = U; a.src[1] = G; a.src[2] = nullptr; a.src_rows[0] = p; a.src_rows[1] = n; a.src_rows[2] = p;
     a.src_k0[0] = 0; a.src_k0[1] = kp; a.src_k0[2] = kp + kn; a.src_kind[0] = 0; a.src_kind[1] = 0; a.src_kind[2] = argc > 1 ? 0 : 1;
     if (argc > 1) a.src[2] = U;
-    a.nsrc = 3; a.J = J; a.j_offset = 0; a.out = out; a.rowc = rowc; a.metric_part = argc > 2 ? nullptr : mpart; a.metric_seg = 1;
+    if (argc > 3) { a.ktot = 1536; a.src_rows[0] = a.src_rows[1] = a.src_rows[2] = 512; a.src_k0[1] = 512; a.src_k0[2] = 1024; hipFree(W); hipMalloc(&W, rpad * 1536 * 4); hipMemset(W, 0, rpad * 1536 * 4); a.W = W; }
+    a.nsrc = 3; a.J = J; a.j_offset = 0; a.out = out; a.rowc = rowc; a.metric_part = argc > 2 ? nullptr : mpart; a.metric_seg = 1; a.tri_seg = argc > 4 ? -1 : 2;
     a.seed_lo = 1; a.seed_hi = 2; a.step = 3;
     using C = UpdCfg<float>;
     constexpr int RC = 4 * C::WR * 32, BN = C::WC * 32;
@@ -35,6 +36,6 @@ int main(int argc, char** argv) {
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("ABL=%d xi=%s metrics=%s: %.1f us/launch  (%.1f TF algorithmic)\n", UPD_ABL, argc > 1 ? "mem" : "philox", argc > 2 ? "off" : "on",
-           ms * 100.0, 2.0 * p * ktot * J / (ms * 1e-4) / 1e12);
+           ms * 100.0, 2.0 * p * a.ktot * J / (ms * 1e-4) / 1e12);
     return 0;
 }
