@@ -168,8 +168,10 @@ def main():
     # algorithmic flops per launch: symmetric-aware Gram of the stacked
     # anomaly (p+n)^2 per particle; fused update GEMM 2 p (2p+n) per particle
     kern = {
-        "gram_kernel(K1)": dict(ms=gram_ms / max(gram_cnt, 1), flops=float(p + n) ** 2 * J),
-        "update_kernel(K3)": dict(ms=upd_ms / max(upd_cnt, 1), flops=2.0 * p * (2 * p + n) * J),
+        # per step: K1 is one launch; K3 is one launch, or two (drift part beside the Cholesky,
+        # then the noise part) -- their durations are summed
+        "gram_kernel(K1)": dict(ms=gram_ms / args.steps, flops=float(p + n) ** 2 * J, launches=gram_cnt / args.steps),
+        "update_kernel(K3)": dict(ms=upd_ms / args.steps, flops=2.0 * p * (2 * p + n) * J, launches=upd_cnt / args.steps),
     }
     for k in kern.values():
         k["tflops"] = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
@@ -185,8 +187,9 @@ def main():
     roofline = dict(bound="mfma", kernel=dom, achieved=round(kern[dom]["tflops"], 2), peak=peak,
                     unit="TFLOP/s", frac=round(kern[dom]["tflops"] / peak, 4), traffic=traffic,
                     avg_launch_ms=round(kern[dom]["ms"], 4),
-                    kernels={k: dict(avg_launch_ms=round(v["ms"], 4), tflops=round(v["tflops"], 2),
-                                     frac=round(v["tflops"] / peak, 4)) for k, v in kern.items()},
+                    kernels={k: dict(avg_launch_ms=round(v["ms"], 4), launches_per_step=v["launches"],
+                                     tflops=round(v["tflops"], 2), frac=round(v["tflops"] / peak, 4))
+                             for k, v in kern.items()},
                     step_flops_frac=round(sum(v["flops"] for v in kern.values()) /
                                           (elapsed / args.steps) / 1e12 / peak, 4))
     rec = dict(metric="EKS particle-updates/sec", value=Jg * args.steps / elapsed, unit="particle-updates/s",

@@ -134,6 +134,9 @@ struct Engine {
     cesx_config cfg{};
     std::string err;
     bool problem_set = false, shift_valid = false;
+    bool overlap_chol = false;     // ALDI: run chol(C) on the side stream beside the drift part of K3 (CESX_OVERLAP=1).
+                                   // Measured at C2: hides the 141 us Cholesky but the split update costs +115 us
+                                   // (narrow tiles, un-hidden Philox in the noise pass): no net gain, so off by default
     int p = 0, n = 0, P = 0;
     int64_t J = 0, Jg = 0;
     size_t esz = 4;               // sizeof(T)
@@ -201,7 +204,9 @@ struct Engine {
     Scalars* h_scal = nullptr;           // pinned, device-mapped: the GPU writes results straight into it
     Scalars* h_scal_dev = nullptr;       // device address of h_scal
     unsigned long long seq = 0;
-    hipEvent_t ev = nullptr;
+    hipEvent_t ev = nullptr, ev_a = nullptr, ev_b = nullptr;
+    hipStream_t side = nullptr;      // side stream: chol(C) runs beside the drift part of the update
+    int last_update_grid_x = 0, last_update_grid = 0, last_metric_parts = 0;
     bool pending = false;
     cesx_step_params last_prm{};
 };
@@ -220,13 +225,20 @@ int launch_colsum(Engine& e, const void* U, const void* G, double* sums, hipStre
 int launch_set_shift(Engine& e, const double* sums, hipStream_t s);
 int launch_gram(Engine& e, const void* U, const void* G, double* mom, hipStream_t s);
 int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int phase, hipStream_t s);
+int launch_assemble_noise(Engine& e, hipStream_t s);
+struct UpdateOpt {
+    int ldw = 0;          // row stride of W (0: = ktot)
+    bool narrow = false;  // narrow particle tile (more, shorter workgroups)
+    int metric_seg = 1;   // K-segment that holds G (data metrics)
+    int prof = -1;        // profiling slot (1 = K3) or -1
+};
 int launch_update(Engine& e, int out_rows, const void* W, int ktot, const void* bias,
                   const UpdateSrc* src, int nsrc,
                   const void* add1, const double* c1, double c1_imm,
                   const void* add2, const double* c2, double c2_imm,
-                  void* out, double* absmax_part, uint64_t step_index, bool metrics, hipStream_t s);
+                  void* out, double* absmax_part, uint64_t step_index, bool metrics,
+                  const UpdateOpt& opt, hipStream_t s);
 int update_grid_blocks(Engine& e, int out_rows);
-int update_grid_x(Engine& e);
 int launch_data_metrics(Engine& e, const void* G, hipStream_t s);   // dense Gamma: separate pass
 int launch_metric_final(Engine& e, const double* mom, hipStream_t s);
 int launch_publish(Engine& e, hipStream_t s);

@@ -3,6 +3,7 @@
 #include "cesx_internal.h"
 #include <cmath>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -103,8 +104,31 @@ int finish_step(Engine& e, const cesx_step_params& prm, hipStream_t s) {
 int run_update_main(Engine& e, const cesx_step_params& prm, const void* U, const void* G, const void* xi,
                     void* Unext, hipStream_t s) {
     UpdateSrc src[3] = {{U, e.p, 0, 0}, {G, e.n, 0, 0}, {xi, e.p, xi ? 0 : 1, 1}};
-    return launch_update(e, e.p, e.d_W, e.ktot, e.d_bias, src, 3, nullptr, nullptr, 0.0, nullptr, nullptr, 0.0,
-                         Unext, nullptr, prm.step_index, e.diag_gamma, s);
+    UpdateOpt opt;
+    opt.prof = 1;
+    int rc = launch_update(e, e.p, e.d_W, e.ktot, e.d_bias, src, 3, nullptr, nullptr, 0.0, nullptr, nullptr, 0.0,
+                           Unext, nullptr, prm.step_index, e.diag_gamma, opt, s);
+    e.last_metric_parts = e.last_update_grid_x;
+    return rc;
+}
+
+// ALDI with the Cholesky overlapped: drift part W_UG [U; G] + b (K3a, beside chol(C) on the side
+// stream), then U_next += sqrt(2 hk) L xi (K3b)
+int run_update_split(Engine& e, const cesx_step_params& prm, const void* U, const void* G, const void* xi,
+                     void* Unext, hipStream_t s) {
+    UpdateSrc src_a[2] = {{U, e.p, 0, 0}, {G, e.n, 0, 0}};
+    UpdateOpt oa;
+    oa.ldw = e.ktot; oa.narrow = true; oa.prof = 1;
+    TRY(launch_update(e, e.p, e.d_W, e.kp + e.kn, e.d_bias, src_a, 2, nullptr, nullptr, 0.0, nullptr, nullptr, 0.0,
+                      Unext, nullptr, prm.step_index, e.diag_gamma, oa, s));
+    e.last_metric_parts = e.last_update_grid_x;
+    TRY(launch_assemble_noise(e, s));
+    UpdateSrc src_b[1] = {{xi, e.p, xi ? 0 : 1, 1}};
+    UpdateOpt ob;
+    ob.ldw = e.ktot; ob.narrow = true; ob.prof = 1;
+    const char* Wn = (const char*)e.d_W + (size_t)(e.kp + e.kn) * e.esz;
+    return launch_update(e, e.p, Wn, e.kp, nullptr, src_b, 1, Unext, nullptr, 1.0, nullptr, nullptr, 0.0,
+                         Unext, nullptr, prm.step_index, false, ob, s);
 }
 
 // data metrics: K3 accumulated them (diagonal Gamma) or a separate pass does (dense Gamma)
@@ -139,6 +163,7 @@ int cesx_create(const cesx_config* cfg, cesx_handle* out) {
     e.p = cfg->p; e.n = cfg->n_obs; e.P = e.p + e.n;
     e.J = cfg->J_local; e.Jg = cfg->J_global;
     e.esz = cfg->dtype == CESX_F32 ? 4 : 8;
+    if (const char* ov = std::getenv("CESX_OVERLAP")) e.overlap_chol = ov[0] != '0';
     auto fail = [&](int rc) { g_create_err = e.err; cesx_destroy(reinterpret_cast<cesx_handle>(ep)); return rc; };
     int rc;
     if ((rc = set_device(e))) return fail(rc);
@@ -204,7 +229,10 @@ int cesx_create(const cesx_config* cfg, cesx_handle* out) {
 #undef DM
     if (hipHostMalloc(reinterpret_cast<void**>(&e.h_scal), sizeof(Scalars), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void**>(&e.h_scal_dev), e.h_scal, 0) != hipSuccess ||
-        hipEventCreateWithFlags(&e.ev, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&e.ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e.ev_a, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e.ev_b, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking) != hipSuccess) {
         e.err = "pinned host buffer / event creation failed";
         return fail(CESX_EHIP);
     }
@@ -232,6 +260,9 @@ void cesx_destroy(cesx_handle h) {
     for (auto ev : e.prof_pool) (void)hipEventDestroy(ev);
     if (e.h_scal) (void)hipHostFree(e.h_scal);
     if (e.ev) (void)hipEventDestroy(e.ev);
+    if (e.ev_a) (void)hipEventDestroy(e.ev_a);
+    if (e.ev_b) (void)hipEventDestroy(e.ev_b);
+    if (e.side) (void)hipStreamDestroy(e.side);
     delete &e;
 }
 
@@ -309,10 +340,13 @@ int cesx_apply_drift(cesx_handle h, const cesx_step_params* prm, const double* m
     hipStream_t s = (hipStream_t)stream;
     TRY(launch_dense(e, *prm, mom, 1, s));
     UpdateSrc src[2] = {{U, e.p, 0, 0}, {G, e.n, 0, 0}};
+    UpdateOpt opt;
     TRY(launch_update(e, e.p, e.d_W, e.kp + e.kn, e.d_bias, src, 2, nullptr, nullptr, 0.0, nullptr, nullptr, 0.0,
-                      Unext, e.d_absmax_part, prm->step_index, e.diag_gamma, s));
+                      Unext, e.d_absmax_part, prm->step_index, e.diag_gamma, opt, s));
+    e.last_metric_parts = e.last_update_grid_x;
+    const int nparts = e.last_update_grid;
     TRY(finish_metrics(e, mom, G, s));
-    return launch_absmax_final(e, update_grid_blocks(e, e.p), absmax, s);
+    return launch_absmax_final(e, nparts, absmax, s);
 }
 
 int cesx_apply_finish(cesx_handle h, const cesx_step_params* prm, const double* absmax, const void* U,
@@ -327,8 +361,9 @@ int cesx_apply_finish(cesx_handle h, const cesx_step_params* prm, const double* 
     TRY(launch_dense(e, *prm, nullptr, 2, s));
     // U_next = sqrt(2hk) L xi + 1 * U + hk * drift   (drift currently lives in U_next)
     UpdateSrc src[1] = {{xi, e.p, xi ? 0 : 1, 1}};
+    UpdateOpt opt;
     TRY(launch_update(e, e.p, e.d_W, e.kp, nullptr, src, 1, U, nullptr, 1.0, Unext, &e.d_scal->hk, 1.0, Unext,
-                      nullptr, prm->step_index, false, s));
+                      nullptr, prm->step_index, false, opt, s));
     return finish_step(e, *prm, s);
 }
 
@@ -345,8 +380,13 @@ int cesx_apply(cesx_handle h, const cesx_step_params* prm, const double* mom, co
     }
     TRY(set_device(e));
     hipStream_t s = (hipStream_t)stream;
-    TRY(launch_dense(e, *prm, mom, 0, s));
-    TRY(run_update_main(e, *prm, U, G, xi, Unext, s));
+    if (prm->update == CESX_UPDATE_ALDI && e.overlap_chol) {
+        TRY(launch_dense(e, *prm, mom, 3, s));
+        TRY(run_update_split(e, *prm, U, G, xi, Unext, s));
+    } else {
+        TRY(launch_dense(e, *prm, mom, 0, s));
+        TRY(run_update_main(e, *prm, U, G, xi, Unext, s));
+    }
     TRY(finish_metrics(e, mom, G, s));
     return finish_step(e, *prm, s);
 }
@@ -419,8 +459,9 @@ int cesx_forward_lineal(cesx_handle h, const void* A, const void* b, const void*
     CESX_HIP(hipMemcpy2DAsync(e.d_Wfwd, (size_t)e.kp * e.esz, A, (size_t)e.p * e.esz, (size_t)e.p * e.esz, e.n,
                               hipMemcpyDeviceToDevice, s));
     UpdateSrc src[1] = {{U, e.p, 0, 0}};
+    UpdateOpt opt;
     return launch_update(e, e.n, e.d_Wfwd, e.kp, b, src, 1, nullptr, nullptr, 0.0, nullptr, nullptr, 0.0, G,
-                         nullptr, 0, false, s);
+                         nullptr, 0, false, opt, s);
 }
 
 int cesx_profile_enable(cesx_handle h, int on) {

@@ -678,7 +678,7 @@ __global__ void constant_hk_kernel(cesx_step_params prm, const double* __restric
 // and the next centring shift (predicted mean for ALDI, current mean otherwise).
 // ---------------------------------------------------------------------------
 template <typename T>
-__global__ void assemble_kernel(int mode, int p, int n, int kp, int kn, int rpad, int ktot, double sw,
+__global__ void assemble_kernel(int mode, int part, int p, int n, int kp, int kn, int rpad, int ktot, double sw,
                                 const Scalars* __restrict__ sc, const double* __restrict__ M,
                                 const double* __restrict__ K, const double* __restrict__ L, int ldl,
                                 const double* __restrict__ P, const double* __restrict__ PK,
@@ -694,8 +694,12 @@ __global__ void assemble_kernel(int mode, int p, int n, int kp, int kn, int rpad
     const double* Mm = mvs + 2 * mx;   // M mu
     const double* Mu = mvs + 3 * mx;   // M ubar
     const double* Pv = mvs + 4 * mx;   // P (hk (Ky + M mu))
+    // part 0: everything; 1: all but the noise columns (they wait for the Cholesky on the side
+    // stream); 2: only the noise columns
     if (idx < (long long)rpad * ktot) {
         const int i = (int)(idx / ktot), k = (int)(idx % ktot);
+        const bool noise_col = mode != 3 && k >= kp + kn;
+        if ((part == 1 && noise_col) || (part == 2 && !noise_col)) return;
         double v = 0.0;
         if (i < p) {
             if (mode == 3) {
@@ -720,6 +724,7 @@ __global__ void assemble_kernel(int mode, int p, int n, int kp, int kn, int rpad
         }
         W[idx] = (T)v;
     }
+    if (part == 2) return;
     if (idx < rpad) {
         const int i = (int)idx;
         double b = 0.0;
@@ -818,10 +823,10 @@ static int spd_inverse(Engine& e, hipStream_t s, int n, const double* A, double*
 }
 
 template <typename T>
-static int assemble(Engine& e, hipStream_t s, int mode, int ktot, double sw) {
+static int assemble(Engine& e, hipStream_t s, int mode, int ktot, double sw, int part = 0) {
     const int mx = e.p > e.n ? e.p : e.n;
     const long long len = (long long)e.rpad * ktot;
-    hipLaunchKernelGGL(assemble_kernel<T>, g1(len), dim3(256), 0, s, mode, e.p, e.n, e.kp, e.kn, e.rpad, ktot,
+    hipLaunchKernelGGL(assemble_kernel<T>, g1(len), dim3(256), 0, s, mode, part, e.p, e.n, e.kp, e.kn, e.rpad, ktot,
                        sw, e.d_scal, e.d_M, e.d_K, e.d_L, potrf_ld(e.p), e.d_P, e.d_PK, e.d_mv, mx, e.d_ubar, e.d_gbar,
                        e.d_y, e.diag_gamma ? e.d_gw : (const double*)nullptr, (T*)e.d_W, (T*)e.d_bias,
                        (T*)e.d_shiftT, e.d_shift64, (T*)e.d_rowc, (T*)e.d_gbarT);
@@ -847,9 +852,14 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
                        e.diag_sigma ? e.d_sw : (const double*)nullptr, unbiased, e.d_ubar, e.d_gbar, e.d_m,
                        e.d_dg, e.d_C, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_M, e.d_part, e.d_scal);
     CESX_HIP(hipGetLastError());
-    // (a side stream for the Cholesky was measured: the two cross-stream event waits cost
-    //  ~20 us, more than the ~5 us of K2 work it could overlap)
-    if ((rc = potrf(e, s, p, e.d_C, e.d_L))) return rc;
+    if (phase == 3) {
+        // ALDI overlap: chol(C) runs on the side stream beside the drift part of the update
+        // (K3a); only the noise columns of W wait for it (launch_assemble_noise)
+        CESX_HIP(hipEventRecord(e.ev_a, s));
+        CESX_HIP(hipStreamWaitEvent(e.side, e.ev_a, 0));
+        if ((rc = potrf(e, e.side, p, e.d_C, e.d_L))) return rc;
+        CESX_HIP(hipEventRecord(e.ev_b, e.side));
+    } else if ((rc = potrf(e, s, p, e.d_C, e.d_L))) return rc;
     if (!e.diag_gamma) {
         // Frobenius term <Ginv Srr Ginv, See>, and K = C_ug Ginv
         if ((rc = gemm(e, s, n, n, n, 1.0, e.d_Ginv, n, 1, e.d_Srr, n, 1, e.d_t1))) return rc;
@@ -882,7 +892,7 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
     scalars_and_matvecs();
     CESX_HIP(hipGetLastError());
 
-    if (phase == 0 && (prm.time_step == CESX_TS_CONSTANT || (prm.time_step == CESX_TS_MIX && prm.update == CESX_UPDATE_ALDI))) {
+    if ((phase == 0 || phase == 3) && (prm.time_step == CESX_TS_CONSTANT || (prm.time_step == CESX_TS_MIX && prm.update == CESX_UPDATE_ALDI))) {
         // K' = C_ug (hk C_gg + Gamma)^{-1},  C_gg = See / N   (:440-441, :472-473)
         hipLaunchKernelGGL(axpb_kernel, g1((long long)n * n), dim3(256), 0, s, (long long)n * n, &e.d_scal->hk,
                            mom, e.d_See, e.d_Gamma, e.d_t3);
@@ -910,8 +920,16 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
         hipLaunchKernelGGL(matvec_kernel, g1(p, 4), dim3(DT), 0, s, p, p, e.d_P, e.d_mv + 5 * mx, e.d_mv + 4 * mx);
         CESX_HIP(hipGetLastError());
     }
+    if (phase == 3)
+        return f32 ? assemble<float>(e, s, 0, e.ktot, prm.switch_mult, 1) : assemble<double>(e, s, 0, e.ktot, prm.switch_mult, 1);
     const int ktot = mode == 2 ? e.kp + e.kn : e.ktot;
     return f32 ? assemble<float>(e, s, mode, ktot, prm.switch_mult) : assemble<double>(e, s, mode, ktot, prm.switch_mult);
+}
+
+// second half of the overlapped ALDI K2: the sqrt(2 hk) L columns of W, after the side-stream Cholesky
+int launch_assemble_noise(Engine& e, hipStream_t s) {
+    CESX_HIP(hipStreamWaitEvent(s, e.ev_b, 0));
+    return e.cfg.dtype == CESX_F32 ? assemble<float>(e, s, 0, e.ktot, 0.0, 2) : assemble<double>(e, s, 0, e.ktot, 0.0, 2);
 }
 
 }  // namespace cesx

@@ -221,7 +221,7 @@ int launch_publish(Engine& e, hipStream_t s) {
 }
 
 int launch_metric_final(Engine& e, const double* mom, hipStream_t s) {
-    const int nparts = e.diag_gamma ? update_grid_x(e) : (int)((e.J + 63) / 64);
+    const int nparts = e.diag_gamma ? e.last_metric_parts : (int)((e.J + 63) / 64);
     hipLaunchKernelGGL(metric_final_kernel, dim3(1), dim3(ST_THREADS), 0, s, e.d_metric_part, nparts, mom,
                        e.mom_len - 2, e.d_metric_sums, e.d_scal);
     CESX_HIP(hipGetLastError());

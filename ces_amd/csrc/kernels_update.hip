@@ -42,7 +42,7 @@ template <> struct UpdCfg<double> {
 
 template <typename T>
 struct UpdArgs {
-    const T* W; int ktot; const T* bias; int out_rows;
+    const T* W; int ktot; int ldw; const T* bias; int out_rows;   // W: out_rows x ktot window of a row-major matrix with row stride ldw
     const T* src[3]; int src_rows[3]; int src_k0[3]; int src_kind[3]; int nsrc;
     long long J, j_offset;
     T* out;
@@ -56,14 +56,14 @@ struct UpdArgs {
     int tri_seg;      // K-segment whose W columns are lower triangular (sqrt(2hk) L), -1 if none
 };
 
-template <typename T, bool ALIGNED>
+template <typename T, bool ALIGNED, int WCT>
 __global__ __launch_bounds__(UPD_THREADS, sizeof(T) == 4 ? 2 : 1)
 void update_kernel(const UpdArgs<T> a) {
     using M = Mfma<T>;
     using vec_t = typename M::vec_t;
     using acc_t = typename M::acc_t;
     using C = UpdCfg<T>;
-    constexpr int TILE = M::TILE, VEC = M::VEC, WR = C::WR, WC = C::WC;
+    constexpr int TILE = M::TILE, VEC = M::VEC, WR = C::WR, WC = WCT;   // WCT blocks of particles per wave
     constexpr int RC = 4 * WR * TILE;                 // output rows per workgroup (256)
     constexpr int BN = WC * TILE;                     // particles per workgroup
     constexpr int SW = C::STRIDE_W, SX = BN + C::XPAD;
@@ -121,7 +121,7 @@ void update_kernel(const UpdArgs<T> a) {
         for (int i = 0; i < WCH; ++i) {
             const int c = tid + UPD_THREADS * i;
             const int row = c / WPR, part = c % WPR;
-            wst[i] = *reinterpret_cast<const vec_t*>(a.W + (size_t)(rc0 + row) * a.ktot + k0 + part * VEC);
+            wst[i] = *reinterpret_cast<const vec_t*>(a.W + (size_t)(rc0 + row) * a.ldw + k0 + part * VEC);
         }
         // which K-segment does this tile belong to?
         int s = 0;
@@ -376,17 +376,38 @@ __global__ void noise_kernel(T* __restrict__ xi, int p, long long J, long long j
 }
 
 // ---------------------------------------------------------------------------
+// opt.ldw    row stride of W (0: = ktot)
+// opt.narrow use the narrow particle tile (f32: 64 instead of 128 particles per workgroup):
+//            twice as many, shorter workgroups, so that a launch running beside the
+//            single-workgroup Cholesky still load-balances over the CUs
+template <typename T, int WCT>
+static int update_launch(Engine& e, UpdArgs<T>& a, bool aligned, int out_rows, int prof_which, hipStream_t s) {
+    using C = UpdCfg<T>;
+    constexpr int RC = 4 * C::WR * Mfma<T>::TILE, BN = WCT * Mfma<T>::TILE;
+    dim3 grid((unsigned)((e.J + BN - 1) / BN), (unsigned)((out_rows + RC - 1) / RC));
+    const int lds = 2 * (RC * C::STRIDE_W + BK * (BN + C::XPAD)) * (int)sizeof(T) + 64 + e.kn * 4 * (int)sizeof(T);
+    auto kern = aligned ? update_kernel<T, true, WCT> : update_kernel<T, false, WCT>;
+    CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    e.last_update_grid_x = (int)grid.x;
+    e.last_update_grid = (int)(grid.x * grid.y);
+    {
+        ProfScope prof(e, prof_which, s);
+        hipLaunchKernelGGL(kern, grid, dim3(UPD_THREADS), lds, s, a);
+    }
+    CESX_HIP(hipGetLastError());
+    return CESX_OK;
+}
+
 template <typename T>
 static int update_t(Engine& e, int out_rows, const void* W, int ktot, const void* bias,
                     const UpdateSrc* src, int nsrc, const void* add1, const double* c1, double c1_imm,
                     const void* add2, const double* c2, double c2_imm, void* out, double* absmax_part,
-                    uint64_t step_index, bool metrics, hipStream_t s) {
-    using C = UpdCfg<T>;
-    constexpr int RC = 4 * C::WR * Mfma<T>::TILE, BN = C::WC * Mfma<T>::TILE;
+                    uint64_t step_index, bool metrics, const UpdateOpt& opt, hipStream_t s) {
     UpdArgs<T> a{};
-    a.W = (const T*)W; a.ktot = ktot; a.bias = (const T*)bias; a.out_rows = out_rows;
+    a.W = (const T*)W; a.ktot = ktot; a.ldw = opt.ldw ? opt.ldw : ktot; a.bias = (const T*)bias; a.out_rows = out_rows;
     int k0 = 0;
-    bool aligned = (e.J % Mfma<T>::VEC == 0);
+    bool aligned = (e.J % Mfma<T>::VEC == 0) && ((uintptr_t)W % 16 == 0) && (a.ldw % Mfma<T>::VEC == 0);
     for (int i = 0; i < 3; ++i) {
         a.src[i] = nullptr; a.src_rows[i] = 0; a.src_k0[i] = 0x7fffffff; a.src_kind[i] = 0;
     }
@@ -407,45 +428,29 @@ static int update_t(Engine& e, int out_rows, const void* W, int ktot, const void
     a.absmax_part = absmax_part;
     a.rowc = (const T*)e.d_rowc;
     a.metric_part = metrics ? e.d_metric_part : nullptr;
-    a.metric_seg = 1;                    // [U; G; ...]: G is segment 1
+    a.metric_seg = opt.metric_seg;
     a.tri_seg = -1;
     for (int i = 0; i < nsrc; ++i)
         if (src[i].tri) a.tri_seg = i;
     a.seed_lo = (unsigned)e.cfg.seed; a.seed_hi = (unsigned)(e.cfg.seed >> 32); a.step = (unsigned)step_index;
-    dim3 grid((unsigned)((e.J + BN - 1) / BN), (unsigned)((out_rows + RC - 1) / RC));
-    const int lds = 2 * (RC * C::STRIDE_W + BK * (BN + C::XPAD)) * (int)sizeof(T) + 64 + e.kn * 4 * (int)sizeof(T);
-    auto kern = aligned ? update_kernel<T, true> : update_kernel<T, false>;
-    CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    {
-        ProfScope prof(e, nsrc == 3 ? 1 : -1, s);   // only the full [U; G; xi] update is K3
-        hipLaunchKernelGGL(kern, grid, dim3(UPD_THREADS), lds, s, a);
-    }
-    CESX_HIP(hipGetLastError());
-    return CESX_OK;
+    if (opt.narrow && sizeof(T) == 4) return update_launch<T, UpdCfg<T>::WC / 2>(e, a, aligned, out_rows, opt.prof, s);
+    return update_launch<T, UpdCfg<T>::WC>(e, a, aligned, out_rows, opt.prof, s);
 }
 
 int launch_update(Engine& e, int out_rows, const void* W, int ktot, const void* bias,
                   const UpdateSrc* src, int nsrc, const void* add1, const double* c1, double c1_imm,
                   const void* add2, const double* c2, double c2_imm, void* out, double* absmax_part,
-                  uint64_t step_index, bool metrics, hipStream_t s) {
+                  uint64_t step_index, bool metrics, const UpdateOpt& opt, hipStream_t s) {
     return e.cfg.dtype == CESX_F32
-        ? update_t<float>(e, out_rows, W, ktot, bias, src, nsrc, add1, c1, c1_imm, add2, c2, c2_imm, out, absmax_part, step_index, metrics, s)
-        : update_t<double>(e, out_rows, W, ktot, bias, src, nsrc, add1, c1, c1_imm, add2, c2, c2_imm, out, absmax_part, step_index, metrics, s);
+        ? update_t<float>(e, out_rows, W, ktot, bias, src, nsrc, add1, c1, c1_imm, add2, c2, c2_imm, out, absmax_part, step_index, metrics, opt, s)
+        : update_t<double>(e, out_rows, W, ktot, bias, src, nsrc, add1, c1, c1_imm, add2, c2, c2_imm, out, absmax_part, step_index, metrics, opt, s);
 }
 
-int update_grid_x(Engine& e) {
-    const int BN = e.cfg.dtype == CESX_F32 ? UpdCfg<float>::WC * 32 : UpdCfg<double>::WC * 16;
-    return (int)((e.J + BN - 1) / BN);
-}
-
+// upper bound of the number of workgroups of any update launch (sizes the partial-result buffers)
 int update_grid_blocks(Engine& e, int out_rows) {
-    if (e.cfg.dtype == CESX_F32) {
-        constexpr int RC = 4 * UpdCfg<float>::WR * 32, BN = UpdCfg<float>::WC * 32;
-        return (int)((e.J + BN - 1) / BN) * ((out_rows + RC - 1) / RC);
-    }
-    constexpr int RC = 4 * UpdCfg<double>::WR * 16, BN = UpdCfg<double>::WC * 16;
-    return (int)((e.J + BN - 1) / BN) * ((out_rows + RC - 1) / RC);
+    const int bn = e.cfg.dtype == CESX_F32 ? UpdCfg<float>::WC * 32 / 2 : UpdCfg<double>::WC * 16;
+    const int rc = 256;
+    return (int)((e.J + bn - 1) / bn) * ((out_rows + rc - 1) / rc);
 }
 
 int launch_absmax_final(Engine& e, int nparts, double* absmax_out, hipStream_t s) {

@@ -16,18 +16,18 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < hw.size(); ++i) hw[i] = (float)((i * 40503u) % 1001) / 5000.f - 0.1f;
     hipMemcpy(W, hw.data(), hw.size() * 4, hipMemcpyHostToDevice); hipMemset(bias, 0, rpad * 4); hipMemset(rowc, 0, kn * 16);
     UpdArgs<float> a{};
-    a.W = W; a.ktot = ktot; a.bias = bias; a.out_rows = p;
+    a.W = W; a.ktot = ktot; a.ldw = ktot; a.bias = bias; a.out_rows = p;
     a.src[0] = U; a.src[1] = G; a.src[2] = nullptr; a.src_rows[0] = p; a.src_rows[1] = n; a.src_rows[2] = p;
     a.src_k0[0] = 0; a.src_k0[1] = kp; a.src_k0[2] = kp + kn; a.src_kind[0] = 0; a.src_kind[1] = 0; a.src_kind[2] = argc > 1 ? 0 : 1;
     if (argc > 1) a.src[2] = U;
-    if (argc > 3) { a.ktot = 1536; a.src_rows[0] = a.src_rows[1] = a.src_rows[2] = 512; a.src_k0[1] = 512; a.src_k0[2] = 1024; hipFree(W); hipMalloc(&W, rpad * 1536 * 4); hipMemset(W, 0, rpad * 1536 * 4); a.W = W; }
+    if (argc > 3) { a.ktot = 1536; a.ldw = 1536; a.src_rows[0] = a.src_rows[1] = a.src_rows[2] = 512; a.src_k0[1] = 512; a.src_k0[2] = 1024; hipFree(W); hipMalloc(&W, rpad * 1536 * 4); hipMemset(W, 0, rpad * 1536 * 4); a.W = W; }
     a.nsrc = 3; a.J = J; a.j_offset = 0; a.out = out; a.rowc = rowc; a.metric_part = argc > 2 ? nullptr : mpart; a.metric_seg = 1; a.tri_seg = argc > 4 ? -1 : 2;
     a.seed_lo = 1; a.seed_hi = 2; a.step = 3;
     using C = UpdCfg<float>;
     constexpr int RC = 4 * C::WR * 32, BN = C::WC * 32;
     dim3 grid((unsigned)((J + BN - 1) / BN), 1);
     const int lds = 2 * (RC * C::STRIDE_W + BK * (BN + C::XPAD)) * 4 + 64 + kn * 16;
-    auto kern = update_kernel<float, true>;
+    auto kern = update_kernel<float, true, UpdCfg<float>::WC>;
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, grid, dim3(UPD_THREADS), lds, 0, a);
