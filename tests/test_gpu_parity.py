@@ -253,3 +253,90 @@ def test_forward_lineal_hook(eng_mod):
         eng = eng_mod.Engine(p, n, J, dtype=dtype)
         G = lineal(A, b=b).forward_device(eng, eng.to_device(U)).cpu().numpy()
         assert rel_err(G, A @ U + b[:, None]) < tol
+
+
+def test_c4_darcy_drop_in(eng_mod):
+    """BASELINE.json configs[3] shape: Darcy forward map on the host (ces_amd/darcy.py,
+    model_trunc(p=64), 50 observations) + ensemble update on the GPU, driven exactly like
+    examples/scripts/darcy-flow.py:43-93; every step is checked against the literal oracle."""
+    from ces_amd.calibrate import sampling
+    from ces_amd import darcy
+    from oracle import ces_numpy as oc
+    full = darcy.model(); full.set_initial(); full.n_obs = 50
+    Ufull = full(full.ustar, full_solution=True)
+    np.random.seed(1)
+    obs_index = np.random.choice(int(full.p), 50, replace=False, p=Ufull / Ufull.sum())
+    model = darcy.model_trunc(p=64); model.set_initial(); model.n_obs = 50; model.obs_index = obs_index
+    gamma = 0.005
+    Gamma = gamma ** 2 * np.identity(50)
+    y_obs = model(model.ustar) + gamma * np.random.normal(0, 1, 50)
+    J = 192
+    eks = sampling(p=model.p, n_obs=model.n_obs, J=J)
+    eks.ustar = model.ustar.reshape(model.p, -1)
+    eks.T = 3
+    eks.mu = np.zeros((model.p, 1)); eks.sigma = 100. * np.identity(model.p)
+    np.random.seed(0)
+    U0 = 10 * np.random.normal(0, 1, [eks.p, J])
+    np.random.seed(5)
+    eks.run(y_obs, U0, model, Gamma, np.linalg.cholesky(Gamma), t_tol=5)
+    assert eks.Uall.shape == (4, 64, J) and eks.Gall.shape == (4, 50, J)
+    np.random.seed(5)
+    st = oc.OracleState(64, 50, J, eks.mu, eks.sigma, eks.ustar, T=3)
+    for i in range(3):
+        st.trace_len = i + 1
+        xi = np.random.normal(0, 1, [64, J])
+        ref = oc.literal_step(st, y_obs, eks.Uall[i], eks.Gall[i], Gamma, xi, update="aldi")
+        assert rel_err(eks.Uall[i + 1], ref) < TOL64
+    assert np.allclose(eks.metrics["t"], st.metrics["t"], rtol=1e-8)
+    assert np.allclose(eks.metrics["bias-data"], st.metrics["bias-data"], rtol=1e-7)
+
+
+def test_save_load_round_trip(eng_mod, tmp_path):
+    """On-disk format of enka.save / enka.load (ces/calibrate.py:170-237): file names,
+    metrics pickle, path arrays, per-iteration online dumps."""
+    import os
+    from ces_amd.calibrate import sampling
+    from ces_amd.utils import lineal
+    rng = np.random.default_rng(4)
+    p, n, J = 3, 5, 30
+    A = rng.standard_normal((n, p))
+    model = lineal(A); model.l_window = 7                      # run(save_online=True) reads model.l_window (:376)
+    eks = sampling(p=p, n_obs=n, J=J); eks.T = 4
+    eks.ustar = np.ones((p, 1)); eks.mu = np.zeros((p, 1)); eks.sigma = 10.0 * np.eye(p)
+    eks.directory = str(tmp_path); eks.nexp = 3
+    y = A @ np.ones(p)
+    eks.run(y, rng.standard_normal((p, J)), model, 0.1 * np.eye(n), None, save_online=True, t_tol=1e9)
+    d = tmp_path / "ensembles" / "lineal-eks-007-0030-03"
+    assert sorted(os.listdir(d)) == ["Gensemble_000%d.npy" % i for i in range(4)] + \
+        ["ensemble_000%d.npy" % i for i in range(4)] + ["metrics.pkl"]
+    assert eks.online_path.endswith("/ensembles/lineal-0030-03/")
+    eks.save(path=str(tmp_path) + "/", file="final/", all=True)
+    assert sorted(os.listdir(tmp_path / "final")) == ["Gensemble.npy", "Gensemble_path.npy", "ensemble.npy",
+                                                      "ensemble_path.npy", "metrics.pkl"]
+    other = sampling(p=p, n_obs=n, J=J)
+    assert other.load(path=str(tmp_path) + "/", eks_dir="final/")
+    assert np.array_equal(other.Uall, eks.Uall) and other.metrics["t"] == eks.metrics["t"]
+    third = sampling(p=p, n_obs=n, J=1)
+    assert third.load(path=str(d) + "/", eks_dir="", ix_ensemble=True)
+    assert third.Uall.shape == (4, p, J) and third.J == J and np.array_equal(third.Ustar, eks.Uall[3])
+    # resume: a second run on the same object appends (ces/calibrate.py:307-310, SURVEY.md 3.1)
+    n_before = len(eks.metrics["t"])
+    eks.run(y, eks.Ustar, model, 0.1 * np.eye(n), None, t_tol=1e9)
+    assert len(eks.metrics["t"]) == n_before + 4 and eks.Uall.shape[0] == 10
+    assert eks.metrics["t"][n_before] > eks.metrics["t"][n_before - 1]      # pseudo-time keeps accumulating
+
+
+def test_overlapped_cholesky_path_matches(eng_mod, monkeypatch):
+    """CESX_OVERLAP=1: chol(C) on the side stream beside the drift half of the update."""
+    p, n, J = 96, 80, 5000
+    d = _synthetic(p, n, J, seed=12)
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("CESX_OVERLAP", flag)
+        eng = eng_mod.Engine(p, n, J, dtype="float32", seed=3)
+        eng.set_problem(d["y"], d["Gamma"], d["mu"], d["sigma"], d["ustar"])
+        out = eng.step(eng_mod.step_params(update="aldi", step_index=2), d["U0"], d["G"], xi=None)
+        res = eng.result()
+        outs.append((out.cpu().numpy(), res.hk, res.bias_data, res.self_bias_data))
+    assert rel_err(outs[1][0], outs[0][0]) < 1e-5
+    assert outs[1][1:] == pytest.approx(outs[0][1:], rel=1e-6)
