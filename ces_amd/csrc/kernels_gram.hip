@@ -19,11 +19,15 @@
 #include <algorithm>
 #include <cmath>
 #include <set>
+#include <type_traits>
 
 namespace cesx {
 
 constexpr int GRAM_THREADS = 1024;         // 16 waves = 4 per SIMD: the MFMA pipe always finds a ready wave
 constexpr int GRAM_WAVES = GRAM_THREADS / 64;
+#ifndef GRAM_ABL     // timing ablations of tools/gram_bench.hip (results are wrong when set)
+#define GRAM_ABL 0
+#endif
 constexpr int ROW_BYTES = 128;            // one staged row of a tile: 32 f32 / 16 f64
 constexpr int ROW_STRIDE = ROW_BYTES + 16;  // +16 B pad: conflict-free ds_read_b128 over 16 rows
 constexpr int MAX_STAGE_ROWS = 512;
@@ -132,19 +136,25 @@ void gram_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __re
             }
         }
     };
-    auto store_tile = [&](int buf) {
-        char* base = smem + buf * buf_bytes;
+    // chunk i of the staged tile: subtract the shift, accumulate the row sum, write to LDS
+    auto store_chunk = [&](int buf, auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int row = row0 + RPP * i;
+        if (i < nch && row < nrows) {
+            char* base = smem + buf * buf_bytes;
+            vec_t v = stage[i];
+            const T sh = rowshift[row];
 #pragma unroll
-        for (int i = 0; i < MAXCH; ++i) {
-            const int row = row0 + RPP * i;
-            if (i < nch && row < nrows) {
-                vec_t v = stage[i];
-                const T sh = rowshift[row];
-#pragma unroll
-                for (int c = 0; c < VEC; ++c) { v[c] -= sh; rs[i] += v[c]; }
-                *reinterpret_cast<vec_t*>(base + row * ROW_STRIDE + part * 16) = v;
-            }
+            for (int c = 0; c < VEC; ++c) { v[c] -= sh; rs[i] += v[c]; }
+            *reinterpret_cast<vec_t*>(base + row * ROW_STRIDE + part * 16) = v;
         }
+    };
+    auto store_tile = [&](int buf) {
+        store_chunk(buf, std::integral_constant<int, 0>{});
+        if constexpr (MAXCH > 1) store_chunk(buf, std::integral_constant<int, 1>{});
+        if constexpr (MAXCH > 2) store_chunk(buf, std::integral_constant<int, 2>{});
+        if constexpr (MAXCH > 3) store_chunk(buf, std::integral_constant<int, 3>{});
+        static_assert(MAXCH <= 4, "store_tile handles up to 4 chunks per thread");
     };
 
     const int laneoff = (lane % TILE) * ROW_STRIDE + (lane / TILE) * 16;
@@ -156,24 +166,45 @@ void gram_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __re
     __syncthreads();
     for (long long t = t0; t < t1; ++t) {
         const int cur = (int)((t - t0) & 1);
-        if (t + 1 < t1) load_tile(t + 1);
+        if (!(GRAM_ABL & 1) && t + 1 < t1) load_tile(t + 1);
         const char* base = smem + cur * buf_bytes + laneoff;
-#pragma unroll 1
-        for (int g = 0; g < NGROUP; ++g) {
+        // The staged chunks of tile t+1 are written to the other LDS buffer BETWEEN the MFMA
+        // groups of tile t instead of after them: with one workgroup per CU all 16 waves would
+        // otherwise leave the matrix pipe idle together while they store.
+        const bool stage_next = !(GRAM_ABL & 1) && t + 1 < t1;
+        auto compute_group = [&](int g) {
 #pragma unroll
             for (int b = 0; b < NBW; ++b) {
                 if (b < nb) {
-                    const vec_t a = *reinterpret_cast<const vec_t*>(
-                        base + (iab[b] & 0xff) * (TILE * ROW_STRIDE) + g * (GROUP * (int)sizeof(T)));
-                    const vec_t c = *reinterpret_cast<const vec_t*>(
-                        base + (iab[b] >> 8) * (TILE * ROW_STRIDE) + g * (GROUP * (int)sizeof(T)));
+                    vec_t a, c;
+                    if (GRAM_ABL & 4) {
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) { a[v] = (T)(lane + v + b); c[v] = (T)(lane - v + g); }
+                    } else {
+                        a = *reinterpret_cast<const vec_t*>(
+                            base + (iab[b] & 0xff) * (TILE * ROW_STRIDE) + g * (GROUP * (int)sizeof(T)));
+                        c = *reinterpret_cast<const vec_t*>(
+                            base + (iab[b] >> 8) * (TILE * ROW_STRIDE) + g * (GROUP * (int)sizeof(T)));
+                    }
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) acc[b] = M::mma(a[v], c[v], acc[b]);
                 }
             }
+            asm volatile("" ::: "memory");
+        };
+        constexpr int CPG = MAXCH / NGROUP;      // chunks stored after each group (f32: 1, f64: 2)
+        static_assert(MAXCH % NGROUP == 0 && CPG >= 1 && CPG <= 2, "chunk / group interleave");
+        compute_group(0);
+        if (stage_next) { store_chunk(cur ^ 1, std::integral_constant<int, 0>{}); if constexpr (CPG == 2) store_chunk(cur ^ 1, std::integral_constant<int, 1>{}); }
+        compute_group(1);
+        if (stage_next) { store_chunk(cur ^ 1, std::integral_constant<int, CPG>{}); if constexpr (CPG == 2) store_chunk(cur ^ 1, std::integral_constant<int, 3>{}); }
+        if constexpr (NGROUP == 4) {
+            compute_group(2);
+            if (stage_next) store_chunk(cur ^ 1, std::integral_constant<int, 2>{});
+            compute_group(3);
+            if (stage_next) store_chunk(cur ^ 1, std::integral_constant<int, 3>{});
         }
-        if (t + 1 < t1) store_tile(cur ^ 1);
-        __syncthreads();
+        if (!(GRAM_ABL & 2)) __syncthreads();
     }
 
     // shifted row sums of this slice (first moments): the 8 threads that share a row

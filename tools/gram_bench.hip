@@ -1,0 +1,34 @@
+// dev tool: time gram_kernel<float> alone (C2 shape) with ablation switches.
+#include "../ces_amd/csrc/kernels_gram.hip"
+#include <cstdio>
+#include <vector>
+int main(int argc, char** argv) {
+    using namespace cesx;
+    const int p = 256, n = 256, P = 512; const long long J = 65536;
+    GramPlan pl = make_gram_plan(P, 32, GramCfg<float>::NBW, MAX_STAGE_ROWS);
+    int nslices = 256 / pl.ntypes; nslices -= nslices % 8;
+    float *U, *G, *shift, *slabs; double* rsp; int *th, *rows, *wblk;
+    hipMalloc(&U, p * J * 4); hipMalloc(&G, n * J * 4); hipMalloc(&shift, P * 4);
+    hipMalloc(&slabs, (size_t)nslices * pl.nblocks * 1024 * 4); hipMalloc(&rsp, (size_t)nslices * P * 8);
+    std::vector<float> h((size_t)p * J);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) % 2001) / 1000.f - 1.f;
+    hipMemcpy(U, h.data(), h.size() * 4, hipMemcpyHostToDevice); hipMemcpy(G, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    hipMemset(shift, 0, P * 4);
+    hipMalloc(&th, pl.type_hdr.size() * 4); hipMalloc(&rows, pl.rows.size() * 4); hipMalloc(&wblk, pl.wblk.size() * 4);
+    hipMemcpy(th, pl.type_hdr.data(), pl.type_hdr.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(rows, pl.rows.data(), pl.rows.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(wblk, pl.wblk.data(), pl.wblk.size() * 4, hipMemcpyHostToDevice);
+    const int lds = 2 * pl.max_rb * pl.tile * ROW_STRIDE + pl.max_rb * pl.tile * 16;
+    auto kern = gram_kernel<float, true>;
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    dim3 grid(pl.ntypes * nslices), block(GRAM_THREADS);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, grid, block, lds, 0, U, G, shift, p, n, J, th, rows, wblk, nslices, pl.nblocks, slabs, rsp);
+    hipEventRecord(e0);
+    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, grid, block, lds, 0, U, G, shift, p, n, J, th, rows, wblk, nslices, pl.nblocks, slabs, rsp);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("GRAM_ABL=%d types %d slices %d: %.1f us/launch (%.1f TF executed, %.1f TF algorithmic)\n", GRAM_ABL, pl.ntypes, nslices,
+           ms * 100.0, 2.0 * pl.nblocks * 1024 * J / (ms * 1e-4) / 1e12, (double)P * P * J / (ms * 1e-4) / 1e12);
+    return 0;
+}
