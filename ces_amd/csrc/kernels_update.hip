@@ -155,9 +155,13 @@ void update_kernel(const UpdArgs<T> a) {
             xq0 = (k0 - a.src_k0[s]) / 4;      // first row quad of this noise tile
         }
     };
-    auto store_tile = [&](int buf) {
+    // half = 0 / 1: the staged tile is written in two halves, one after each MFMA group of the
+    // current tile (so that staging and noise generation interleave with the matrix pipe);
+    // half = -1 writes everything
+    auto store_tile = [&](int buf, int half) {
 #pragma unroll
         for (int i = 0; i < WCH; ++i) {
+            if (half >= 0 && (i * 2 / WCH) != half) continue;
             const int c = tid + UPD_THREADS * i;
             const int row = c / WPR, part = c % WPR;
             *reinterpret_cast<vec_t*>(&sW[buf][row * SW + part * VEC]) = wst[i];
@@ -165,6 +169,7 @@ void update_kernel(const UpdArgs<T> a) {
         if (xkind == 0) {
 #pragma unroll
             for (int i = 0; i < XCH; ++i) {
+                if (half >= 0 && (XCH > 1 ? (i * 2 / XCH) : 0) != half) continue;
                 const int c = tid + UPD_THREADS * i;
                 *reinterpret_cast<vec_t*>(&sX[buf][(c / CPR) * SX + (c % CPR) * VEC]) = xst[i];
             }
@@ -172,6 +177,7 @@ void update_kernel(const UpdArgs<T> a) {
             const unsigned q0 = (unsigned)xq0;
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
+                if (half >= 0 && (NQ > 1 ? (i * 2 / NQ) : 1) != half) continue;
                 const int item = tid + UPD_THREADS * i;
                 const int jl = item % BN, ql = item / BN;
                 const unsigned long long gj = (unsigned long long)(a.j_offset + jt0 + jl);
@@ -196,7 +202,7 @@ void update_kernel(const UpdArgs<T> a) {
     const int li = lane % TILE, lh = lane / TILE;
 
     load_tile(0);
-    store_tile(0);
+    store_tile(0, -1);
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
@@ -235,9 +241,7 @@ void update_kernel(const UpdArgs<T> a) {
         bool any_need = false;
 #pragma unroll
         for (int r = 0; r < WR; ++r) any_need = any_need || need[r];
-        if (any_need) {
-#pragma unroll
-            for (int g = 0; g < BK / GROUP; ++g) {
+        auto compute_group = [&](int g) {
                 vec_t af[WR];
                 T xf[WC][VEC];
                 if (UPD_ABL & 4) {
@@ -271,9 +275,14 @@ void update_kernel(const UpdArgs<T> a) {
                                 acc[r][c] = M::mma(af[r][v], xf[c][v], acc[r][c]);
                     }
                 }
-            }
-        }
-        if (!(UPD_ABL & 1) && kt + 1 < nkt) store_tile(cur ^ 1);
+            asm volatile("" ::: "memory");
+        };
+        static_assert(BK / GROUP == 2, "two MFMA groups per k-tile");
+        const bool stage_next = !(UPD_ABL & 1) && kt + 1 < nkt;
+        if (any_need) compute_group(0);
+        if (stage_next) store_tile(cur ^ 1, 0);
+        if (any_need) compute_group(1);
+        if (stage_next) store_tile(cur ^ 1, 1);
         if (!(UPD_ABL & 2)) __syncthreads();
     }
 
