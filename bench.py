@@ -127,7 +127,10 @@ def main():
         U, G = batches[i % NB]
         prm = engine.step_params(update=args.update, first_step=(i == 0), t_len=min(i, 1), t_last=t_hist[0],
                                  step_index=i)
-        sh.step(prm, U, G, xi=None, out=out, recenter=(i == 0))
+        if world == 1:
+            eng.step(prm, U, G, xi=None, out=out, recenter=(i == 0))      # cesx_step: moments + apply in one call
+        else:
+            sh.step(prm, U, G, xi=None, out=out, recenter=(i == 0))       # moments -> all-reduce -> apply
         res = eng.result()                     # the driver loop reads t every step (ces/calibrate.py:387)
         t_hist[0] = res.t_new
         return res

@@ -240,7 +240,7 @@ int launch_update(Engine& e, int out_rows, const void* W, int ktot, const void* 
                   const UpdateOpt& opt, hipStream_t s);
 int update_grid_blocks(Engine& e, int out_rows);
 int launch_data_metrics(Engine& e, const void* G, hipStream_t s);   // dense Gamma: separate pass
-int launch_metric_final(Engine& e, const double* mom, hipStream_t s);
+int launch_metric_final(Engine& e, const double* mom, bool publish, hipStream_t s);
 int launch_publish(Engine& e, hipStream_t s);
 int launch_absmax_final(Engine& e, int nparts, double* absmax_out, hipStream_t s);
 int potrf_ld(int n);

@@ -132,9 +132,9 @@ int run_update_split(Engine& e, const cesx_step_params& prm, const void* U, cons
 }
 
 // data metrics: K3 accumulated them (diagonal Gamma) or a separate pass does (dense Gamma)
-int finish_metrics(Engine& e, const double* mom, const void* G, hipStream_t s) {
+int finish_metrics(Engine& e, const double* mom, const void* G, bool publish, hipStream_t s) {
     if (!e.diag_gamma) TRY(launch_data_metrics(e, G, s));
-    return launch_metric_final(e, mom, s);
+    return launch_metric_final(e, mom, publish, s);
 }
 
 }  // namespace
@@ -345,7 +345,7 @@ int cesx_apply_drift(cesx_handle h, const cesx_step_params* prm, const double* m
                       Unext, e.d_absmax_part, prm->step_index, e.diag_gamma, opt, s));
     e.last_metric_parts = e.last_update_grid_x;
     const int nparts = e.last_update_grid;
-    TRY(finish_metrics(e, mom, G, s));
+    TRY(finish_metrics(e, mom, G, false, s));
     return launch_absmax_final(e, nparts, absmax, s);
 }
 
@@ -387,8 +387,10 @@ int cesx_apply(cesx_handle h, const cesx_step_params* prm, const double* mom, co
         TRY(launch_dense(e, *prm, mom, 0, s));
         TRY(run_update_main(e, *prm, U, G, xi, Unext, s));
     }
-    TRY(finish_metrics(e, mom, G, s));
-    return finish_step(e, *prm, s);
+    TRY(finish_metrics(e, mom, G, true, s));     // also publishes the step result to the host
+    e.pending = true;
+    e.last_prm = *prm;
+    return CESX_OK;
 }
 
 int cesx_step(cesx_handle h, const cesx_step_params* prm, const void* U, const void* G, const void* xi,

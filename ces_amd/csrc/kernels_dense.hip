@@ -367,8 +367,8 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
         while (R * (R + 1) / 2 > q) --R;
         const int Cc = q - R * (R + 1) / 2;
         const bool on = q < ntile;
-        tR[s] = on ? R : -1;
-        tC[s] = on ? Cc : 0;
+        tR[s] = __builtin_amdgcn_readfirstlane(on ? R : -1);      // wave-uniform -> SGPRs
+        tC[s] = __builtin_amdgcn_readfirstlane(on ? Cc : 0);
 #pragma clang loop unroll(full)
         for (int e = 0; e < 4; ++e) {
             int i = R * 16 + lr + 4 * e, j = Cc * 16 + lc;
@@ -381,14 +381,15 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
     long long tph[5] = {0, 0, 0, 0, 0}, tl = clock64();
 #define PH(i) if (dbg) { const long long t_ = clock64(); tph[i] += t_ - tl; tl = t_; }
     // columns kbn .. kbn+7 of tile s -> buf[col - kbn][row - kbn] (rows at or below the panel's diagonal block)
+    // (no per-lane branches: elements outside the panel are written to the 4 pad rows of column 0)
     auto publish = [&](int s, int kbn, double* buf) {
         const int col = tC[s] * 16 + lc - kbn;
-        if (col >= 0 && col < QNB) {
+        const bool cok = col >= 0 && col < QNB;
 #pragma clang loop unroll(full)
-            for (int e = 0; e < 4; ++e) {
-                const int row = tR[s] * 16 + lr + 4 * e - kbn;
-                if (row >= 0) buf[col * ldt + row] = Pt[s][e];
-            }
+        for (int e = 0; e < 4; ++e) {
+            const int row = tR[s] * 16 + lr + 4 * e - kbn;
+            const int off = (cok && row >= 0) ? col * ldt + row : np - kbn + e;
+            buf[off] = Pt[s][e];
         }
     };
 #pragma clang loop unroll(full)
@@ -457,18 +458,19 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
 #pragma clang loop unroll(full)
         for (int s = 0; s < SLOTS; ++s) {
             if (tR[s] >= 0 && tC[s] * 16 + 15 >= kn) {
-                const double* pa = cur + tR[s] * 16 - kb + lc;      // row index of the A operand = lane & 15
-                const double* pb = cur + tC[s] * 16 - kb + lc;
-                // rows / columns left of kn inside this tile read panel rows < 8 (or negative
-                // offsets for finished columns): those products only touch entries that are
-                // never used again, but the addresses must stay inside the buffer
-                const bool aok = tR[s] * 16 + lc >= kb, bok = tC[s] * 16 + lc >= kb;
+                // A operand: row index = lane & 15.  Rows / columns of the tile left of the panel
+                // (finished columns) have no panel entry: load from a clamped address and select 0
+                // afterwards, so that all four loads issue back to back (no exec-mask branches)
+                const int ra = tR[s] * 16 - kb + lc, rb = tC[s] * 16 - kb + lc;
+                const bool aok = ra >= 0, bok = rb >= 0;
+                const double* pa = cur + (aok ? ra : 0);
+                const double* pb = cur + (bok ? rb : 0);
+                double av[2], bv[2];
 #pragma clang loop unroll(full)
-                for (int h = 0; h < 2; ++h) {
-                    const double av = aok ? -pa[(4 * h + lr) * ldt] : 0.0;
-                    const double bv = bok ? pb[(4 * h + lr) * ldt] : 0.0;
-                    Pt[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, Pt[s], 0, 0, 0);
-                }
+                for (int h = 0; h < 2; ++h) { av[h] = pa[(4 * h + lr) * ldt]; bv[h] = pb[(4 * h + lr) * ldt]; }
+#pragma clang loop unroll(full)
+                for (int h = 0; h < 2; ++h)
+                    Pt[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(aok ? -av[h] : 0.0, bok ? bv[h] : 0.0, Pt[s], 0, 0, 0);
                 if (kn < np && tC[s] == kn / 16) publish(s, kn, nxt);
             }
         }

@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
     int hst; hipMemcpy(&hst, st, 4, hipMemcpyDeviceToHost);
     hipLaunchKernelGGL(kern, dim3(1), dim3(cesx::PRT), lds, 0, n, np, dA, dLp, st, dbg);
     long long hd[5]; hipMemcpy(hd, dbg, 40, hipMemcpyDeviceToHost);
-    printf("cycles: load %lld publish %lld diag %lld solve %lld trailing %lld\n", hd[0], hd[1], hd[2], hd[3], hd[4]);
+    printf("cycles (wave 0): init %lld | factor %lld barrier %lld | trailing %lld barrier %lld\n", hd[0], hd[1], hd[2], hd[3], hd[4]);
     printf("n=%d potrf %.1f us/call, max |LL^T - A| = %.3e, status %d\n", n, ms * 100.0, err, hst);
     return 0;
 }
