@@ -100,6 +100,24 @@ __device__ __forceinline__ void normal4(uint4x r, double out[4]) {
 }
 
 // ---------------------------------------------------------------------------
+// Packed fp64 moment buffer (the only data that crosses GPUs).  The part that
+// depends on U alone comes first and is contiguous, so that it can be reduced
+// (and chol(C) started) before the rest of the Gram is finished:
+//   [ N | sum a (p) | S_aa (p x p) ][ sum b (n) | S_ab (p x n) | S_bb (n x n) | lagged q sums (2) ]
+// ---------------------------------------------------------------------------
+struct MomLayout {
+    int p, n;
+    __host__ __device__ size_t sa() const { return 1; }
+    __host__ __device__ size_t Saa() const { return 1 + (size_t)p; }
+    __host__ __device__ size_t uu_len() const { return 1 + (size_t)p + (size_t)p * p; }
+    __host__ __device__ size_t sb() const { return uu_len(); }
+    __host__ __device__ size_t Sab() const { return sb() + n; }
+    __host__ __device__ size_t Sbb() const { return Sab() + (size_t)p * n; }
+    __host__ __device__ size_t tail() const { return Sbb() + (size_t)n * n; }
+    __host__ __device__ size_t len() const { return tail() + 2; }
+};
+
+// ---------------------------------------------------------------------------
 // Gram work partition (host builds it once per engine).
 // ---------------------------------------------------------------------------
 struct GramPlan {
@@ -115,8 +133,20 @@ struct GramPlan {
     //  wblk[(blocks_off + wave*nbw + b)*3 + {0,1,2}] = {ia, ib, out block id} or ia = -1
     //  blk_rc[out*2 + {0,1}] = (R, C) of output block
     std::vector<int> type_hdr, rows, wblk, blk_rc;
+    int own_lo = 0, own_hi = 0;   // block rows [own_lo, own_hi) whose row sums this plan reports
 };
-GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds);
+// subset: 0 = all lower-triangular blocks, 1 = the blocks that only involve the first pbU
+// block rows (U x U: everything chol(C) needs), 2 = all the others
+GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset, int pbU);
+
+// one Gram launch: plan + its device tables and partial-result buffers
+struct GramPart {
+    GramPlan plan;
+    int *d_type_hdr = nullptr, *d_rows = nullptr, *d_wblk = nullptr, *d_blk_rc = nullptr;
+    int nslices = 0;
+    void* d_slabs = nullptr;            // [nslices][nblocks][tile*tile] engine dtype
+    double* d_rowsum_part = nullptr;    // [nslices][p+n]
+};
 
 // ---------------------------------------------------------------------------
 // Engine state
@@ -134,9 +164,10 @@ struct Engine {
     cesx_config cfg{};
     std::string err;
     bool problem_set = false, shift_valid = false;
-    bool overlap_chol = false;     // ALDI: run chol(C) on the side stream beside the drift part of K3 (CESX_OVERLAP=1).
-                                   // Measured at C2: hides the 141 us Cholesky but the split update costs +115 us
-                                   // (narrow tiles, un-hidden Philox in the noise pass): no net gain, so off by default
+    bool chol_inflight = false;    // cesx_chol_async ran for the current moments; cesx_apply joins the side stream
+    bool overlap_chol = true;      // run chol(C) on the side stream beside the second (non U x U) part of the Gram
+                                   // (CESX_OVERLAP=0 disables)
+    bool split_update = false;     // ALDI: split K3 into drift + noise launches (CESX_SPLIT_UPDATE=1; measured: no gain)
     int p = 0, n = 0, P = 0;
     int64_t J = 0, Jg = 0;
     size_t esz = 4;               // sizeof(T)
@@ -152,12 +183,9 @@ struct Engine {
     void*   d_yT = nullptr;        // y in engine dtype
     void*   d_gwT = nullptr;       // diag(Gamma^{-1}) in engine dtype
     void*   d_GinvT = nullptr;     // dense Gamma^{-1} in engine dtype (n x n)
-    // gram
-    GramPlan plan;
-    int *d_type_hdr = nullptr, *d_rows = nullptr, *d_wblk = nullptr, *d_blk_rc = nullptr;
-    int nslices = 0;
-    void* d_slabs = nullptr;       // [nslices][nblocks][tile*tile] engine dtype
-    double* d_rowsum_part = nullptr;   // [nslices][p+n] shifted first moments per slice
+    // gram: part 0 = U x U blocks (all chol(C) needs), part 1 = the rest
+    GramPart gp[2];
+    MomLayout ml{};
     // stats partials
     int stats_blocks = 0;
     double* d_stat_part = nullptr; // [stats_blocks][stat_len]
@@ -223,9 +251,10 @@ struct UpdateSrc {            // one K-segment of the update GEMM
 
 int launch_colsum(Engine& e, const void* U, const void* G, double* sums, hipStream_t s);
 int launch_set_shift(Engine& e, const double* sums, hipStream_t s);
-int launch_gram(Engine& e, const void* U, const void* G, double* mom, hipStream_t s);
+int launch_gram(Engine& e, int part, const void* U, const void* G, double* mom, hipStream_t s);   // part 0 / 1
 int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int phase, hipStream_t s);
 int launch_assemble_noise(Engine& e, hipStream_t s);
+int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s);
 struct UpdateOpt {
     int ldw = 0;          // row stride of W (0: = ktot)
     bool narrow = false;  // narrow particle tile (more, shorter workgroups)

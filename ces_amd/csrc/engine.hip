@@ -164,6 +164,7 @@ int cesx_create(const cesx_config* cfg, cesx_handle* out) {
     e.J = cfg->J_local; e.Jg = cfg->J_global;
     e.esz = cfg->dtype == CESX_F32 ? 4 : 8;
     if (const char* ov = std::getenv("CESX_OVERLAP")) e.overlap_chol = ov[0] != '0';
+    if (const char* sv = std::getenv("CESX_SPLIT_UPDATE")) e.split_update = sv[0] != '0';
     auto fail = [&](int rc) { g_create_err = e.err; cesx_destroy(reinterpret_cast<cesx_handle>(ep)); return rc; };
     int rc;
     if ((rc = set_device(e))) return fail(rc);
@@ -171,21 +172,32 @@ int cesx_create(const cesx_config* cfg, cesx_handle* out) {
     const size_t pp = (size_t)p * p, pn = (size_t)p * n, nn = (size_t)n * n;
     const size_t mm = (size_t)potrf_ld(mx) * potrf_ld(mx);     // temporaries also hold padded Cholesky factors
 
-    // gram plan
-    e.plan = make_gram_plan(P, gram_tile(cfg->dtype), gram_nbw(cfg->dtype), gram_max_stage_rows());
-    if (e.plan.max_rb * e.plan.tile > gram_max_stage_rows()) { e.err = "gram plan exceeds LDS"; return fail(CESX_EINVAL); }
-    const long long ntiles = (e.J + gram_kt(cfg->dtype) - 1) / gram_kt(cfg->dtype);
-    int nsl = 256 / e.plan.ntypes;
-    if (nsl < 1) nsl = 1;
-    if (nsl > 8) nsl -= nsl % 8;
-    if (nsl > ntiles) nsl = (int)ntiles;
-    e.nslices = nsl;
+    // gram plans: part 0 = blocks among the first ceil(p / tile) block rows (U x U: all that
+    // chol(C) needs), part 1 = the rest.  Part 1 is sized to leave a few CUs free, because the
+    // single-workgroup Cholesky runs beside it on the side stream.
+    e.ml = MomLayout{p, n};
+    {
+        const int tile = gram_tile(cfg->dtype), kt = gram_kt(cfg->dtype);
+        const int pbU = (p + tile - 1) / tile;
+        const long long ntiles = (e.J + kt - 1) / kt;
+        for (int part = 0; part < 2; ++part) {
+            GramPart& gp = e.gp[part];
+            gp.plan = make_gram_plan(P, tile, gram_nbw(cfg->dtype), gram_max_stage_rows(), part + 1, pbU);
+            if (gp.plan.max_rb * tile > gram_max_stage_rows()) { e.err = "gram plan exceeds LDS"; return fail(CESX_EINVAL); }
+            if (gp.plan.nblocks == 0) { gp.nslices = 1; continue; }
+            int nsl = (part == 0 ? 256 : 224) / gp.plan.ntypes;      // part 1: 7 workgroups per shader engine (8 CUs), so that the Cholesky always finds a free CU
+            if (nsl < 1) nsl = 1;
+            if (nsl > 8) nsl -= nsl % 4;
+            if (nsl > ntiles) nsl = (int)ntiles;
+            gp.nslices = nsl;
+        }
+    }
     e.colsum_slices = (int)std::min<long long>(16, (e.J + 1023) / 1024);
     if (e.colsum_slices < 1) e.colsum_slices = 1;
     e.stats_blocks = (int)((e.J + 63) / 64);
     e.kp = (p + 15) / 16 * 16; e.kn = (n + 15) / 16 * 16; e.ktot = 2 * e.kp + e.kn;
     e.rpad = (mx + 255) / 256 * 256;
-    e.mom_len = 1 + P + pp + pn + nn + 2;        // + lagged {sum q_r^2, sum q_e^2} of the previous apply
+    e.mom_len = e.ml.len();                      // incl. lagged {sum q_r^2, sum q_e^2} of the previous apply
 
 #define DM(ptr, bytes) if ((rc = dmalloc(e, &ptr, (bytes)))) return fail(rc)
     DM(e.d_y, n * 8); DM(e.d_mu, p * 8); DM(e.d_ustar, p * 8);
@@ -201,18 +213,25 @@ int cesx_create(const cesx_config* cfg, cesx_handle* out) {
         DM(t, n * e.esz); e.d_wdT = t;
         DM(t, n * e.esz); e.d_gbarT = t;
         DM(t, (size_t)e.kn * 4 * e.esz); e.d_rowc = t;
-        DM(t, (size_t)e.nslices * e.plan.nblocks * e.plan.tile * e.plan.tile * e.esz); e.d_slabs = t;
+        for (int part = 0; part < 2; ++part) {
+            const GramPlan& pl = e.gp[part].plan;
+            DM(t, (size_t)e.gp[part].nslices * pl.nblocks * pl.tile * pl.tile * e.esz); e.gp[part].d_slabs = t;
+        }
         DM(t, (size_t)e.rpad * e.ktot * e.esz); e.d_W = t;
         DM(t, (size_t)e.rpad * e.esz); e.d_bias = t;
         DM(t, (size_t)e.rpad * e.kp * e.esz); e.d_Wfwd = t;
     }
-    DM(e.d_type_hdr, e.plan.type_hdr.size() * 4); DM(e.d_rows, e.plan.rows.size() * 4);
-    DM(e.d_wblk, e.plan.wblk.size() * 4); DM(e.d_blk_rc, e.plan.blk_rc.size() * 4);
-    if ((rc = upload(e, e.d_type_hdr, e.plan.type_hdr.data(), e.plan.type_hdr.size() * 4))) return fail(rc);
-    if ((rc = upload(e, e.d_rows, e.plan.rows.data(), e.plan.rows.size() * 4))) return fail(rc);
-    if ((rc = upload(e, e.d_wblk, e.plan.wblk.data(), e.plan.wblk.size() * 4))) return fail(rc);
-    if ((rc = upload(e, e.d_blk_rc, e.plan.blk_rc.data(), e.plan.blk_rc.size() * 4))) return fail(rc);
-    DM(e.d_rowsum_part, (size_t)e.nslices * P * 8);
+    for (int part = 0; part < 2; ++part) {
+        GramPart& gp = e.gp[part];
+        const GramPlan& pl = gp.plan;
+        DM(gp.d_type_hdr, pl.type_hdr.size() * 4); DM(gp.d_rows, pl.rows.size() * 4);
+        DM(gp.d_wblk, pl.wblk.size() * 4); DM(gp.d_blk_rc, pl.blk_rc.size() * 4);
+        if ((rc = upload(e, gp.d_type_hdr, pl.type_hdr.data(), pl.type_hdr.size() * 4))) return fail(rc);
+        if ((rc = upload(e, gp.d_rows, pl.rows.data(), pl.rows.size() * 4))) return fail(rc);
+        if ((rc = upload(e, gp.d_wblk, pl.wblk.data(), pl.wblk.size() * 4))) return fail(rc);
+        if ((rc = upload(e, gp.d_blk_rc, pl.blk_rc.data(), pl.blk_rc.size() * 4))) return fail(rc);
+        DM(gp.d_rowsum_part, (size_t)gp.nslices * P * 8);
+    }
     DM(e.d_metric_part, ((size_t)((e.J + 63) / 64) + 8) * 2 * 8);
     DM(e.d_metric_sums, 2 * 8);
     DM(e.d_colsum_part, (size_t)P * e.colsum_slices * 8);
@@ -246,10 +265,12 @@ void cesx_destroy(cesx_handle h) {
     Engine& e = *reinterpret_cast<Engine*>(h);
     (void)hipSetDevice(e.cfg.device);
     void* ptrs[] = {e.d_y, e.d_mu, e.d_ustar, e.d_Gamma, e.d_Ginv, e.d_gw, e.d_Wh, e.d_Sigma, e.d_Sinv, e.d_sw,
-                    e.d_shift64, e.d_shiftT, e.d_yT, e.d_gwT, e.d_GinvT, e.d_wdT, e.d_slabs, e.d_W,
-                    e.d_bias, e.d_Wfwd, e.d_type_hdr, e.d_rows, e.d_wblk, e.d_blk_rc, e.d_metric_part, e.d_metric_sums,
+                    e.d_shift64, e.d_shiftT, e.d_yT, e.d_gwT, e.d_GinvT, e.d_wdT, e.d_W,
+                    e.d_bias, e.d_Wfwd, e.d_metric_part, e.d_metric_sums,
                     e.d_gbarT, e.d_rowc,
-                    e.d_colsum_part, e.d_rowsum_part, e.d_mom, e.d_sums, e.d_ubar, e.d_gbar, e.d_m, e.d_dg,
+                    e.d_colsum_part, e.d_mom,
+                    e.gp[0].d_type_hdr, e.gp[0].d_rows, e.gp[0].d_wblk, e.gp[0].d_blk_rc, e.gp[0].d_slabs, e.gp[0].d_rowsum_part,
+                    e.gp[1].d_type_hdr, e.gp[1].d_rows, e.gp[1].d_wblk, e.gp[1].d_blk_rc, e.gp[1].d_slabs, e.gp[1].d_rowsum_part, e.d_sums, e.d_ubar, e.d_gbar, e.d_m, e.d_dg,
                     e.d_wdel, e.d_C, e.d_L, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_Kp, e.d_M, e.d_P, e.d_PK,
                     e.d_t1, e.d_t2, e.d_t3, e.d_t4, e.d_Lp, e.d_lanczos, e.d_mv, e.d_part, e.d_scal, e.d_absmax,
                     e.d_c0, e.d_absmax_part};
@@ -300,6 +321,7 @@ int cesx_set_problem(cesx_handle h, const double* y, const double* Gamma, const 
 }
 
 size_t cesx_moments_len(cesx_handle h) { return h ? reinterpret_cast<Engine*>(h)->mom_len : 0; }
+size_t cesx_moments_uu_len(cesx_handle h) { return h ? reinterpret_cast<Engine*>(h)->ml.uu_len() : 0; }
 
 int cesx_colsum(cesx_handle h, const void* U, const void* G, double* sums, void* stream) {
     if (!h) return CESX_EINVAL;
@@ -317,17 +339,41 @@ int cesx_set_shift(cesx_handle h, const double* sums, void* stream) {
     return launch_set_shift(e, sums, (hipStream_t)stream);
 }
 
-int cesx_moments(cesx_handle h, const void* U, const void* G, double* mom, void* stream) {
-    if (!h) return CESX_EINVAL;
-    Engine& e = *reinterpret_cast<Engine*>(h);
+static int moments_check(Engine& e, const void* U, const void* G, double* mom) {
     if (!U || !G || !mom) { e.err = "cesx_moments: null pointer"; return CESX_EINVAL; }
     if (!e.problem_set) { e.err = "cesx_set_problem has not been called"; return CESX_ESTATE; }
     if (!e.shift_valid) { e.err = "no centring shift: call cesx_colsum + cesx_set_shift (or cesx_step with recenter) first"; return CESX_ESTATE; }
+    return set_device(e);
+}
+
+int cesx_moments_uu(cesx_handle h, const void* U, const void* G, double* mom, void* stream) {
+    if (!h) return CESX_EINVAL;
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    TRY(moments_check(e, U, G, mom));
+    return launch_gram(e, 0, U, G, mom, (hipStream_t)stream);
+}
+
+int cesx_chol_async(cesx_handle h, int update, const double* mom, void* stream) {
+    if (!h) return CESX_EINVAL;
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    if (!mom || update < 0 || update > 2) { e.err = "cesx_chol_async: bad argument"; return CESX_EINVAL; }
+    if (!e.problem_set) { e.err = "cesx_set_problem has not been called"; return CESX_ESTATE; }
     TRY(set_device(e));
-    hipStream_t s = (hipStream_t)stream;
-    // tail: this shard's data-metric sums of the PREVIOUS apply ride on this step's all-reduce
-    CESX_HIP(hipMemcpyAsync(mom + e.mom_len - 2, e.d_metric_sums, 16, hipMemcpyDeviceToDevice, s));
-    return launch_gram(e, U, G, mom, s);
+    return launch_chol_async(e, update, mom, (hipStream_t)stream);
+}
+
+int cesx_moments_rest(cesx_handle h, const void* U, const void* G, double* mom, void* stream) {
+    if (!h) return CESX_EINVAL;
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    TRY(moments_check(e, U, G, mom));
+    // (the reduce kernel of this launch also copies this shard's data-metric sums of the PREVIOUS
+    //  apply to the tail of the buffer: they ride on this step's all-reduce)
+    return launch_gram(e, 1, U, G, mom, (hipStream_t)stream);
+}
+
+int cesx_moments(cesx_handle h, const void* U, const void* G, double* mom, void* stream) {
+    int rc = cesx_moments_uu(h, U, G, mom, stream);
+    return rc ? rc : cesx_moments_rest(h, U, G, mom, stream);
 }
 
 int cesx_apply_drift(cesx_handle h, const cesx_step_params* prm, const double* mom, const void* U,
@@ -380,7 +426,7 @@ int cesx_apply(cesx_handle h, const cesx_step_params* prm, const double* mom, co
     }
     TRY(set_device(e));
     hipStream_t s = (hipStream_t)stream;
-    if (prm->update == CESX_UPDATE_ALDI && e.overlap_chol) {
+    if (prm->update == CESX_UPDATE_ALDI && e.split_update) {
         TRY(launch_dense(e, *prm, mom, 3, s));
         TRY(run_update_split(e, *prm, U, G, xi, Unext, s));
     } else {
@@ -405,7 +451,10 @@ int cesx_step(cesx_handle h, const cesx_step_params* prm, const void* U, const v
         TRY(cesx_colsum(h, U, G, e.d_sums, stream));
         TRY(cesx_set_shift(h, e.d_sums, stream));
     }
-    TRY(cesx_moments(h, U, G, e.d_mom, stream));
+    // U x U moments -> chol(C) on the side stream, beside the rest of the Gram -> apply
+    TRY(cesx_moments_uu(h, U, G, e.d_mom, stream));
+    if (e.overlap_chol) TRY(cesx_chol_async(h, prm->update, e.d_mom, stream));
+    TRY(cesx_moments_rest(h, U, G, e.d_mom, stream));
     return cesx_apply(h, prm, e.d_mom, U, G, xi, Unext, stream);
 }
 

@@ -31,25 +31,29 @@ __device__ __forceinline__ double dblock_sum(double v, double* red) {
 struct MomView {
     int p, n;
     const double* mom;
+    __device__ MomLayout ml() const { return MomLayout{p, n}; }
     __device__ double N() const { return mom[0]; }
-    __device__ const double* sa() const { return mom + 1; }
-    __device__ const double* sb() const { return mom + 1 + p; }
-    __device__ const double* Saa() const { return mom + 1 + p + n; }
-    __device__ const double* Sab() const { return Saa() + (size_t)p * p; }
-    __device__ const double* Sbb() const { return Sab() + (size_t)p * n; }
+    __device__ const double* sa() const { return mom + ml().sa(); }
+    __device__ const double* sb() const { return mom + ml().sb(); }
+    __device__ const double* Saa() const { return mom + ml().Saa(); }
+    __device__ const double* Sab() const { return mom + ml().Sab(); }
+    __device__ const double* Sbb() const { return mom + ml().Sbb(); }
 };
 
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(DT)
 void center_kernel(MomView mv, const double* __restrict__ shift, const double* __restrict__ y,
                    const double* __restrict__ ustar, const double* __restrict__ gw,
-                   const double* __restrict__ sw, int unbiased,
+                   const double* __restrict__ sw, int unbiased, int what,
                    double* __restrict__ ubar, double* __restrict__ gbar, double* __restrict__ mvec,
                    double* __restrict__ dg, double* __restrict__ C, double* __restrict__ Cug,
                    double* __restrict__ See, double* __restrict__ Srr, double* __restrict__ K,
                    double* __restrict__ M, double* __restrict__ part, Scalars* __restrict__ sc) {
     __shared__ double red[DT / 64];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // what & 1: the part that depends on U alone (C, M = C Sigma^{-1}, ubar, tr S_uu, |ubar - u*|^2):
+    //           everything chol(C) needs, available before the rest of the Gram is finished
+    // what & 2: the part that involves G
+    if ((what & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         sc->status = CESX_OK;
         sc->radspec = 0.0;
         sc->spare[0] = 0.0;
@@ -63,7 +67,8 @@ void center_kernel(MomView mv, const double* __restrict__ shift, const double* _
     const long long pp = (long long)p * p, pn = (long long)p * n, nn = (long long)n * n;
     const long long gid = (long long)blockIdx.x * DT + threadIdx.x, gsz = (long long)gridDim.x * DT;
     double tr = 0.0, b2 = 0.0, fr = 0.0;
-    for (long long idx = gid; idx < pp + pn + nn; idx += gsz) {
+    const long long lo = (what & 1) ? 0 : pp, hi = (what & 2) ? pp + pn + nn : pp;
+    for (long long idx = lo + gid; idx < hi; idx += gsz) {
         if (idx < pp) {
             const int i = (int)(idx / p), j = (int)(idx % p);
             const double suu = mv.Saa()[idx] - sa[i] * sa[j] / N;
@@ -88,7 +93,8 @@ void center_kernel(MomView mv, const double* __restrict__ shift, const double* _
             if (gw) fr += see * srr * gw[i] * gw[j];
         }
     }
-    for (long long i = gid; i < p + n; i += gsz) {
+    const long long vlo = (what & 1) ? 0 : p, vhi = (what & 2) ? p + n : p;
+    for (long long i = vlo + gid; i < vhi; i += gsz) {
         if (i < p) {
             const double ub = shift[i] + sa[i] / N;
             ubar[i] = ub;
@@ -105,9 +111,8 @@ void center_kernel(MomView mv, const double* __restrict__ shift, const double* _
     b2 = dblock_sum(b2, red);
     fr = dblock_sum(fr, red);
     if (threadIdx.x == 0) {
-        part[blockIdx.x * 4 + 0] = tr;
-        part[blockIdx.x * 4 + 1] = b2;
-        part[blockIdx.x * 4 + 2] = fr;
+        if (what & 1) { part[blockIdx.x * 4 + 0] = tr; part[blockIdx.x * 4 + 1] = b2; }
+        if (what & 2) part[blockIdx.x * 4 + 2] = fr;
     }
 }
 
@@ -849,19 +854,16 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
     }
     MomView mv{p, n, mom};
     const int unbiased = prm.update == CESX_UPDATE_EKS ? 0 : 1;
+    // If cesx_chol_async already ran for these moments, the U-only part of K2 (C, M, ubar, chol(C))
+    // is done or in flight on the side stream; otherwise do it here, in line.
+    const bool early = e.chol_inflight;
     hipLaunchKernelGGL(center_kernel, dim3(NPB), dim3(DT), 0, s, mv, e.d_shift64, e.d_y, e.d_ustar,
                        e.diag_gamma ? e.d_gw : (const double*)nullptr,
-                       e.diag_sigma ? e.d_sw : (const double*)nullptr, unbiased, e.d_ubar, e.d_gbar, e.d_m,
-                       e.d_dg, e.d_C, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_M, e.d_part, e.d_scal);
+                       e.diag_sigma ? e.d_sw : (const double*)nullptr, unbiased, early ? 2 : 3, e.d_ubar, e.d_gbar,
+                       e.d_m, e.d_dg, e.d_C, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_M, e.d_part, e.d_scal);
     CESX_HIP(hipGetLastError());
-    if (phase == 3) {
-        // ALDI overlap: chol(C) runs on the side stream beside the drift part of the update
-        // (K3a); only the noise columns of W wait for it (launch_assemble_noise)
-        CESX_HIP(hipEventRecord(e.ev_a, s));
-        CESX_HIP(hipStreamWaitEvent(e.side, e.ev_a, 0));
-        if ((rc = potrf(e, e.side, p, e.d_C, e.d_L))) return rc;
-        CESX_HIP(hipEventRecord(e.ev_b, e.side));
-    } else if ((rc = potrf(e, s, p, e.d_C, e.d_L))) return rc;
+    if (!early)
+        if ((rc = potrf(e, s, p, e.d_C, e.d_L))) return rc;
     if (!e.diag_gamma) {
         // Frobenius term <Ginv Srr Ginv, See>, and K = C_ug Ginv
         if ((rc = gemm(e, s, n, n, n, 1.0, e.d_Ginv, n, 1, e.d_Srr, n, 1, e.d_t1))) return rc;
@@ -924,13 +926,39 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
     }
     if (phase == 3)
         return f32 ? assemble<float>(e, s, 0, e.ktot, prm.switch_mult, 1) : assemble<double>(e, s, 0, e.ktot, prm.switch_mult, 1);
+    if (early) {                                     // join the side-stream Cholesky before W needs L
+        CESX_HIP(hipStreamWaitEvent(s, e.ev_b, 0));
+        e.chol_inflight = false;
+    }
     const int ktot = mode == 2 ? e.kp + e.kn : e.ktot;
     return f32 ? assemble<float>(e, s, mode, ktot, prm.switch_mult) : assemble<double>(e, s, mode, ktot, prm.switch_mult);
+}
+
+// U-only part of K2, started as soon as the U x U part of the moments is complete (and, on
+// several devices, all-reduced): C = S_uu / div + 1e-8 I, M, ubar, then chol(C) on the engine's
+// side stream.  cesx_apply joins it right before W is assembled.
+int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s) {
+    const int p = e.p, n = e.n;
+    MomView mv{p, n, mom};
+    const int unbiased = update == CESX_UPDATE_EKS ? 0 : 1;
+    hipLaunchKernelGGL(center_kernel, dim3(NPB), dim3(DT), 0, s, mv, e.d_shift64, e.d_y, e.d_ustar,
+                       e.diag_gamma ? e.d_gw : (const double*)nullptr,
+                       e.diag_sigma ? e.d_sw : (const double*)nullptr, unbiased, 1, e.d_ubar, e.d_gbar,
+                       e.d_m, e.d_dg, e.d_C, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_M, e.d_part, e.d_scal);
+    CESX_HIP(hipGetLastError());
+    CESX_HIP(hipEventRecord(e.ev_a, s));
+    CESX_HIP(hipStreamWaitEvent(e.side, e.ev_a, 0));
+    int rc;
+    if ((rc = potrf(e, e.side, p, e.d_C, e.d_L))) return rc;
+    CESX_HIP(hipEventRecord(e.ev_b, e.side));
+    e.chol_inflight = true;
+    return CESX_OK;
 }
 
 // second half of the overlapped ALDI K2: the sqrt(2 hk) L columns of W, after the side-stream Cholesky
 int launch_assemble_noise(Engine& e, hipStream_t s) {
     CESX_HIP(hipStreamWaitEvent(s, e.ev_b, 0));
+    e.chol_inflight = false;
     return e.cfg.dtype == CESX_F32 ? assemble<float>(e, s, 0, e.ktot, 0.0, 2) : assemble<double>(e, s, 0, e.ktot, 0.0, 2);
 }
 

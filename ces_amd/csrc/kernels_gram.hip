@@ -238,30 +238,48 @@ void gram_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __re
 
 // Sum the per-slice partial blocks in fp64 (fixed order) and scatter them into
 // the packed moment buffer as full symmetric S_aa, S_ab, S_bb.  A workgroup
-// handles 64 16-byte groups (4 f32 / 2 f64 along a block row); its 4 waves
-// each sum a quarter of the slices (8 loads in flight per lane), the quarters
-// are combined through LDS in a fixed order.
-constexpr int RED_G = 64;
+// handles RED_G 16-byte groups (4 f32 / 2 f64 along a block row) x RED_S slice
+// parts (each lane sums nslices / RED_S slices with up to 8 loads in flight);
+// the parts are combined through LDS in a fixed order.
+constexpr int RED_G = 16, RED_S = 16;
 template <typename T>
 __global__ __launch_bounds__(256)
 void gram_reduce_kernel(const T* __restrict__ slabs, const int* __restrict__ blk_rc,
-                        int nslices, int nblocks, int tile, int p, int n, long long J,
-                        const double* __restrict__ rowsum_part, double* __restrict__ mom) {
+                        int nslices, int nblocks, int tile, MomLayout ml, long long J, int row_lo, int row_hi,
+                        int write_N, const double* __restrict__ rowsum_part, const double* __restrict__ tail_src,
+                        double* __restrict__ mom) {
     using vec_t = typename Mfma<T>::vec_t;
     constexpr int VEC = Mfma<T>::VEC;
-    __shared__ double part[4][RED_G][VEC];
+    const int p = ml.p, n = ml.n;
+    __shared__ double part[RED_S][RED_G][VEC];
     const int tt = tile * tile;
     const long long ngroups = (long long)nblocks * tt / VEC;
-    const int gq = threadIdx.x >> 6, gl = threadIdx.x & 63;
+    const int gq = threadIdx.x / RED_G, gl = threadIdx.x % RED_G;
     const long long idx = (long long)blockIdx.x * RED_G + gl;
     if ((long long)blockIdx.x * RED_G >= ngroups) {
-        // tail workgroups: N and the first moments sum_j (z_ij - s_i)
-        const long long r = ((long long)blockIdx.x * RED_G - ngroups) / RED_G * 256 + threadIdx.x;
-        if (r == 0) mom[0] = (double)J;
-        if (r < p + n) {
-            double s = 0.0;
-            for (int k = 0; k < nslices; ++k) s += rowsum_part[(size_t)k * (p + n) + r];
-            mom[1 + r] = s;
+        // tail workgroups: N, the first moments sum_j (z_ij - s_i) of the rows this launch owns
+        // (16 rows x 16 slice parts per workgroup), and (second launch) the lagged data-metric
+        // sums that ride at the end of the buffer
+        const int tw = (int)(((long long)blockIdx.x * RED_G - ngroups) / RED_G);
+        const long long r = row_lo + (long long)tw * RED_G + gl;
+        if (tw == 0 && threadIdx.x == 0) {
+            if (write_N) mom[0] = (double)J;
+            if (tail_src) { mom[ml.tail()] = tail_src[0]; mom[ml.tail() + 1] = tail_src[1]; }
+        }
+        double s = 0.0;
+        if (r < row_hi) {
+            const int per = (nslices + RED_S - 1) / RED_S;
+            const int k1 = min(nslices, (gq + 1) * per);
+#pragma unroll 8
+            for (int k = gq * per; k < k1; ++k) s += rowsum_part[(size_t)k * (p + n) + r];
+        }
+        part[gq][gl][0] = s;
+        __syncthreads();
+        if (gq == 0 && r < row_hi) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < RED_S; ++q) t += part[q][gl][0];
+            mom[r < p ? ml.sa() + r : ml.sb() + (r - p)] = t;
         }
         return;
     }
@@ -272,7 +290,7 @@ void gram_reduce_kernel(const T* __restrict__ slabs, const int* __restrict__ blk
     for (int c = 0; c < VEC; ++c) acc[c] = 0.0;
     const T* src = slabs + (size_t)blk * tt + e0;
     const size_t stride = (size_t)nblocks * tt;
-    const int per = (nslices + 3) / 4;
+    const int per = (nslices + RED_S - 1) / RED_S;
     const int k1 = min(nslices, (gq + 1) * per);
     int k = gq * per;
     if (on) {
@@ -297,16 +315,18 @@ void gram_reduce_kernel(const T* __restrict__ slabs, const int* __restrict__ blk
     if (gq != 0 || !on) return;
     const int R = blk_rc[blk * 2], C = blk_rc[blk * 2 + 1];
     const int P = p + n;
-    double* Saa = mom + 1 + p + n;
-    double* Sab = Saa + (size_t)p * p;
-    double* Sbb = Sab + (size_t)p * n;
+    double* Saa = mom + ml.Saa();
+    double* Sab = mom + ml.Sab();
+    double* Sbb = mom + ml.Sbb();
 #pragma unroll
     for (int c = 0; c < VEC; ++c) {
         const int e = e0 + c;
         const int gr = R * tile + e / tile, gc = C * tile + e % tile;
         if (gr >= P || gc >= P) continue;
         if (R == C && gc > gr) continue;          // diagonal block: lower half, mirrored below
-        const double s = ((part[0][gl][c] + part[1][gl][c]) + part[2][gl][c]) + part[3][gl][c];
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < RED_S; ++q) s += part[q][gl][c];
         if (gr < p) {                              // both in U (gr >= gc)
             Saa[(size_t)gr * p + gc] = s;
             Saa[(size_t)gc * p + gr] = s;
@@ -322,20 +342,27 @@ void gram_reduce_kernel(const T* __restrict__ slabs, const int* __restrict__ blk
 // ---------------------------------------------------------------------------
 // host: work partition
 // ---------------------------------------------------------------------------
-GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds) {
+GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset, int pbU) {
     GramPlan pl;
     pl.tile = tile;
     pl.nbw = nbw;
     pl.nbr = (P + tile - 1) / tile;
     const int cap = GRAM_WAVES * nbw;
+    auto wanted = [&](int R, int C) {
+        const bool uu = R < pbU && C < pbU;
+        return subset == 0 || (subset == 1 ? uu : !uu);
+    };
+    pl.own_lo = subset == 2 ? std::min(pbU, pl.nbr) : 0;
+    pl.own_hi = subset == 1 ? std::min(pbU, pl.nbr) : pl.nbr;
     std::vector<std::vector<std::pair<int, int>>> types;   // blocks (R, C) per type
     if (pl.nbr * tile <= max_rows_lds) {
         // all rows fit in LDS: chop the row-major lower triangle into equal runs
         std::vector<std::pair<int, int>> all;
         for (int R = 0; R < pl.nbr; ++R)
-            for (int C = 0; C <= R; ++C) all.push_back({R, C});
-        const int nt = ((int)all.size() + cap - 1) / cap;
-        const int per = ((int)all.size() + nt - 1) / nt;
+            for (int C = 0; C <= R; ++C)
+                if (wanted(R, C)) all.push_back({R, C});
+        const int nt = std::max(1, ((int)all.size() + cap - 1) / cap);
+        const int per = std::max(1, ((int)all.size() + nt - 1) / nt);
         for (int t = 0; t < nt; ++t) {
             std::vector<std::pair<int, int>> v(all.begin() + std::min<size_t>(all.size(), (size_t)t * per),
                                                all.begin() + std::min<size_t>(all.size(), (size_t)(t + 1) * per));
@@ -353,21 +380,24 @@ GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds) {
                 std::vector<std::pair<int, int>> v;
                 for (int R = R0; R < std::min(R0 + a, pl.nbr); ++R)
                     for (int C = C0; C < std::min(C0 + b, pl.nbr); ++C)
-                        if (C <= R) v.push_back({R, C});
+                        if (C <= R && wanted(R, C)) v.push_back({R, C});
                 if (!v.empty()) types.push_back(v);
             }
     }
     pl.ntypes = (int)types.size();
     pl.max_rb = 0;
-    // output block ids in row-major lower-triangular order
-    auto out_id = [](int R, int C) { return R * (R + 1) / 2 + C; };
-    pl.nblocks = pl.nbr * (pl.nbr + 1) / 2;
-    pl.blk_rc.assign((size_t)pl.nblocks * 2, 0);
+    // output block ids: position in the row-major list of this plan's blocks
+    std::vector<int> idmap((size_t)pl.nbr * pl.nbr, -1);
+    pl.nblocks = 0;
+    pl.blk_rc.clear();
     for (int R = 0; R < pl.nbr; ++R)
-        for (int C = 0; C <= R; ++C) {
-            pl.blk_rc[(size_t)out_id(R, C) * 2] = R;
-            pl.blk_rc[(size_t)out_id(R, C) * 2 + 1] = C;
-        }
+        for (int C = 0; C <= R; ++C)
+            if (wanted(R, C)) {
+                idmap[(size_t)R * pl.nbr + C] = pl.nblocks++;
+                pl.blk_rc.push_back(R);
+                pl.blk_rc.push_back(C);
+            }
+    auto out_id = [&](int R, int C) { return idmap[(size_t)R * pl.nbr + C]; };
     std::set<int> owned;
     for (int t = 0; t < pl.ntypes; ++t) {
         const auto& v = types[t];
@@ -382,7 +412,8 @@ GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds) {
         pl.type_hdr.push_back((int)(pl.wblk.size() / 3));
         pl.type_hdr.push_back((int)v.size());
         for (int r : rows) {
-            const bool first = owned.insert(r).second;     // the first type that stages a block row reports its sums
+            // the first type that stages an owned block row reports its sums
+            const bool first = r >= pl.own_lo && r < pl.own_hi && owned.insert(r).second;
             pl.rows.push_back(r | (first ? 1 << 16 : 0));
         }
         const int nv = (int)v.size();
@@ -408,33 +439,37 @@ GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds) {
 }
 
 template <typename T>
-static int launch_gram_t(Engine& e, const void* U, const void* G, double* mom, hipStream_t s) {
-    const GramPlan& pl = e.plan;
+static int launch_gram_t(Engine& e, int part, const void* U, const void* G, double* mom, hipStream_t s) {
+    GramPart& gp = e.gp[part];
+    const GramPlan& pl = gp.plan;
     const int lds = 2 * pl.max_rb * pl.tile * ROW_STRIDE + pl.max_rb * pl.tile * 16;
     const bool aligned = (e.J % Mfma<T>::VEC == 0) && ((uintptr_t)U % 16 == 0) && ((uintptr_t)G % 16 == 0);
-    dim3 grid(pl.ntypes * e.nslices), block(GRAM_THREADS);
+    dim3 grid(pl.ntypes * gp.nslices), block(GRAM_THREADS);
     auto kern = aligned ? gram_kernel<T, true> : gram_kernel<T, false>;
     CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    {
+    if (pl.nblocks > 0) {       // (a tiny problem can have all its blocks in part 0; the reduce below still
+                                //  writes part 1's share of the buffer: row sums it owns and the lagged tail)
         ProfScope prof(e, 0, s);
         hipLaunchKernelGGL(kern, grid, block, lds, s, (const T*)U, (const T*)G, (const T*)e.d_shiftT,
-                           e.p, e.n, (long long)e.J, e.d_type_hdr, e.d_rows, e.d_wblk, e.nslices,
-                           pl.nblocks, (T*)e.d_slabs, e.d_rowsum_part);
+                           e.p, e.n, (long long)e.J, gp.d_type_hdr, gp.d_rows, gp.d_wblk, gp.nslices,
+                           pl.nblocks, (T*)gp.d_slabs, gp.d_rowsum_part);
     }
     CESX_HIP(hipGetLastError());
     const long long ngroups = (long long)pl.nblocks * pl.tile * pl.tile / Mfma<T>::VEC;
-    const long long wgs = (ngroups + RED_G - 1) / RED_G + (e.p + e.n + 255) / 256;
+    const int row_lo = std::min(pl.own_lo * pl.tile, e.p + e.n), row_hi = std::min(pl.own_hi * pl.tile, e.p + e.n);
+    const long long wgs = (ngroups + RED_G - 1) / RED_G + std::max(1, (row_hi - row_lo + RED_G - 1) / RED_G);
     hipLaunchKernelGGL(gram_reduce_kernel<T>, dim3((unsigned)wgs), dim3(256), 0, s,
-                       (const T*)e.d_slabs, e.d_blk_rc, e.nslices, pl.nblocks, pl.tile, e.p, e.n,
-                       (long long)e.J, e.d_rowsum_part, mom);
+                       (const T*)gp.d_slabs, gp.d_blk_rc, gp.nslices, pl.nblocks, pl.tile, e.ml,
+                       (long long)e.J, row_lo, row_hi, part == 0 ? 1 : 0, gp.d_rowsum_part,
+                       part == 1 ? e.d_metric_sums : (const double*)nullptr, mom);
     CESX_HIP(hipGetLastError());
     return CESX_OK;
 }
 
-int launch_gram(Engine& e, const void* U, const void* G, double* mom, hipStream_t s) {
-    return e.cfg.dtype == CESX_F32 ? launch_gram_t<float>(e, U, G, mom, s)
-                                   : launch_gram_t<double>(e, U, G, mom, s);
+int launch_gram(Engine& e, int part, const void* U, const void* G, double* mom, hipStream_t s) {
+    return e.cfg.dtype == CESX_F32 ? launch_gram_t<float>(e, part, U, G, mom, s)
+                                   : launch_gram_t<double>(e, part, U, G, mom, s);
 }
 
 int gram_nbw(int dtype) { return dtype == CESX_F32 ? GramCfg<float>::NBW : GramCfg<double>::NBW; }

@@ -236,7 +236,7 @@ int launch_publish(Engine& e, hipStream_t s) {
 int launch_metric_final(Engine& e, const double* mom, bool publish, hipStream_t s) {
     const int nparts = e.diag_gamma ? e.last_metric_parts : (int)((e.J + 63) / 64);
     hipLaunchKernelGGL(metric_final_kernel, dim3(1), dim3(ST_THREADS), 0, s, e.d_metric_part, nparts, mom,
-                       e.mom_len - 2, e.d_metric_sums, e.d_scal, publish ? e.h_scal_dev : (Scalars*)nullptr,
+                       e.ml.tail(), e.d_metric_sums, e.d_scal, publish ? e.h_scal_dev : (Scalars*)nullptr,
                        publish ? ++e.seq : 0ull);
     CESX_HIP(hipGetLastError());
     return CESX_OK;

@@ -2,9 +2,13 @@
 
 One process per GPU.  Rank r owns the column range ``shard_range(J, N, r)`` of
 U, G and U_next.  Particles are exchangeable and couple only through first and
-second moments, so one step needs exactly ONE collective: an
+second moments, so one step needs one exchange: an
 all-reduce(sum) of the packed fp64 moment buffer between the two halves of the
-step (``cesx_moments`` -> all-reduce -> ``cesx_apply``).  Rule-specific extras:
+step (``cesx_moments`` -> all-reduce -> ``cesx_apply``).  The buffer is sent in
+two pieces -- first the part that depends on U alone (N, sum u, S_uu: 0.5 MB
+at p = 256), then the rest -- so that every rank can start chol(C) on its side
+stream while the remaining 74 % of the Gram is still being computed; the total
+payload is that of one all-reduce.  Rule-specific extras:
 a (1+p+n)-double all-reduce when the centring shift is (re)computed from the
 data (first step of a run), and a one-scalar all-reduce(max) for
 ``eks_update_aldi_constant`` (ces/calibrate.py:519 takes max|drift| over the
@@ -57,7 +61,12 @@ class ShardedUpdate:
         eng = self.engine
         if recenter or not self._recentered:
             self.recenter(U, G)
-        mom = self._all_reduce(eng.moments(U, G))
+        nuu = eng.moments_uu_len()
+        mom = eng.moments_uu(U, G)
+        self._all_reduce(mom[:nuu])             # N, sum(u - s), S_aa: all chol(C) needs
+        eng.chol_async(prm, mom)                # C, then L = chol(C) on the side stream ...
+        eng.moments_rest(U, G, mom)             # ... beside the rest of the Gram
+        self._all_reduce(mom[nuu:])
         if prm.update == 2:                     # aldi_constant: max|drift| over all shards
             out = eng.empty(eng.p) if out is None else out
             absmax = self._all_reduce(eng.apply_drift(prm, mom, U, G, out), op=dist.ReduceOp.MAX)

@@ -23,7 +23,8 @@ ABI_VERSION = 1
 EXPORTS = ("cesx_abi_version", "cesx_create", "cesx_destroy", "cesx_last_error", "cesx_set_problem",
            "cesx_step", "cesx_result", "cesx_moments_len", "cesx_colsum", "cesx_set_shift",
            "cesx_moments", "cesx_apply", "cesx_apply_drift", "cesx_apply_finish", "cesx_draw_noise",
-           "cesx_forward_lineal", "cesx_debug_dense", "cesx_profile_enable", "cesx_profile_read")
+           "cesx_forward_lineal", "cesx_debug_dense", "cesx_profile_enable", "cesx_profile_read",
+           "cesx_moments_uu_len", "cesx_moments_uu", "cesx_chol_async", "cesx_moments_rest")
 
 
 class Config(C.Structure):
@@ -80,6 +81,11 @@ def load_library(path=None):
     lib.cesx_colsum.argtypes = [vp, vp, vp, vp, vp]
     lib.cesx_set_shift.argtypes = [vp, vp, vp]
     lib.cesx_moments.argtypes = [vp, vp, vp, vp, vp]
+    lib.cesx_moments_uu_len.argtypes = [vp]
+    lib.cesx_moments_uu_len.restype = C.c_size_t
+    lib.cesx_moments_uu.argtypes = [vp, vp, vp, vp, vp]
+    lib.cesx_moments_rest.argtypes = [vp, vp, vp, vp, vp]
+    lib.cesx_chol_async.argtypes = [vp, i32, vp, vp]
     lib.cesx_apply.argtypes = [vp, C.POINTER(StepParams), vp, vp, vp, vp, vp, vp]
     lib.cesx_apply_drift.argtypes = [vp, C.POINTER(StepParams), vp, vp, vp, vp, vp, vp]
     lib.cesx_apply_finish.argtypes = [vp, C.POINTER(StepParams), vp, vp, vp, vp, vp]
@@ -237,6 +243,26 @@ class Engine:
         mom = torch.empty(self.moments_len(), dtype=torch.float64, device=self.device) if out is None else out
         with torch.cuda.device(self.device):
             self._check(self.lib.cesx_moments(self._h, U.data_ptr(), G.data_ptr(), mom.data_ptr(), self._stream()))
+        return mom
+
+    def moments_uu_len(self):
+        return int(self.lib.cesx_moments_uu_len(self._h))
+
+    def moments_uu(self, U, G, out=None):
+        """U x U part of the moments into the leading moments_uu_len() entries of the buffer."""
+        mom = torch.empty(self.moments_len(), dtype=torch.float64, device=self.device) if out is None else out
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cesx_moments_uu(self._h, U.data_ptr(), G.data_ptr(), mom.data_ptr(), self._stream()))
+        return mom
+
+    def chol_async(self, prm, mom):
+        """C = cov(U) and L = chol(C) on the engine's side stream (joined by apply)."""
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cesx_chol_async(self._h, int(prm.update), mom.data_ptr(), self._stream()))
+
+    def moments_rest(self, U, G, mom):
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cesx_moments_rest(self._h, U.data_ptr(), G.data_ptr(), mom.data_ptr(), self._stream()))
         return mom
 
     def apply(self, prm, mom, U, G, xi=None, out=None):

@@ -155,9 +155,11 @@ int cesx_result(cesx_handle h, cesx_step_result* out);
 /* ---- split entry points (multi-device, testing) ----------------------- */
 
 /* Length in doubles of the packed moment buffer that is summed across devices:
-   [N, sum(u-s_u) (p), sum(g-s_g) (n), S_aa (p x p), S_ab (p x n), S_bb (n x n),
-    lagged sum q_r^2, lagged sum q_e^2 (data-metric sums of the previous step)]. */
+   [ N, sum(u-s_u) (p), S_aa (p x p) | sum(g-s_g) (n), S_ab (p x n), S_bb (n x n),
+     lagged sum q_r^2, lagged sum q_e^2 (data-metric sums of the previous step) ].
+   The first cesx_moments_uu_len() doubles depend on U alone. */
 size_t cesx_moments_len(cesx_handle h);
+size_t cesx_moments_uu_len(cesx_handle h);
 
 /* Row sums of this shard: sums_dev[0] = J_local, then sum_j U (p), sum_j G (n)
    (fp64).  After summing over devices pass the result to cesx_set_shift. */
@@ -168,6 +170,18 @@ int cesx_set_shift(cesx_handle h, const double* sums_dev, void* stream);
    metric sums of :432-435): shifted first and second moments of this shard in
    fp64 into mom_dev (cesx_moments_len doubles).  Additive over shards. */
 int cesx_moments(cesx_handle h, const void* U_dev, const void* G_dev, double* mom_dev, void* stream);
+
+/* The same in two pieces, so that chol(C) can start before the Gram is complete:
+   cesx_moments_uu fills the leading cesx_moments_uu_len() doubles (N, sum(u-s_u), S_aa -- all
+   that cov(U) of ces/calibrate.py:424/:476/:512 needs; a few entries of the second section
+   are written too when p is not a multiple of the MFMA tile); cesx_chol_async, called on the
+   (summed) leading part, forms C and starts L = chol(C) (:446/:487/:526) on the engine's side
+   stream; cesx_moments_rest fills the remainder while that runs; cesx_apply joins.
+   cesx_moments = cesx_moments_uu + cesx_moments_rest.  `update` is a CESX_UPDATE_* value
+   (it selects the covariance divisor J vs. J-1, :424 vs. :476). */
+int cesx_moments_uu(cesx_handle h, const void* U_dev, const void* G_dev, double* mom_dev, void* stream);
+int cesx_chol_async(cesx_handle h, int update, const double* mom_dev, void* stream);
+int cesx_moments_rest(cesx_handle h, const void* U_dev, const void* G_dev, double* mom_dev, void* stream);
 
 /* Second half: small dense algebra on the (summed) moments -- covariance,
    Cholesky, gain, time step (ces/calibrate.py:243-267, :437-446, :469-487) --

@@ -49,21 +49,39 @@ class FakeEngine:
         s = sums.numpy()
         self.shift = s[1:] / s[0]
 
-    def moments(self, U, G):
-        p, n = self.p, self.n_obs
+    # packed layout of include/cesx.h: [N, sum a, S_aa | sum b, S_ab, S_bb, lagged q sums]
+    def moments_uu_len(self):
+        return 1 + self.p + self.p * self.p
+
+    def moments_uu(self, U, G, out=None):
+        p = self.p
+        a = U.numpy() - self.shift[:p, None]
+        mom = torch.zeros(self.moments_len(), dtype=torch.float64) if out is None else out
+        mom[: self.moments_uu_len()] = torch.as_tensor(np.concatenate([[float(self.J)], a.sum(axis=1), (a @ a.T).ravel()]))
+        return mom
+
+    def chol_async(self, prm, mom):
+        pass                                     # the stand-in factors C inside apply()
+
+    def moments_rest(self, U, G, mom):
+        p = self.p
         a = U.numpy() - self.shift[:p, None]
         b = G.numpy() - self.shift[p:, None]
-        mom = np.concatenate([[float(self.J)], a.sum(axis=1), b.sum(axis=1), (a @ a.T).ravel(),
-                              (a @ b.T).ravel(), (b @ b.T).ravel(), self.metric_sums])
-        return torch.as_tensor(mom)
+        mom[self.moments_uu_len():] = torch.as_tensor(np.concatenate([b.sum(axis=1), (a @ b.T).ravel(), (b @ b.T).ravel(),
+                                                                       self.metric_sums]))
+        return mom
+
+    def moments(self, U, G):
+        return self.moments_rest(U, G, self.moments_uu(U, G))
 
     def _dense(self, prm, mom):
         p, n = self.p, self.n_obs
         m = mom.numpy()
         N = m[0]
-        sa, sb = m[1:1 + p], m[1 + p:1 + p + n]
-        o = 1 + p + n
+        sa = m[1:1 + p]
+        o = 1 + p
         Saa = m[o:o + p * p].reshape(p, p); o += p * p
+        sb = m[o:o + n]; o += n
         Sab = m[o:o + p * n].reshape(p, n); o += p * n
         Sbb = m[o:o + n * n].reshape(n, n); o += n * n
         lag = m[o:o + 2] / N

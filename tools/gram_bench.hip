@@ -5,8 +5,8 @@
 int main(int argc, char** argv) {
     using namespace cesx;
     const int p = 256, n = 256, P = 512; const long long J = 65536;
-    GramPlan pl = make_gram_plan(P, 32, GramCfg<float>::NBW, MAX_STAGE_ROWS);
-    int nslices = 256 / pl.ntypes; nslices -= nslices % 8;
+    GramPlan pl = make_gram_plan(P, 32, GramCfg<float>::NBW, MAX_STAGE_ROWS, argc > 1 ? atoi(argv[1]) : 0, 8);
+    int nslices = (argc > 2 ? atoi(argv[2]) : 256) / pl.ntypes; nslices -= nslices % 4;
     float *U, *G, *shift, *slabs; double* rsp; int *th, *rows, *wblk;
     hipMalloc(&U, p * J * 4); hipMalloc(&G, n * J * 4); hipMalloc(&shift, P * 4);
     hipMalloc(&slabs, (size_t)nslices * pl.nblocks * 1024 * 4); hipMalloc(&rsp, (size_t)nslices * P * 8);
