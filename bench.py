@@ -7,7 +7,8 @@
 A "step" is one pass of the hot path -- K1 moments, the all-reduce, K2 small
 dense algebra, K3 fused update with on-device noise, and the host's read of
 hk / metrics that the driver loop needs for its t_tol test
-(ces/calibrate.py:387) -- over one resident batch (U, G) of the synthetic
+(ces/calibrate.py:387; the read of step i overlaps the Gram of step i+1, as in
+ces_amd.dist.ShardedSampler.run) -- over one resident batch (U, G) of the synthetic
 linear-Gaussian problem of SURVEY.md 8(d).  Workload at every N: config C2 per
 GPU (J = 65 536 particles per GPU, p = n_obs = 256, fp32, ALDI, default
 Frobenius time step), i.e. weak scaling; N = 8 is config C3.  Inputs are in HBM
@@ -122,37 +123,64 @@ def main():
     torch.cuda.synchronize()
 
     t_hist = [0.0]
+    prm0 = engine.step_params(update=args.update)
 
-    def one_step(i):
+    # One step = begin (moments, all-reduce, chol: needs nothing from the previous step) + finish
+    # (K2 with t_last, K3) + the host's read of the step result, which the driver loop needs for
+    # its t_tol test (ces/calibrate.py:387).  The loop is software-pipelined the way
+    # ShardedSampler.run is: begin(i+1) is enqueued before result(i) is read, so the host's read
+    # overlaps the next Gram instead of idling the GPU.  Every timed step still does all of its
+    # work inside the timed region, and every result is read.
+    # HIP events around K1 / K3 cost ~4 us each (a barrier packet per record), so the live
+    # per-kernel durations are taken on every PROF_EVERY-th step of the timed region
+    PROF_EVERY = 4
+    prof = dict(on=False, steps=0)
+
+    def begin(i):
         U, G = batches[i % NB]
+        if prof["on"]:
+            eng.profile_enable(i % PROF_EVERY == 0)
+        sh.begin(prm0, U, G, recenter=(i == 0))
+
+    def finish(i):
+        U, G = batches[i % NB]
+        if prof["on"]:
+            eng.profile_enable(i % PROF_EVERY == 0)
+            prof["steps"] += int(i % PROF_EVERY == 0)
         prm = engine.step_params(update=args.update, first_step=(i == 0), t_len=min(i, 1), t_last=t_hist[0],
                                  step_index=i)
-        if world == 1:
-            eng.step(prm, U, G, xi=None, out=out, recenter=(i == 0))      # cesx_step: moments + apply in one call
-        else:
-            sh.step(prm, U, G, xi=None, out=out, recenter=(i == 0))       # moments -> all-reduce -> apply
-        res = eng.result()                     # the driver loop reads t every step (ces/calibrate.py:387)
-        t_hist[0] = res.t_new
+        sh.finish(prm, U, G, xi=None, out=out)
+
+    def run_steps(first, count):
+        begin(first)
+        res = None
+        for i in range(first, first + count):
+            finish(i)
+            if i + 1 < first + count:
+                begin(i + 1)
+            res = eng.result()
+            t_hist[0] = res.t_new
         return res
 
     # untimed pre-warm (clocks, code objects, allocator) before the W warmup steps
-    for i in range(8):
-        one_step(i)
+    run_steps(0, 8)
     t_hist[0] = 0.0
-    for i in range(args.warmup):
-        one_step(i)
-    eng.profile_enable(True)
+    if args.warmup:
+        run_steps(0, args.warmup)
+    eng.profile_enable(True)                    # creates the event pool outside the timed region
     eng.profile_read(0), eng.profile_read(1)
+    eng.profile_enable(False)
+    prof["on"] = not os.environ.get("CESX_BENCH_NOPROF")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        res = one_step(args.warmup + i)
+    res = run_steps(args.warmup, args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    prof["on"] = False
     eng.profile_enable(False)
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -170,11 +198,12 @@ def main():
 
     # algorithmic flops per launch: symmetric-aware Gram of the stacked
     # anomaly (p+n)^2 per particle; fused update GEMM 2 p (2p+n) per particle
+    nprof = max(prof["steps"], 1)
     kern = {
-        # per step: K1 is one launch; K3 is one launch, or two (drift part beside the Cholesky,
-        # then the noise part) -- their durations are summed
-        "gram_kernel(K1)": dict(ms=gram_ms / args.steps, flops=float(p + n) ** 2 * J, launches=gram_cnt / args.steps),
-        "update_kernel(K3)": dict(ms=upd_ms / args.steps, flops=2.0 * p * (2 * p + n) * J, launches=upd_cnt / args.steps),
+        # per step: K1 is two launches (U x U blocks, then the rest beside the Cholesky), K3 one
+        # (two for aldi_constant) -- the durations of a step's launches are summed
+        "gram_kernel(K1)": dict(ms=gram_ms / nprof, flops=float(p + n) ** 2 * J, launches=gram_cnt / nprof),
+        "update_kernel(K3)": dict(ms=upd_ms / nprof, flops=2.0 * p * (2 * p + n) * J, launches=upd_cnt / nprof),
     }
     for k in kern.values():
         k["tflops"] = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
@@ -189,7 +218,7 @@ def main():
             traffic = None
     roofline = dict(bound="mfma", kernel=dom, achieved=round(kern[dom]["tflops"], 2), peak=peak,
                     unit="TFLOP/s", frac=round(kern[dom]["tflops"] / peak, 4), traffic=traffic,
-                    avg_launch_ms=round(kern[dom]["ms"], 4),
+                    avg_launch_ms=round(kern[dom]["ms"], 4), profiled_steps=prof["steps"],
                     kernels={k: dict(avg_launch_ms=round(v["ms"], 4), launches_per_step=v["launches"],
                                      tflops=round(v["tflops"], 2), frac=round(v["tflops"] / peak, 4))
                              for k, v in kern.items()},

@@ -1,0 +1,466 @@
+// K3, fp32 fast path -- the same GEMM  U_next = W . [U ; G ; xi] + b 1^T  as kernels_update.hip
+// (ces/calibrate.py:443-447, :484-488, :515-527), restructured around the gfx950 LDS-DMA:
+//
+//  * W is read in "fragment-major" order (written that way by K2's assemble kernel): for every
+//    16-column k-tile, 16 pieces of 1 KiB; piece (g, rb) holds, lane by lane, the four A operands
+//    of k-steps 4g..4g+3 of row block rb.  One global_load_lds_dwordx4 per piece drops it into LDS
+//    exactly as the waves read it back (ds_read_b128, lane-linear, conflict-free).  A wave loads
+//    only the pieces it consumes itself.
+//  * [U; G] tiles (16 rows x 128 particles, 512-B row segments) go global -> LDS the same way,
+//    2 pieces per wave; no staging registers, no ds_write pass.
+//  * particle 4 li + c of the tile is column li of MFMA block c: one ds_read_b128 yields the B
+//    operands of all four blocks of a k-step, and the epilogue stores float4s.
+//  * 3-slot LDS ring, loads two tiles ahead, ONE raw s_barrier per k-tile with a counted
+//    s_waitcnt vmcnt(N) (the DMAs of the tile after next stay in flight across the barrier).
+//  * xi tiles: Philox4x32-10 + Box-Muller into the ring slot one tile ahead; the lower-triangular
+//    sqrt(2hk) L segment skips row blocks above the diagonal.
+//
+// All global -> LDS traffic is inline asm, so hipcc's own s_waitcnt bookkeeping never sees a DMA
+// (it would otherwise drain the ring with vmcnt(0) at the first ds_read of every tile).
+// Bound: MFMA (v_mfma_f32_32x32x2_f32).
+#include "cesx_internal.h"
+
+namespace cesx {
+
+constexpr int U2_THREADS = 256;
+constexpr int U2_BK = 16;            // k-tile
+constexpr int U2_BN = 128;           // particles per workgroup
+constexpr int U2_RC = 256;           // output rows per workgroup
+constexpr int U2_WSLOT = U2_RC * U2_BK * 4;      // 16 KiB
+constexpr int U2_XSLOT = U2_BK * U2_BN * 4;      // 8 KiB
+constexpr int U2_RING = 3;
+#ifndef U2_ABL      // timing ablations (tools/update2_bench.hip); results are wrong when set
+#define U2_ABL 0
+#endif
+
+struct Upd2Args {
+    const float* Wf; int nkt; int out_rows; const float* bias;
+    // K segments (no arrays: an indexable kernarg array sends the whole struct to scratch)
+    const float *src0, *src1, *src2; int rows0, rows1, rows2; int kt1, kt2;      // first k-tile of segments 1, 2 (INT_MAX: absent)
+    int kind0, kind1, kind2;
+    long long J, j_offset;
+    float* out;
+    const float* add1; const double* c1p; double c1i;
+    const float* add2; const double* c2p; double c2i;
+    double* absmax_part;
+    unsigned int seed_lo, seed_hi, step;
+    const float* rowc; double* metric_part; int metric_seg;
+    int tri_seg;
+};
+
+// one LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to lds_dst + 16 lane (M0 = the
+// wave-uniform LDS byte address; hipcc keeps nothing live in M0 across a statement)
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// wait until at most `n` of this wave's DMAs are outstanding, retire its LDS traffic, barrier
+__device__ __forceinline__ void ring_barrier(int n) {
+    if (n >= 6)      asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (n >= 2) asm volatile("s_waitcnt vmcnt(2)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else             asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// What the K loop needs to know about one k-tile, all wave-uniform (SGPRs); three of them (tiles
+// kt, kt+1, kt+2) rotate through the loop, so the segment arithmetic runs once per tile.
+struct TileD {
+    int valid;           // tile index < nkt
+    int noise;           // drawn in-kernel (else read from memory)
+    int r0;              // first row of the tile inside its segment
+    int rows;            // rows of the segment (rows >= r0 + 16 except in a ragged last tile)
+    const float* base;   // segment base pointer
+    int ndma;            // DMAs one wave issues for it
+};
+
+__device__ __forceinline__ TileD make_tile(int t, const Upd2Args& a) {
+    // branch-free selects (a ternary chain over loaded values becomes a lookup table in scratch)
+    const int b1 = t >= a.kt1 ? 1 : 0, b2 = t >= a.kt2 ? 1 : 0;
+    TileD d;
+    d.valid = t < a.nkt ? 1 : 0;
+    d.noise = (a.kind0 + b1 * (a.kind1 - a.kind0) + b2 * (a.kind2 - a.kind1)) != 0 ? 1 : 0;
+    d.r0 = (t - (b1 * a.kt1 + b2 * (a.kt2 - a.kt1))) * U2_BK;
+    d.rows = a.rows0 + b1 * (a.rows1 - a.rows0) + b2 * (a.rows2 - a.rows1);
+    const long long p0 = (long long)a.src0, p1 = (long long)a.src1, p2 = (long long)a.src2;
+    d.base = (const float*)(p0 + b1 * (p1 - p0) + b2 * (p2 - p1));
+    d.ndma = d.valid ? (((!d.noise && !(U2_ABL & 1)) ? 2 : 0) + ((U2_ABL & 2) ? 0 : 4)) : 0;
+    return d;
+}
+
+// One xi item (4 normals: rows 4q..4q+3 of one particle) generated in 7 stages, so that the
+// stages can sit between MFMA groups and run in their shadow (a wave issues in order: 32
+// back-to-back MFMAs followed by 150 VALU instructions overlap nothing).
+struct NoiseItem { uint32_t c0, c1, c2, c3, k0, k1; };
+__device__ __forceinline__ void noise_rounds2(NoiseItem& s) {
+    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint64_t p0 = (uint64_t)M0 * s.c0, p1 = (uint64_t)M1 * s.c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ s.c1 ^ s.k0, n2 = (uint32_t)(p0 >> 32) ^ s.c3 ^ s.k1;
+        s.c1 = (uint32_t)p1; s.c3 = (uint32_t)p0; s.c0 = n0; s.c2 = n2;
+        s.k0 += W0; s.k1 += W1;
+    }
+}
+// Box-Muller on one pair of the counter words (same arithmetic as normal4 in cesx_internal.h)
+__device__ __forceinline__ void noise_pair(uint32_t a, uint32_t b, float& z0, float& z1) {
+    const float sc = 5.9604644775390625e-08f;   // 2^-24
+    const float u0 = ((float)(a >> 8) + 0.5f) * sc, u1 = ((float)(b >> 8) + 0.5f) * sc;
+    const float ra = __builtin_sqrtf(-2.0f * __logf(u0));
+    z0 = ra * __builtin_amdgcn_cosf(u1);
+    z1 = ra * __builtin_amdgcn_sinf(u1);
+}
+
+__global__ __launch_bounds__(U2_THREADS, 2)
+void update2_kernel(const Upd2Args a) {
+    using acc_t = Mfma<float>::acc_t;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // [ W ring 3 x 16 KiB | X ring 3 x 8 KiB | rowc kn x 16 B ]
+    float* const sRowc = reinterpret_cast<float*>(smem + U2_RING * (U2_WSLOT + U2_XSLOT));
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
+
+#ifdef U2_CLOCKS
+    const long long clk0 = clock64(), wclk0 = wall_clock64();
+#endif
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const long long jt0 = (long long)blockIdx.x * U2_BN;
+    const int rc0 = blockIdx.y * U2_RC;
+    const int nkt = a.nkt;
+    // mirrored pair of row blocks (w, 7 - w): equal work for every wave in the triangular segment
+    const int rb0 = wave, rb1 = 7 - wave;
+    const bool on0 = rc0 + rb0 * 32 < a.out_rows, on1 = rc0 + rb1 * 32 < a.out_rows;
+    const int tri_t0 = a.tri_seg == 0 ? 0 : a.tri_seg == 1 ? a.kt1 : a.tri_seg == 2 ? a.kt2 : 0x7fffffff;
+    const int tri_t1 = a.tri_seg == 0 ? a.kt1 : a.tri_seg == 1 ? a.kt2 : a.tri_seg == 2 ? nkt : 0x7fffffff;
+    // last row of each block, relative to the triangular segment's first column
+    const int last0 = rc0 + rb0 * 32 + 31, last1 = rc0 + rb1 * 32 + 31;
+    const bool do_metrics = a.metric_part != nullptr && blockIdx.y == 0;
+    const int met_t0 = !do_metrics ? 0x7fffffff : a.metric_seg == 0 ? 0 : a.metric_seg == 1 ? a.kt1 : a.kt2;
+    const int met_t1 = !do_metrics ? 0x7fffffff : a.metric_seg == 0 ? (a.kt1 < nkt ? a.kt1 : nkt)
+                                                : a.metric_seg == 1 ? (a.kt2 < nkt ? a.kt2 : nkt) : nkt;
+
+    // this lane's column inside the tile, clamped for the ragged last workgroup (J % 4 == 0)
+    long long colc = jt0 + 4 * li;
+    if (colc > a.J - 4) colc = a.J - 4;
+    // fragment-major W: this lane's 16 bytes of piece 0 of tile 0; + t * 16 KiB + piece * 1 KiB
+    const char* const wlane = reinterpret_cast<const char*>(a.Wf) + ((size_t)blockIdx.y * nkt * 16) * 1024 + lane * 16;
+    const unsigned long long gj0 = (unsigned long long)(a.j_offset + jt0);
+
+    // LDS byte addresses of the ring slots (wave-uniform), rotated with the tiles
+    unsigned wsl0 = lds0, wsl1 = lds0 + U2_WSLOT, wsl2 = lds0 + 2 * U2_WSLOT;
+    unsigned xsl0 = lds0 + U2_RING * U2_WSLOT, xsl1 = xsl0 + U2_XSLOT, xsl2 = xsl0 + 2 * U2_XSLOT;
+    // the same slots as generic pointers for the ds_reads / noise stores
+#define U2_LDSP(addr) (smem + ((addr) - lds0))
+
+    // piece i of a tile (descriptor d, W image at wt) into ring slots (wsl, xsl):
+    // i = 0, 1: rows 2q, 2q+1 of the [U; G] tile for q = wave + 4 i; i = 2..5: the W pieces
+    // (g, rb) = (0, rb0), (0, rb1), (1, rb0), (1, rb1) that this wave alone consumes
+#define U2_PIECE(i, d, wt, wsl, xsl) do {                                                                   \
+        if ((d).valid) {                                                                                    \
+            if ((i) < 2) {                                                                                  \
+                if (!(d).noise && !(U2_ABL & 1)) {                                                          \
+                    const int q_ = wave + 4 * (i);                                                          \
+                    int row_ = (d).r0 + 2 * q_ + lh;                                                        \
+                    row_ = row_ < (d).rows ? row_ : (d).rows - 1;   /* padded rows meet zero columns of W */ \
+                    glds16((d).base + (size_t)row_ * a.J + colc, (xsl) + q_ * 1024);                        \
+                }                                                                                           \
+            } else if (!(U2_ABL & 2)) {                                                                     \
+                const int piece_ = (((i) - 2) >> 1) * 8 + ((((i) - 2) & 1) ? rb1 : rb0);                    \
+                glds16((wt) + piece_ * 1024, (wsl) + piece_ * 1024);                                        \
+            }                                                                                               \
+        }                                                                                                   \
+    } while (0)
+    // xi tile by Philox4x32-10 + Box-Muller into ring slot xsl: item = (row quad, particle), 2 per thread
+#define U2_NOISE(half, d, xsl) do {                                                                         \
+        float* X_ = reinterpret_cast<float*>(U2_LDSP(xsl));                                                 \
+        const int item_ = tid + U2_THREADS * (half);                                                        \
+        const int jl_ = item_ % U2_BN, ql_ = item_ / U2_BN;                                                 \
+        const unsigned long long gj_ = gj0 + jl_;                                                           \
+        const uint4x r_ = philox4x32_10((uint32_t)gj_, (uint32_t)(gj_ >> 32), (unsigned)((d).r0 / 4 + ql_), \
+                                        a.step, a.seed_lo, a.seed_hi);                                      \
+        float z_[4];                                                                                        \
+        normal4(r_, z_);                                                                                    \
+        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) X_[(4 * ql_ + e_) * U2_BN + jl_] = z_[e_];         \
+    } while (0)
+
+    // stage k (0..6) of the item of half `half` of the xi tile d (ring slot xsl), when `on`
+#define U2_NSTAGE(k, on, half, d, xsl, it) do { if (on) {                                                   \
+        const int item_ = tid + U2_THREADS * (half);                                                        \
+        const int jl_ = item_ % U2_BN, ql_ = item_ / U2_BN;                                                 \
+        if ((k) == 0) {                                                                                     \
+            const unsigned long long gj_ = gj0 + jl_;                                                       \
+            (it).c0 = (uint32_t)gj_; (it).c1 = (uint32_t)(gj_ >> 32);                                       \
+            (it).c2 = (unsigned)((d).r0 / 4 + ql_); (it).c3 = a.step;                                       \
+            (it).k0 = a.seed_lo; (it).k1 = a.seed_hi;                                                       \
+        }                                                                                                   \
+        if ((k) < 5) noise_rounds2(it);                                                                     \
+        else {                                                                                              \
+            float* X_ = reinterpret_cast<float*>(U2_LDSP(xsl)) + (4 * ql_ + ((k) == 5 ? 0 : 2)) * U2_BN + jl_; \
+            float z0_, z1_;                                                                                 \
+            if ((k) == 5) noise_pair((it).c0, (it).c1, z0_, z1_); else noise_pair((it).c2, (it).c3, z0_, z1_); \
+            X_[0] = z0_; X_[U2_BN] = z1_;                                                                   \
+        }                                                                                                   \
+    } } while (0)
+
+    acc_t acc[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[r][c][e] = 0;
+
+    if (do_metrics) {
+        const int rows4 = (met_t1 - met_t0) * U2_BK * 4;
+        for (int i = tid; i < rows4; i += U2_THREADS) sRowc[i] = a.rowc[i];
+    }
+    float mq_e[4] = {0, 0, 0, 0}, mq_r[4] = {0, 0, 0, 0};
+#ifdef U2_CLOCKS
+    long long clk_bar = 0, clk_loop0 = 0, clk_s1 = 0, clk_s2 = 0;
+#endif
+
+    // Software pipeline (one barrier B_kt per k-tile, in the MIDDLE of its MFMA stream):
+    //   first half of iteration kt : read F1 = fragments of k-steps 4..7 of tile kt; MFMAs of k-steps
+    //                                0..3 from F0, the DMAs of tile kt+2 issued one by one in their shadow
+    //   B_kt                       : counted vmcnt (tile kt+1 landed, tile kt+2 stays in flight), barrier
+    //   second half                : read F0 = fragments of k-steps 0..3 of tile kt+1; MFMAs 4..7 from F1
+    // so every ds_read has 32 MFMAs between issue and use.  Slot (kt+2) % 3 was last read before
+    // B_{kt-1}; tile kt+1 is read only after B_kt.
+#ifdef U2_STAGGER
+    // the two workgroups that share a CU start half a k-tile apart, so that one computes while
+    // the other waits / stages (dispatch order fills every CU once before the second round)
+    if (blockIdx.x * 2 >= gridDim.x) __builtin_amdgcn_s_sleep(U2_STAGGER);
+#endif
+    TileD d0 = make_tile(0, a), d1 = make_tile(1, a);
+    const char* wt = wlane;                       // W image of the tile being issued
+#pragma unroll
+    for (int i = 0; i < 6; ++i) U2_PIECE(i, d0, wt, wsl0, xsl0);
+    if (d0.valid && d0.noise) { U2_NOISE(0, d0, xsl0); U2_NOISE(1, d0, xsl0); }
+    wt += 16 * 1024;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) U2_PIECE(i, d1, wt, wsl1, xsl1);
+    ring_barrier(d1.ndma);
+    f4 f0b[4], f0a0, f0a1;
+    {
+        const float* X0 = reinterpret_cast<const float*>(U2_LDSP(xsl0));
+#pragma unroll
+        for (int v = 0; v < 4; ++v) f0b[v] = *reinterpret_cast<const f4*>(X0 + (2 * v + lh) * U2_BN + 4 * li);
+        f0a0 = *reinterpret_cast<const f4*>(U2_LDSP(wsl0) + rb0 * 1024 + lane * 16);
+        f0a1 = *reinterpret_cast<const f4*>(U2_LDSP(wsl0) + rb1 * 1024 + lane * 16);
+    }
+    if (d1.valid && d1.noise) U2_NOISE(0, d1, xsl1);
+
+#ifdef U2_CLOCKS
+    clk_loop0 = clock64();
+#endif
+#define U2_MFMA4(R, A, B) do { _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) \
+        acc[R][c_] = __builtin_amdgcn_mfma_f32_32x32x2f32(A, (B)[c_], acc[R][c_], 0, 0, 0); } while (0)
+    for (int kt = 0; kt < nkt; ++kt) {
+#ifdef U2_CLOCKS
+        if (kt == a.kt1) clk_s1 = clock64();
+        if (kt == a.kt2) clk_s2 = clock64();
+#endif
+        wt += 16 * 1024;
+        const TileD d2 = make_tile(kt + 2, a);
+        const bool intri = kt >= tri_t0 && kt < tri_t1;
+        const bool need0 = on0 && (!intri || last0 >= d0.r0);
+        const bool need1 = on1 && (!intri || last1 >= d0.r0);
+        const char* Wt = U2_LDSP(wsl0);
+        const float* Xt = reinterpret_cast<const float*>(U2_LDSP(xsl0));
+
+        f4 f1b[4], f1a0, f1a1;
+        if (U2_ABL & 4) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) f1b[v] = f0b[v] + 1.f;
+            f1a0 = f0a0 - 1.f; f1a1 = f0a1 + 2.f;
+        } else {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) f1b[v] = *reinterpret_cast<const f4*>(Xt + (2 * (4 + v) + lh) * U2_BN + 4 * li);
+            f1a0 = *reinterpret_cast<const f4*>(Wt + (8 + rb0) * 1024 + lane * 16);
+            f1a1 = *reinterpret_cast<const f4*>(Wt + (8 + rb1) * 1024 + lane * 16);
+        }
+        if (kt >= met_t0 && kt < met_t1) {
+            // data metrics of the G tile in this slot: thread = (row t/32 + 8h, 4 particles)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int rr = (tid >> 5) + 8 * h;
+                const f4 x = *reinterpret_cast<const f4*>(Xt + rr * U2_BN + 4 * (tid & 31));
+                const f4 rc = *reinterpret_cast<const f4*>(sRowc + (size_t)(d0.r0 + rr) * 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float b = x[c] - rc[0], r = x[c] - rc[1];
+                    mq_e[c] += rc[2] * b * b;
+                    mq_r[c] += rc[2] * r * r;
+                }
+            }
+        }
+        // first half: MFMAs of k-steps 0..3; in their shadow the DMAs of tile kt+2 and, stage by
+        // stage, the second xi item of tile kt+1
+        const bool g1 = d1.valid && d1.noise;
+        NoiseItem it;
+        if (need0) {
+            U2_MFMA4(0, f0a0[0], f0b[0]); U2_PIECE(0, d2, wt, wsl2, xsl2); U2_NSTAGE(0, g1, 1, d1, xsl1, it);
+            U2_MFMA4(0, f0a0[1], f0b[1]); U2_PIECE(1, d2, wt, wsl2, xsl2); U2_NSTAGE(1, g1, 1, d1, xsl1, it);
+            U2_MFMA4(0, f0a0[2], f0b[2]); U2_PIECE(2, d2, wt, wsl2, xsl2); U2_NSTAGE(2, g1, 1, d1, xsl1, it);
+            U2_MFMA4(0, f0a0[3], f0b[3]); U2_PIECE(3, d2, wt, wsl2, xsl2); U2_NSTAGE(3, g1, 1, d1, xsl1, it);
+        } else {
+            U2_PIECE(0, d2, wt, wsl2, xsl2); U2_PIECE(1, d2, wt, wsl2, xsl2);
+            U2_PIECE(2, d2, wt, wsl2, xsl2); U2_PIECE(3, d2, wt, wsl2, xsl2);
+            U2_NSTAGE(0, g1, 1, d1, xsl1, it); U2_NSTAGE(1, g1, 1, d1, xsl1, it);
+            U2_NSTAGE(2, g1, 1, d1, xsl1, it); U2_NSTAGE(3, g1, 1, d1, xsl1, it);
+        }
+        if (need1) {
+            U2_MFMA4(1, f0a1[0], f0b[0]); U2_PIECE(4, d2, wt, wsl2, xsl2); U2_NSTAGE(4, g1, 1, d1, xsl1, it);
+            U2_MFMA4(1, f0a1[1], f0b[1]); U2_PIECE(5, d2, wt, wsl2, xsl2); U2_NSTAGE(5, g1, 1, d1, xsl1, it);
+            U2_MFMA4(1, f0a1[2], f0b[2]); U2_NSTAGE(6, g1, 1, d1, xsl1, it);
+            U2_MFMA4(1, f0a1[3], f0b[3]);
+        } else {
+            U2_PIECE(4, d2, wt, wsl2, xsl2); U2_PIECE(5, d2, wt, wsl2, xsl2);
+            U2_NSTAGE(4, g1, 1, d1, xsl1, it); U2_NSTAGE(5, g1, 1, d1, xsl1, it); U2_NSTAGE(6, g1, 1, d1, xsl1, it);
+        }
+#ifdef U2_CLOCKS
+        const long long tb0 = clock64();
+#endif
+        if (!(U2_ABL & 8)) ring_barrier(d2.ndma);
+#ifdef U2_CLOCKS
+        clk_bar += clock64() - tb0;
+#endif
+        // second half
+        if (d1.valid && !(U2_ABL & 4)) {
+            const float* Xn = reinterpret_cast<const float*>(U2_LDSP(xsl1));
+#pragma unroll
+            for (int v = 0; v < 4; ++v) f0b[v] = *reinterpret_cast<const f4*>(Xn + (2 * v + lh) * U2_BN + 4 * li);
+            f0a0 = *reinterpret_cast<const f4*>(U2_LDSP(wsl1) + rb0 * 1024 + lane * 16);
+            f0a1 = *reinterpret_cast<const f4*>(U2_LDSP(wsl1) + rb1 * 1024 + lane * 16);
+        }
+        // ... MFMAs of k-steps 4..7, and the first xi item of tile kt+2
+        const bool g2 = d2.valid && d2.noise;
+        if (need0) {
+            U2_MFMA4(0, f1a0[0], f1b[0]); U2_NSTAGE(0, g2, 0, d2, xsl2, it);
+            U2_MFMA4(0, f1a0[1], f1b[1]); U2_NSTAGE(1, g2, 0, d2, xsl2, it);
+            U2_MFMA4(0, f1a0[2], f1b[2]); U2_NSTAGE(2, g2, 0, d2, xsl2, it);
+            U2_MFMA4(0, f1a0[3], f1b[3]); U2_NSTAGE(3, g2, 0, d2, xsl2, it);
+        } else {
+            U2_NSTAGE(0, g2, 0, d2, xsl2, it); U2_NSTAGE(1, g2, 0, d2, xsl2, it);
+            U2_NSTAGE(2, g2, 0, d2, xsl2, it); U2_NSTAGE(3, g2, 0, d2, xsl2, it);
+        }
+        if (need1) {
+            U2_MFMA4(1, f1a1[0], f1b[0]); U2_NSTAGE(4, g2, 0, d2, xsl2, it);
+            U2_MFMA4(1, f1a1[1], f1b[1]); U2_NSTAGE(5, g2, 0, d2, xsl2, it);
+            U2_MFMA4(1, f1a1[2], f1b[2]); U2_NSTAGE(6, g2, 0, d2, xsl2, it);
+            U2_MFMA4(1, f1a1[3], f1b[3]);
+        } else {
+            U2_NSTAGE(4, g2, 0, d2, xsl2, it); U2_NSTAGE(5, g2, 0, d2, xsl2, it); U2_NSTAGE(6, g2, 0, d2, xsl2, it);
+        }
+        // rotate tiles and ring slots
+        d0 = d1; d1 = d2;
+        { const unsigned t_ = wsl0; wsl0 = wsl1; wsl1 = wsl2; wsl2 = t_; }
+        { const unsigned t_ = xsl0; xsl0 = xsl1; xsl1 = xsl2; xsl2 = t_; }
+    }
+#ifdef U2_CLOCKS
+    const long long clk_loop1 = clock64();
+#endif
+    // the last iteration's barrier had nothing in flight; one more so that the ring can be reused
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    // epilogue: lane holds, for row (e&3) + 8 (e>>2) + 4 lh of each of its blocks, particles 4 li .. 4 li + 3
+    const double c1 = a.add1 ? (a.c1p ? *a.c1p * a.c1i : a.c1i) : 0.0;
+    const double c2 = a.add2 ? (a.c2p ? *a.c2p * a.c2i : a.c2i) : 0.0;
+    const long long j = jt0 + 4 * li;
+    float amax = 0.f;
+    if (j < a.J) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int rb = r == 0 ? rb0 : rb1;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int i = rc0 + rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (i < a.out_rows) {
+                    const float bi = a.bias ? a.bias[i] : 0.f;
+                    const size_t o = (size_t)i * a.J + j;
+                    f4 v = {acc[r][0][e] + bi, acc[r][1][e] + bi, acc[r][2][e] + bi, acc[r][3][e] + bi};
+                    if (a.add1) v += (float)c1 * *reinterpret_cast<const f4*>(a.add1 + o);
+                    if (a.add2) v += (float)c2 * *reinterpret_cast<const f4*>(a.add2 + o);
+                    *reinterpret_cast<f4*>(a.out + o) = v;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float av = v[c] < 0 ? -v[c] : v[c];
+                        amax = av > amax ? av : amax;
+                    }
+                }
+            }
+        }
+    }
+    if (do_metrics) {
+        // combine the 8 row groups of every particle through LDS (the ring is idle now)
+        float* comb = reinterpret_cast<float*>(smem);            // [2][8][128]
+        const int grp = tid >> 5;
+        *reinterpret_cast<f4*>(comb + grp * U2_BN + 4 * (tid & 31)) = f4{mq_e[0], mq_e[1], mq_e[2], mq_e[3]};
+        *reinterpret_cast<f4*>(comb + 8 * U2_BN + grp * U2_BN + 4 * (tid & 31)) = f4{mq_r[0], mq_r[1], mq_r[2], mq_r[3]};
+        __syncthreads();
+        double se = 0.0, sr = 0.0;
+        if (tid < U2_BN && jt0 + tid < a.J) {
+            float qe = 0, qr = 0;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) { qe += comb[g * U2_BN + tid]; qr += comb[8 * U2_BN + g * U2_BN + tid]; }
+            se = (double)qe * (double)qe;
+            sr = (double)qr * (double)qr;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { se += __shfl_down(se, o, 64); sr += __shfl_down(sr, o, 64); }
+        __syncthreads();
+        double* redm = reinterpret_cast<double*>(smem);
+        if (lane == 0) { redm[wave] = sr; redm[4 + wave] = se; }
+        __syncthreads();
+        if (tid == 0) {
+            a.metric_part[blockIdx.x * 2 + 0] = redm[0] + redm[1] + redm[2] + redm[3];
+            a.metric_part[blockIdx.x * 2 + 1] = redm[4] + redm[5] + redm[6] + redm[7];
+        }
+        __syncthreads();
+    }
+    if (a.absmax_part) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float other = __shfl_down(amax, o, 64);
+            amax = other > amax ? other : amax;
+        }
+        double* red = reinterpret_cast<double*>(smem) + 16;
+        if (lane == 0) red[wave] = (double)amax;
+        __syncthreads();
+        if (tid == 0) {
+            double m = red[0];
+            for (int w = 1; w < U2_THREADS / 64; ++w) m = red[w] > m ? red[w] : m;
+            a.absmax_part[blockIdx.y * gridDim.x + blockIdx.x] = m;
+        }
+    }
+#ifdef U2_CLOCKS
+    if (tid == 0 && a.metric_part) {      // dev instrumentation: core-clock and 100 MHz wall-clock ticks of this workgroup
+        a.metric_part[blockIdx.x * 2 + 0] = (double)(clock64() - clk0);
+        a.metric_part[blockIdx.x * 2 + 1] = (double)(wall_clock64() - wclk0);
+        a.metric_part[8192 + blockIdx.x * 2 + 0] = (double)clk_bar;
+        a.metric_part[8192 + blockIdx.x * 2 + 1] = (double)(clk_loop1 - clk_loop0);
+        a.metric_part[16384 + blockIdx.x * 2 + 0] = (double)(clk_loop0 - clk0);
+        a.metric_part[16384 + blockIdx.x * 2 + 1] = (double)(wclk0 % 100000);
+        a.metric_part[24576 + blockIdx.x * 2 + 0] = (double)(clk_s1 - clk_loop0);
+        a.metric_part[24576 + blockIdx.x * 2 + 1] = (double)(clk_s2 - clk_s1);
+    }
+#endif
+#undef U2_PIECE
+#undef U2_NSTAGE
+#undef U2_NOISE
+#undef U2_MFMA4
+#undef U2_LDSP
+}
+
+// index of W[i][k] (row i of the zero-padded rpad x ktot matrix) in the fragment-major image
+__host__ __device__ inline size_t wf_index(int i, int k, int nkt) {
+    const int y = i >> 8, rb = (i >> 5) & 7, li = i & 31;
+    const int kt = k >> 4, kk = k & 15, m = kk >> 1, lh = kk & 1, g = m >> 2, v = m & 3;
+    return ((((size_t)y * nkt + kt) * 16 + g * 8 + rb) * 64 + lh * 32 + li) * 4 + v;
+}
+
+int update2_lds_bytes(int kn) { return U2_RING * (U2_WSLOT + U2_XSLOT) + kn * 16; }
+
+}  // namespace cesx

@@ -56,8 +56,12 @@ class ShardedUpdate:
         self.engine.set_shift(sums)
         self._recentered = True
 
-    def step(self, prm, U, G, xi=None, out=None, recenter=False):
-        """moments -> all-reduce -> apply on this rank's shard.  Returns U_next."""
+    def begin(self, prm, U, G, recenter=False):
+        """First half of a step: everything that does not need the pseudo-time of the previous
+        step -- the moments, their all-reduce and chol(C).  Only ``prm.update`` is read, so a
+        driver may enqueue ``begin`` of step i+1 BEFORE it reads the result of step i: the
+        host's read (ces/calibrate.py:387 tests ``t`` every iteration) then overlaps the Gram
+        of the next step instead of idling the GPU."""
         eng = self.engine
         if recenter or not self._recentered:
             self.recenter(U, G)
@@ -67,11 +71,22 @@ class ShardedUpdate:
         eng.chol_async(prm, mom)                # C, then L = chol(C) on the side stream ...
         eng.moments_rest(U, G, mom)             # ... beside the rest of the Gram
         self._all_reduce(mom[nuu:])
+        self._mom = mom
+        return mom
+
+    def finish(self, prm, U, G, xi=None, out=None):
+        """Second half: K2 with this step's parameters (t_last, time-step rule) and K3."""
+        eng, mom = self.engine, self._mom
         if prm.update == 2:                     # aldi_constant: max|drift| over all shards
             out = eng.empty(eng.p) if out is None else out
             absmax = self._all_reduce(eng.apply_drift(prm, mom, U, G, out), op=dist.ReduceOp.MAX)
             return eng.apply_finish(prm, absmax, U, xi, out)
         return eng.apply(prm, mom, U, G, xi=xi, out=out)
+
+    def step(self, prm, U, G, xi=None, out=None, recenter=False):
+        """moments -> all-reduce -> apply on this rank's shard.  Returns U_next."""
+        self.begin(prm, U, G, recenter=recenter)
+        return self.finish(prm, U, G, xi=xi, out=out)
 
     def result(self):
         """Result of the last step.  On more than one rank ``bias_data`` /
@@ -121,15 +136,28 @@ class ShardedSampler:
         eng.set_problem(y_obs, Gamma, mu, sigma, ustar)
         U = eng.to_device(U_shard)
         res = None
+        # With a device-side forward map nothing in an iteration needs the host until the t_tol
+        # test, so the first half of step i+1 (forward map, moments, all-reduce, chol) is enqueued
+        # before the result of step i is read; if the run stops there, that work is discarded.
+        pipelined = hasattr(model, "forward_device")
+        prm0 = step_params(update=update, T=self.T)
+        G = self._forward(model, U)
+        if pipelined:
+            self.sh.begin(prm0, U, G, recenter=True)
         for i in range(self.T):
-            G = self._forward(model, U)
             t = m["t"]
             prm = step_params(update=update, time_step=kwargs.get("time_step"), first_step=(i == 0 and not t),
                               t_len=len(t), t_last=t[-1] if t else 0.0, delta_t=kwargs.get("delta_t"),
                               spinup=kwargs.get("spinup", 4.0), switch=kwargs.get("switch", 1.0),
                               step_index=i, T=self.T)
             xi = None if xis is None else eng.to_device(xis[i])
-            U = self.sh.step(prm, U, G, xi=xi, recenter=(i == 0))
+            if pipelined:
+                U = self.sh.finish(prm, U, G, xi=xi)
+                if i + 1 < self.T:
+                    G = self._forward(model, U)
+                    self.sh.begin(prm0, U, G)
+            else:
+                U = self.sh.step(prm, U, G, xi=xi, recenter=(i == 0))
             res = self.sh.result()
             m["self-bias"].append(res.self_bias)
             m["bias"].append(res.bias)
@@ -144,6 +172,8 @@ class ShardedSampler:
                 m["self-bias-data"].append(res.lag_self_bias_data)
             if m["t"][-1] > kwargs.get("t_tol", 2.0):
                 break
+            if not pipelined and i + 1 < self.T:
+                G = self._forward(model, U)
         if self.sh.world > 1 and res is not None:
             bd, sbd = self.sh.flush_data_metrics(res)
             m["bias-data"].append(bd)

@@ -35,7 +35,7 @@ def _problem(p, n, J, T, seed=3):
     return dict(A=A, ustar=ustar, Gamma=Gamma, sigma=sigma, mu=mu, y=y, U0=U0, xis=xis)
 
 
-def _worker(rank, world, port, update, kwargs, q):
+def _worker(rank, world, port, update, kwargs, q, device_hook=False):
     sys.path.insert(0, ROOT)
     from ces_amd.dist import ShardedSampler, shard_range
     from ces_amd.utils import lineal
@@ -52,7 +52,10 @@ def _worker(rank, world, port, update, kwargs, q):
 
         def __call__(self, theta):
             return lineal(d["A"])(theta)
-    model = HostLineal()
+    class HookLineal(HostLineal):            # with a shard-wide hook ShardedSampler pipelines the loop:
+        def forward_device(self, engine, U):  # begin(i+1) is enqueued before result(i) is read
+            return engine.to_device(d["A"] @ U.numpy())
+    model = HookLineal() if device_hook else HostLineal()
     try:
         U = smp.run(d["y"], d["U0"][:, lo:hi], model, d["Gamma"], d["mu"], d["sigma"], d["ustar"],
                     update=update, xis=d["xis"][:, :, lo:hi], t_tol=1e9, **kwargs)
@@ -65,14 +68,16 @@ def _worker(rank, world, port, update, kwargs, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("update,kwargs", [("aldi", {}), ("eks", {"time_step": "constant", "delta_t": 0.01}),
-                                           ("aldi_constant", {"switch": 0.5}), ("aldi", {"time_step": "spectral"})])
-def test_two_ranks_match_single_process_oracle(update, kwargs):
+@pytest.mark.parametrize("update,kwargs,hook", [("aldi", {}, False), ("eks", {"time_step": "constant", "delta_t": 0.01}, False),
+                                                ("aldi_constant", {"switch": 0.5}, False),
+                                                ("aldi", {"time_step": "spectral"}, False),
+                                                ("aldi", {}, True), ("aldi_constant", {"switch": 0.5}, True)])
+def test_two_ranks_match_single_process_oracle(update, kwargs, hook):
     from oracle import ces_numpy as oc
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, update, kwargs, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, update, kwargs, q, hook)) for r in range(world)]
     for pr in procs:
         pr.start()
     full, metrics, radspec = q.get(timeout=120)

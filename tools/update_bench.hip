@@ -2,9 +2,14 @@
 #include "../ces_amd/csrc/kernels_update.hip"
 #include <cstdio>
 #include <vector>
+#include <cstring>
+#include <cstdlib>
+static bool flag(int argc, char** argv, const char* f) { for (int i = 1; i < argc; ++i) if (!strcmp(argv[i], f)) return true; return false; }
 int main(int argc, char** argv) {
     using namespace cesx;
-    const int p = 256, n = 256; const long long J = 65536;
+    const int p = 256, n = 256; long long J = 65536;
+    for (int i = 1; i + 1 < argc; ++i) if (!strcmp(argv[i], "J")) J = atoll(argv[i + 1]);
+    const bool f_mem = flag(argc, argv, "mem"), f_nomet = flag(argc, argv, "nomet"), f_notri = flag(argc, argv, "notri");
     const int kp = 256, kn = 256, ktot = 768, rpad = 256;
     float *U, *G, *W, *bias, *out, *rowc; double* mpart;
     hipMalloc(&U, p * J * 4); hipMalloc(&G, n * J * 4); hipMalloc(&out, p * J * 4);
@@ -18,10 +23,9 @@ int main(int argc, char** argv) {
     UpdArgs<float> a{};
     a.W = W; a.ktot = ktot; a.ldw = ktot; a.bias = bias; a.out_rows = p;
     a.src[0] = U; a.src[1] = G; a.src[2] = nullptr; a.src_rows[0] = p; a.src_rows[1] = n; a.src_rows[2] = p;
-    a.src_k0[0] = 0; a.src_k0[1] = kp; a.src_k0[2] = kp + kn; a.src_kind[0] = 0; a.src_kind[1] = 0; a.src_kind[2] = argc > 1 ? 0 : 1;
-    if (argc > 1) a.src[2] = U;
-    if (argc > 3) { a.ktot = 1536; a.ldw = 1536; a.src_rows[0] = a.src_rows[1] = a.src_rows[2] = 512; a.src_k0[1] = 512; a.src_k0[2] = 1024; hipFree(W); hipMalloc(&W, rpad * 1536 * 4); hipMemset(W, 0, rpad * 1536 * 4); a.W = W; }
-    a.nsrc = 3; a.J = J; a.j_offset = 0; a.out = out; a.rowc = rowc; a.metric_part = argc > 2 ? nullptr : mpart; a.metric_seg = 1; a.tri_seg = argc > 4 ? -1 : 2;
+    a.src_k0[0] = 0; a.src_k0[1] = kp; a.src_k0[2] = kp + kn; a.src_kind[0] = 0; a.src_kind[1] = 0; a.src_kind[2] = f_mem ? 0 : 1;
+    if (f_mem) a.src[2] = U;
+    a.nsrc = 3; a.J = J; a.j_offset = 0; a.out = out; a.rowc = rowc; a.metric_part = f_nomet ? nullptr : mpart; a.metric_seg = 1; a.tri_seg = f_notri ? -1 : 2;
     a.seed_lo = 1; a.seed_hi = 2; a.step = 3;
     using C = UpdCfg<float>;
     constexpr int RC = 4 * C::WR * 32, BN = C::WC * 32;
@@ -35,7 +39,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, grid, dim3(UPD_THREADS), lds, 0, a);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    printf("ABL=%d xi=%s metrics=%s: %.1f us/launch  (%.1f TF algorithmic)\n", UPD_ABL, argc > 1 ? "mem" : "philox", argc > 2 ? "off" : "on",
+    printf("ABL=%d J=%lld xi=%s metrics=%s tri=%s: %.1f us/launch  (%.1f TF algorithmic)\n", UPD_ABL, J, f_mem ? "mem" : "philox", f_nomet ? "off" : "on", f_notri ? "off" : "on",
            ms * 100.0, 2.0 * p * a.ktot * J / (ms * 1e-4) / 1e12);
     return 0;
 }
