@@ -221,6 +221,9 @@ struct Engine {
     // update coefficients (engine dtype)
     int bk = 16, kp = 0, kn = 0, ktot = 0, rpad = 0;
     void* d_W = nullptr;           // [rpad][ktot]
+    void* d_Wf = nullptr;          // fp32 engines: the same matrix in the fragment-major order of kernels_update2.hip
+    bool update_v2 = true;         // fp32 K3 through the LDS-DMA kernel (CESX_UPDATE_V1=1 switches back)
+    int num_cus = 256;
     void* d_bias = nullptr;        // [rpad]
     void* d_Wfwd = nullptr;        // forward-map staging [npad][kp]
     // per-kernel profiling (cesx_profile_*)
@@ -259,6 +262,7 @@ struct UpdateOpt {
     int ldw = 0;          // row stride of W (0: = ktot)
     bool narrow = false;  // narrow particle tile (more, shorter workgroups)
     int metric_seg = 1;   // K-segment that holds G (data metrics)
+    const void* wf = nullptr;  // fragment-major copy of the WHOLE W (fp32): enables the LDS-DMA kernel
     int prof = -1;        // profiling slot (1 = K3) or -1
 };
 int launch_update(Engine& e, int out_rows, const void* W, int ktot, const void* bias,
@@ -268,6 +272,21 @@ int launch_update(Engine& e, int out_rows, const void* W, int ktot, const void* 
                   void* out, double* absmax_part, uint64_t step_index, bool metrics,
                   const UpdateOpt& opt, hipStream_t s);
 int update_grid_blocks(Engine& e, int out_rows);
+// kernels_update2.hip: returns CESX_OK, an error, or -1 when the launch does not qualify (caller falls back)
+int launch_update2(Engine& e, int out_rows, const void* Wf, int ktot, const void* bias,
+                   const UpdateSrc* src, int nsrc,
+                   const void* add1, const double* c1, double c1_imm,
+                   const void* add2, const double* c2, double c2_imm,
+                   void* out, double* absmax_part, uint64_t step_index, bool metrics,
+                   const UpdateOpt& opt, hipStream_t s);
+// index of W[i][k] (row i of the zero-padded rpad x ktot matrix, nkt = ktot / 16) in the fragment-major
+// image: for every 256-row chunk y and k-tile kt, 16 pieces (g, rb) of 64 lanes x 4 floats; lane
+// (lh, li) of piece (g, rb) holds W[256 y + 32 rb + li][16 kt + 2 (4 g + v) + lh], v = 0..3
+__host__ __device__ inline size_t wf_index(int i, int k, int nkt) {
+    const int y = i >> 8, rb = (i >> 5) & 7, li = i & 31;
+    const int kt = k >> 4, kk = k & 15, m = kk >> 1, lh = kk & 1, g = m >> 2, v = m & 3;
+    return ((((size_t)y * nkt + kt) * 16 + g * 8 + rb) * 64 + lh * 32 + li) * 4 + v;
+}
 int launch_data_metrics(Engine& e, const void* G, hipStream_t s);   // dense Gamma: separate pass
 int launch_metric_final(Engine& e, const double* mom, bool publish, hipStream_t s);
 int launch_publish(Engine& e, hipStream_t s);

@@ -106,6 +106,7 @@ int run_update_main(Engine& e, const cesx_step_params& prm, const void* U, const
     UpdateSrc src[3] = {{U, e.p, 0, 0}, {G, e.n, 0, 0}, {xi, e.p, xi ? 0 : 1, 1}};
     UpdateOpt opt;
     opt.prof = 1;
+    opt.wf = e.d_Wf;
     int rc = launch_update(e, e.p, e.d_W, e.ktot, e.d_bias, src, 3, nullptr, nullptr, 0.0, nullptr, nullptr, 0.0,
                            Unext, nullptr, prm.step_index, e.diag_gamma, opt, s);
     e.last_metric_parts = e.last_update_grid_x;
@@ -165,9 +166,14 @@ int cesx_create(const cesx_config* cfg, cesx_handle* out) {
     e.esz = cfg->dtype == CESX_F32 ? 4 : 8;
     if (const char* ov = std::getenv("CESX_OVERLAP")) e.overlap_chol = ov[0] != '0';
     if (const char* sv = std::getenv("CESX_SPLIT_UPDATE")) e.split_update = sv[0] != '0';
+    if (const char* uv = std::getenv("CESX_UPDATE_V1")) e.update_v2 = uv[0] == '0';
     auto fail = [&](int rc) { g_create_err = e.err; cesx_destroy(reinterpret_cast<cesx_handle>(ep)); return rc; };
     int rc;
     if ((rc = set_device(e))) return fail(rc);
+    {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && ncu > 0) e.num_cus = ncu;
+    }
     const int p = e.p, n = e.n, P = e.P, mx = p > n ? p : n;
     const size_t pp = (size_t)p * p, pn = (size_t)p * n, nn = (size_t)n * n;
     const size_t mm = (size_t)potrf_ld(mx) * potrf_ld(mx);     // temporaries also hold padded Cholesky factors
@@ -218,6 +224,7 @@ int cesx_create(const cesx_config* cfg, cesx_handle* out) {
             DM(t, (size_t)e.gp[part].nslices * pl.nblocks * pl.tile * pl.tile * e.esz); e.gp[part].d_slabs = t;
         }
         DM(t, (size_t)e.rpad * e.ktot * e.esz); e.d_W = t;
+        if (e.cfg.dtype == CESX_F32) { DM(t, (size_t)e.rpad * e.ktot * e.esz); e.d_Wf = t; }
         DM(t, (size_t)e.rpad * e.esz); e.d_bias = t;
         DM(t, (size_t)e.rpad * e.kp * e.esz); e.d_Wfwd = t;
     }
@@ -265,7 +272,7 @@ void cesx_destroy(cesx_handle h) {
     Engine& e = *reinterpret_cast<Engine*>(h);
     (void)hipSetDevice(e.cfg.device);
     void* ptrs[] = {e.d_y, e.d_mu, e.d_ustar, e.d_Gamma, e.d_Ginv, e.d_gw, e.d_Wh, e.d_Sigma, e.d_Sinv, e.d_sw,
-                    e.d_shift64, e.d_shiftT, e.d_yT, e.d_gwT, e.d_GinvT, e.d_wdT, e.d_W,
+                    e.d_shift64, e.d_shiftT, e.d_yT, e.d_gwT, e.d_GinvT, e.d_wdT, e.d_W, e.d_Wf,
                     e.d_bias, e.d_Wfwd, e.d_metric_part, e.d_metric_sums,
                     e.d_gbarT, e.d_rowc,
                     e.d_colsum_part, e.d_mom,
@@ -387,6 +394,7 @@ int cesx_apply_drift(cesx_handle h, const cesx_step_params* prm, const double* m
     TRY(launch_dense(e, *prm, mom, 1, s));
     UpdateSrc src[2] = {{U, e.p, 0, 0}, {G, e.n, 0, 0}};
     UpdateOpt opt;
+    opt.wf = e.d_Wf;
     TRY(launch_update(e, e.p, e.d_W, e.kp + e.kn, e.d_bias, src, 2, nullptr, nullptr, 0.0, nullptr, nullptr, 0.0,
                       Unext, e.d_absmax_part, prm->step_index, e.diag_gamma, opt, s));
     e.last_metric_parts = e.last_update_grid_x;
@@ -408,6 +416,7 @@ int cesx_apply_finish(cesx_handle h, const cesx_step_params* prm, const double* 
     // U_next = sqrt(2hk) L xi + 1 * U + hk * drift   (drift currently lives in U_next)
     UpdateSrc src[1] = {{xi, e.p, xi ? 0 : 1, 1}};
     UpdateOpt opt;
+    opt.wf = e.d_Wf;
     TRY(launch_update(e, e.p, e.d_W, e.kp, nullptr, src, 1, U, nullptr, 1.0, Unext, &e.d_scal->hk, 1.0, Unext,
                       nullptr, prm->step_index, false, opt, s));
     return finish_step(e, *prm, s);

@@ -693,7 +693,7 @@ __global__ void assemble_kernel(int mode, int part, int p, int n, int kp, int kn
                                 const double* __restrict__ gbar, const double* __restrict__ y,
                                 const double* __restrict__ gw, T* __restrict__ W, T* __restrict__ bias,
                                 T* __restrict__ shiftT, double* __restrict__ shift64, T* __restrict__ rowc,
-                                T* __restrict__ gbarT) {
+                                T* __restrict__ gbarT, float* __restrict__ Wf) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const double hk = sc->hk, s2 = sc->sqrt2hk, al = sc->alpha;
     const double* Ky = mvs;            // K y
@@ -730,6 +730,7 @@ __global__ void assemble_kernel(int mode, int part, int p, int n, int kp, int kn
             }
         }
         W[idx] = (T)v;
+        if (Wf) Wf[wf_index(i, k, ktot / 16)] = (float)v;     // fragment-major copy for the fp32 LDS-DMA kernel
     }
     if (part == 2) return;
     if (idx < rpad) {
@@ -836,7 +837,8 @@ static int assemble(Engine& e, hipStream_t s, int mode, int ktot, double sw, int
     hipLaunchKernelGGL(assemble_kernel<T>, g1(len), dim3(256), 0, s, mode, part, e.p, e.n, e.kp, e.kn, e.rpad, ktot,
                        sw, e.d_scal, e.d_M, e.d_K, e.d_L, potrf_ld(e.p), e.d_P, e.d_PK, e.d_mv, mx, e.d_ubar, e.d_gbar,
                        e.d_y, e.diag_gamma ? e.d_gw : (const double*)nullptr, (T*)e.d_W, (T*)e.d_bias,
-                       (T*)e.d_shiftT, e.d_shift64, (T*)e.d_rowc, (T*)e.d_gbarT);
+                       (T*)e.d_shiftT, e.d_shift64, (T*)e.d_rowc, (T*)e.d_gbarT,
+                       sizeof(T) == 4 ? (float*)e.d_Wf : (float*)nullptr);
     CESX_HIP(hipGetLastError());
     return CESX_OK;
 }

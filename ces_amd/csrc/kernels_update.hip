@@ -450,6 +450,12 @@ int launch_update(Engine& e, int out_rows, const void* W, int ktot, const void* 
                   const UpdateSrc* src, int nsrc, const void* add1, const double* c1, double c1_imm,
                   const void* add2, const double* c2, double c2_imm, void* out, double* absmax_part,
                   uint64_t step_index, bool metrics, const UpdateOpt& opt, hipStream_t s) {
+    if (opt.wf && e.update_v2) {
+        // fp32 fast path (kernels_update2.hip); -1 = this launch does not qualify
+        const int rc = launch_update2(e, out_rows, opt.wf, ktot, bias, src, nsrc, add1, c1, c1_imm, add2, c2, c2_imm, out,
+                                      absmax_part, step_index, metrics, opt, s);
+        if (rc != -1) return rc;
+    }
     return e.cfg.dtype == CESX_F32
         ? update_t<float>(e, out_rows, W, ktot, bias, src, nsrc, add1, c1, c1_imm, add2, c2, c2_imm, out, absmax_part, step_index, metrics, opt, s)
         : update_t<double>(e, out_rows, W, ktot, bias, src, nsrc, add1, c1, c1_imm, add2, c2, c2_imm, out, absmax_part, step_index, metrics, opt, s);

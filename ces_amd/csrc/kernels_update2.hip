@@ -46,6 +46,7 @@ struct Upd2Args {
     unsigned int seed_lo, seed_hi, step;
     const float* rowc; double* metric_part; int metric_seg;
     int tri_seg;
+    int stagger_from;     // workgroups with a linear index >= this start late (see the kernel)
 };
 
 // one LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to lds_dst + 16 lane (M0 = the
@@ -228,11 +229,14 @@ void update2_kernel(const Upd2Args a) {
     //   second half                : read F0 = fragments of k-steps 0..3 of tile kt+1; MFMAs 4..7 from F1
     // so every ds_read has 32 MFMAs between issue and use.  Slot (kt+2) % 3 was last read before
     // B_{kt-1}; tile kt+1 is read only after B_kt.
-#ifdef U2_STAGGER
-    // the two workgroups that share a CU start half a k-tile apart, so that one computes while
-    // the other waits / stages (dispatch order fills every CU once before the second round)
-    if (blockIdx.x * 2 >= gridDim.x) __builtin_amdgcn_s_sleep(U2_STAGGER);
-#endif
+    // The two workgroups that share a CU start ~12k cycles apart: all workgroups have the same
+    // amount of work, so without this they all reach the 128-KiB store epilogue together and the
+    // matrix pipes idle while HBM drains; staggered, one workgroup's stores (and barrier / staging
+    // stalls) are covered by the other's MFMAs (-3 % at C2).
+    if ((int)(blockIdx.y * gridDim.x + blockIdx.x) >= a.stagger_from) {
+        __builtin_amdgcn_s_sleep(100);
+        __builtin_amdgcn_s_sleep(100);
+    }
     TileD d0 = make_tile(0, a), d1 = make_tile(1, a);
     const char* wt = wlane;                       // W image of the tile being issued
 #pragma unroll
@@ -454,13 +458,58 @@ void update2_kernel(const Upd2Args a) {
 #undef U2_LDSP
 }
 
-// index of W[i][k] (row i of the zero-padded rpad x ktot matrix) in the fragment-major image
-__host__ __device__ inline size_t wf_index(int i, int k, int nkt) {
-    const int y = i >> 8, rb = (i >> 5) & 7, li = i & 31;
-    const int kt = k >> 4, kk = k & 15, m = kk >> 1, lh = kk & 1, g = m >> 2, v = m & 3;
-    return ((((size_t)y * nkt + kt) * 16 + g * 8 + rb) * 64 + lh * 32 + li) * 4 + v;
+int launch_update2(Engine& e, int out_rows, const void* Wf, int ktot, const void* bias,
+                   const UpdateSrc* src, int nsrc,
+                   const void* add1, const double* c1, double c1_imm,
+                   const void* add2, const double* c2, double c2_imm,
+                   void* out, double* absmax_part, uint64_t step_index, bool metrics,
+                   const UpdateOpt& opt, hipStream_t s) {
+    // qualifies: fp32, whole W, 16-byte aligned rows everywhere, LDS budget for two workgroups per CU
+    if (e.cfg.dtype != CESX_F32 || !Wf || opt.ldw != 0 || opt.narrow || nsrc < 1 || nsrc > 3) return -1;
+    if (e.J % 4 != 0 || e.J < 4 || ktot % U2_BK != 0) return -1;
+    const int lds = U2_RING * (U2_WSLOT + U2_XSLOT) + e.kn * 16;
+    if (lds > 80 * 1024) return -1;
+    auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    if (!al16(Wf) || !al16(out) || (add1 && !al16(add1)) || (add2 && !al16(add2))) return -1;
+    Upd2Args a{};
+    a.Wf = (const float*)Wf; a.nkt = ktot / U2_BK; a.out_rows = out_rows; a.bias = (const float*)bias;
+    const float* sp[3] = {nullptr, nullptr, nullptr};
+    int rows[3] = {1, 1, 1}, kind[3] = {0, 0, 0}, kt0[3] = {0, 0x7fffffff, 0x7fffffff};
+    int k0 = 0;
+    a.tri_seg = -1;
+    for (int i = 0; i < nsrc; ++i) {
+        if (src[i].kind == 0 && (!src[i].ptr || !al16(src[i].ptr))) return -1;
+        sp[i] = (const float*)src[i].ptr; rows[i] = src[i].rows; kind[i] = src[i].kind; kt0[i] = k0 / U2_BK;
+        if (src[i].tri) a.tri_seg = i;
+        k0 += (src[i].rows + U2_BK - 1) / U2_BK * U2_BK;
+    }
+    if (k0 != ktot) { e.err = "update: K segments do not add up to ktot"; return CESX_EINVAL; }
+    a.src0 = sp[0]; a.src1 = sp[1]; a.src2 = sp[2];
+    a.rows0 = rows[0]; a.rows1 = rows[1]; a.rows2 = rows[2];
+    a.kind0 = kind[0]; a.kind1 = kind[1]; a.kind2 = kind[2];
+    a.kt1 = kt0[1]; a.kt2 = kt0[2];
+    a.J = e.J; a.j_offset = e.cfg.j_offset;
+    a.out = (float*)out;
+    a.add1 = (const float*)add1; a.c1p = c1; a.c1i = c1_imm;
+    a.add2 = (const float*)add2; a.c2p = c2; a.c2i = c2_imm;
+    a.absmax_part = absmax_part;
+    a.seed_lo = (unsigned)e.cfg.seed; a.seed_hi = (unsigned)(e.cfg.seed >> 32); a.step = (unsigned)step_index;
+    a.rowc = (const float*)e.d_rowc;
+    a.metric_part = metrics ? e.d_metric_part : nullptr;
+    a.metric_seg = opt.metric_seg;
+    dim3 grid((unsigned)((e.J + U2_BN - 1) / U2_BN), (unsigned)((out_rows + U2_RC - 1) / U2_RC));
+    // the dispatcher gives every CU one workgroup before any CU gets its second: from there on start late
+    a.stagger_from = (long long)grid.x * grid.y > e.num_cus ? e.num_cus : 0x7fffffff;
+    CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(update2_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    e.last_update_grid_x = (int)grid.x;
+    e.last_update_grid = (int)(grid.x * grid.y);
+    {
+        ProfScope prof(e, opt.prof, s);
+        hipLaunchKernelGGL(update2_kernel, grid, dim3(U2_THREADS), lds, s, a);
+    }
+    CESX_HIP(hipGetLastError());
+    return CESX_OK;
 }
-
-int update2_lds_bytes(int kn) { return U2_RING * (U2_WSLOT + U2_XSLOT) + kn * 16; }
 
 }  // namespace cesx

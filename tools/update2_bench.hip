@@ -59,7 +59,7 @@ int main(int argc, char** argv) {
     b.src0 = a.src[0]; b.src1 = a.src[1]; b.src2 = a.src[2]; b.rows0 = p; b.rows1 = n; b.rows2 = p;
     b.kt1 = kp / 16; b.kt2 = (kp + kn) / 16; b.kind0 = 0; b.kind1 = 0; b.kind2 = a.src_kind[2];
     b.J = J; b.j_offset = a.j_offset; b.out = out2; b.rowc = rowc; b.metric_part = f_nomet ? nullptr : mpart2; b.metric_seg = 1; b.tri_seg = a.tri_seg;
-    b.seed_lo = 1; b.seed_hi = 2; b.step = 3;
+    b.seed_lo = 1; b.seed_hi = 2; b.step = 3; b.stagger_from = flag(argc, argv, "nostagger") ? 0x7fffffff : 256;
 
     using C = UpdCfg<float>;
     constexpr int RC = 4 * C::WR * 32, BN = C::WC * 32;
@@ -67,7 +67,7 @@ int main(int argc, char** argv) {
     const int lds = 2 * (RC * C::STRIDE_W + BK * (BN + C::XPAD)) * 4 + 64 + kn * 16;
     auto kern = (J % 4 == 0) ? update_kernel<float, true, UpdCfg<float>::WC> : update_kernel<float, false, UpdCfg<float>::WC>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    const int lds2 = update2_lds_bytes(kn);
+    const int lds2 = U2_RING * (U2_WSLOT + U2_XSLOT) + kn * 16;
     CK(hipFuncSetAttribute((const void*)update2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
     CK(hipMemset(out, 0, (size_t)p * J * 4)); CK(hipMemset(out2, 0xff, (size_t)p * J * 4));
     hipLaunchKernelGGL(kern, grid, dim3(UPD_THREADS), lds, 0, a);
