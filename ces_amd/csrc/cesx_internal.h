@@ -137,7 +137,7 @@ struct GramPlan {
 };
 // subset: 0 = all lower-triangular blocks, 1 = the blocks that only involve the first pbU
 // block rows (U x U: everything chol(C) needs), 2 = all the others
-GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset, int pbU);
+GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset = 0, int pbU = 0, int min_types = 1);
 
 // one Gram launch: plan + its device tables and partial-result buffers
 struct GramPart {
@@ -235,7 +235,7 @@ struct Engine {
     Scalars* h_scal = nullptr;           // pinned, device-mapped: the GPU writes results straight into it
     Scalars* h_scal_dev = nullptr;       // device address of h_scal
     unsigned long long seq = 0;
-    hipEvent_t ev = nullptr, ev_a = nullptr, ev_b = nullptr;
+    hipEvent_t ev = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;   // ev_c: side-stream centring done
     hipStream_t side = nullptr;      // side stream: chol(C) runs beside the drift part of the update
     int last_update_grid_x = 0, last_update_grid = 0, last_metric_parts = 0;
     bool pending = false;

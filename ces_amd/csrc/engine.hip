@@ -188,7 +188,9 @@ int cesx_create(const cesx_config* cfg, cesx_handle* out) {
         const long long ntiles = (e.J + kt - 1) / kt;
         for (int part = 0; part < 2; ++part) {
             GramPart& gp = e.gp[part];
-            gp.plan = make_gram_plan(P, tile, gram_nbw(cfg->dtype), gram_max_stage_rows(), part + 1, pbU);
+            int min_types = 1;
+            if (part == 0) if (const char* gv = std::getenv("CESX_GRAM_UU_TYPES")) min_types = std::atoi(gv);
+            gp.plan = make_gram_plan(P, tile, gram_nbw(cfg->dtype), gram_max_stage_rows(), part + 1, pbU, min_types);
             if (gp.plan.max_rb * tile > gram_max_stage_rows()) { e.err = "gram plan exceeds LDS"; return fail(CESX_EINVAL); }
             if (gp.plan.nblocks == 0) { gp.nslices = 1; continue; }
             int nsl = (part == 0 ? 256 : 224) / gp.plan.ntypes;      // part 1: 7 workgroups per shader engine (8 CUs), so that the Cholesky always finds a free CU
@@ -258,6 +260,7 @@ int cesx_create(const cesx_config* cfg, cesx_handle* out) {
         hipEventCreateWithFlags(&e.ev, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e.ev_a, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e.ev_b, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e.ev_c, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking) != hipSuccess) {
         e.err = "pinned host buffer / event creation failed";
         return fail(CESX_EHIP);
@@ -290,6 +293,7 @@ void cesx_destroy(cesx_handle h) {
     if (e.ev) (void)hipEventDestroy(e.ev);
     if (e.ev_a) (void)hipEventDestroy(e.ev_a);
     if (e.ev_b) (void)hipEventDestroy(e.ev_b);
+    if (e.ev_c) (void)hipEventDestroy(e.ev_c);
     if (e.side) (void)hipStreamDestroy(e.side);
     delete &e;
 }

@@ -859,6 +859,7 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
     // If cesx_chol_async already ran for these moments, the U-only part of K2 (C, M, ubar, chol(C))
     // is done or in flight on the side stream; otherwise do it here, in line.
     const bool early = e.chol_inflight;
+    if (early) CESX_HIP(hipStreamWaitEvent(s, e.ev_c, 0));
     hipLaunchKernelGGL(center_kernel, dim3(NPB), dim3(DT), 0, s, mv, e.d_shift64, e.d_y, e.d_ustar,
                        e.diag_gamma ? e.d_gw : (const double*)nullptr,
                        e.diag_sigma ? e.d_sw : (const double*)nullptr, unbiased, early ? 2 : 3, e.d_ubar, e.d_gbar,
@@ -943,13 +944,16 @@ int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s) {
     const int p = e.p, n = e.n;
     MomView mv{p, n, mom};
     const int unbiased = update == CESX_UPDATE_EKS ? 0 : 1;
-    hipLaunchKernelGGL(center_kernel, dim3(NPB), dim3(DT), 0, s, mv, e.d_shift64, e.d_y, e.d_ustar,
+    // the whole U-only part of K2 (centre, C, M, then chol(C)) goes to the side stream: the main
+    // stream continues with the second Gram launch straight after the U x U reduce
+    CESX_HIP(hipEventRecord(e.ev_a, s));
+    CESX_HIP(hipStreamWaitEvent(e.side, e.ev_a, 0));
+    hipLaunchKernelGGL(center_kernel, dim3(NPB), dim3(DT), 0, e.side, mv, e.d_shift64, e.d_y, e.d_ustar,
                        e.diag_gamma ? e.d_gw : (const double*)nullptr,
                        e.diag_sigma ? e.d_sw : (const double*)nullptr, unbiased, 1, e.d_ubar, e.d_gbar,
                        e.d_m, e.d_dg, e.d_C, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_M, e.d_part, e.d_scal);
     CESX_HIP(hipGetLastError());
-    CESX_HIP(hipEventRecord(e.ev_a, s));
-    CESX_HIP(hipStreamWaitEvent(e.side, e.ev_a, 0));
+    CESX_HIP(hipEventRecord(e.ev_c, e.side));      // ubar, C, M are final: the rest of K2 may read them
     int rc;
     if ((rc = potrf(e, e.side, p, e.d_C, e.d_L))) return rc;
     CESX_HIP(hipEventRecord(e.ev_b, e.side));

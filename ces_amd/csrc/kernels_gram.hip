@@ -37,6 +37,10 @@ template <typename T> struct GramCfg;
 template <> struct GramCfg<float>  { static constexpr int NBW = 5; };    // 5 x 16 accumulator VGPRs per wave
 template <> struct GramCfg<double> { static constexpr int NBW = 9; };    // 9 x 8
 
+#ifdef GRAM_CLOCKS   // dev instrumentation (tools/gram_bench.hip): per-workgroup cycle stamps
+__device__ long long g_gram_clk[4096 * 4];
+#endif
+
 template <typename T, bool ALIGNED>
 __global__ __launch_bounds__(GRAM_THREADS, 4)
 void gram_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __restrict__ shift,
@@ -51,6 +55,9 @@ void gram_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __re
     constexpr int NGROUP = KT / GROUP;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef GRAM_CLOCKS
+    const long long gclk0 = clock64(), gw0 = wall_clock64();
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -164,6 +171,9 @@ void gram_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __re
         store_tile(0);
     }
     __syncthreads();
+#ifdef GRAM_CLOCKS
+    const long long gclk1 = clock64();
+#endif
     for (long long t = t0; t < t1; ++t) {
         const int cur = (int)((t - t0) & 1);
         if (!(GRAM_ABL & 1) && t + 1 < t1) load_tile(t + 1);
@@ -207,6 +217,9 @@ void gram_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __re
         if (!(GRAM_ABL & 2)) __syncthreads();
     }
 
+#ifdef GRAM_CLOCKS
+    const long long gclk2 = clock64();
+#endif
     // shifted row sums of this slice (first moments): the 8 threads that share a row
     // are adjacent lanes; only the type that owns the block row reports it
 #pragma unroll
@@ -234,6 +247,12 @@ void gram_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __re
                 out[M::crow(lane, r) * TILE + M::ccol(lane)] = acc[b][r];
         }
     }
+#ifdef GRAM_CLOCKS
+    if (tid == 0 && blockIdx.x < 4096) {
+        g_gram_clk[blockIdx.x * 4 + 0] = gclk1 - gclk0; g_gram_clk[blockIdx.x * 4 + 1] = gclk2 - gclk1;
+        g_gram_clk[blockIdx.x * 4 + 2] = clock64() - gclk2; g_gram_clk[blockIdx.x * 4 + 3] = wall_clock64() - gw0;
+    }
+#endif
 }
 
 // Sum the per-slice partial blocks in fp64 (fixed order) and scatter them into
@@ -342,7 +361,7 @@ void gram_reduce_kernel(const T* __restrict__ slabs, const int* __restrict__ blk
 // ---------------------------------------------------------------------------
 // host: work partition
 // ---------------------------------------------------------------------------
-GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset, int pbU) {
+GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset, int pbU, int min_types) {
     GramPlan pl;
     pl.tile = tile;
     pl.nbw = nbw;
@@ -361,7 +380,7 @@ GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset, 
         for (int R = 0; R < pl.nbr; ++R)
             for (int C = 0; C <= R; ++C)
                 if (wanted(R, C)) all.push_back({R, C});
-        const int nt = std::max(1, ((int)all.size() + cap - 1) / cap);
+        const int nt = std::max(std::max(1, min_types), ((int)all.size() + cap - 1) / cap);
         const int per = std::max(1, ((int)all.size() + nt - 1) / nt);
         for (int t = 0; t < nt; ++t) {
             std::vector<std::pair<int, int>> v(all.begin() + std::min<size_t>(all.size(), (size_t)t * per),

@@ -2,6 +2,7 @@
 #include "../ces_amd/csrc/kernels_gram.hip"
 #include <cstdio>
 #include <vector>
+#include <cmath>
 int main(int argc, char** argv) {
     using namespace cesx;
     const int p = 256, n = 256, P = 512; const long long J = 65536;
@@ -28,6 +29,16 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, grid, block, lds, 0, U, G, shift, p, n, J, th, rows, wblk, nslices, pl.nblocks, slabs, rsp);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
+#ifdef GRAM_CLOCKS
+    {
+        std::vector<long long> c(grid.x * 4);
+        hipMemcpyFromSymbol(c.data(), HIP_SYMBOL(g_gram_clk), c.size() * 8);
+        double a0 = 0, a1 = 0, a2 = 0, w = 0, wmax = 0;
+        for (unsigned i = 0; i < grid.x; ++i) { a0 += c[4 * i]; a1 += c[4 * i + 1]; a2 += c[4 * i + 2]; w += c[4 * i + 3]; wmax = fmax(wmax, (double)c[4 * i + 3]); }
+        printf("wave 0 per WG: prologue %.0f, loop %.0f, epilogue(issue) %.0f cycles; WG wall %.1f us (max %.1f) -> %.0f MHz\n", a0 / grid.x, a1 / grid.x, a2 / grid.x,
+               w / grid.x / 100, wmax / 100, (a0 + a1 + a2) / w * 100);
+    }
+#endif
     printf("GRAM_ABL=%d types %d slices %d: %.1f us/launch (%.1f TF executed, %.1f TF algorithmic)\n", GRAM_ABL, pl.ntypes, nslices,
            ms * 100.0, 2.0 * pl.nblocks * 1024 * J / (ms * 1e-4) / 1e12, (double)P * P * J / (ms * 1e-4) / 1e12);
     return 0;
