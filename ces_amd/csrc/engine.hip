@@ -157,6 +157,10 @@ int cesx_create(const cesx_config* cfg, cesx_handle* out) {
         g_create_err = "cesx_create: invalid shape or dtype";
         return CESX_EINVAL;
     }
+    if (cfg->p > 16384 || cfg->n_obs > 16384) {     // K2 is dense in (p + n)^2 and indexes it with 32 bits
+        g_create_err = "cesx_create: p and n_obs are limited to 16384";
+        return CESX_EINVAL;
+    }
     Engine* ep = new (std::nothrow) Engine();
     if (!ep) { g_create_err = "out of host memory"; return CESX_EINVAL; }
     Engine& e = *ep;
@@ -251,7 +255,7 @@ int cesx_create(const cesx_config* cfg, cesx_handle* out) {
     { const size_t np_ = (size_t)(mx + 31) / 32 * 32; DM(e.d_Lp, np_ * np_ * 8); }
     DM(e.d_t1, mm * 8); DM(e.d_t2, mm * 8); DM(e.d_t3, mm * 8); DM(e.d_t4, mm * 8);
     DM(e.d_lanczos, ((size_t)(e.lanczos_steps + 1) * n + 2 * e.lanczos_steps) * 8);
-    DM(e.d_mv, (size_t)6 * mx * 8); DM(e.d_part, 64 * 4 * 8);
+    DM(e.d_mv, (size_t)6 * mx * 8); DM(e.d_part, 256 * 4 * 8);
     DM(e.d_scal, sizeof(Scalars)); DM(e.d_absmax, 8); DM(e.d_c0, 8);
     DM(e.d_absmax_part, (size_t)update_grid_blocks(e, p) * 8);
 #undef DM

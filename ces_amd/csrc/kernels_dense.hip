@@ -12,7 +12,7 @@
 
 namespace cesx {
 
-constexpr int NPB = 64;          // partial-sum blocks
+constexpr int NPB = 256;         // partial-sum blocks (engine.hip sizes d_part for 256)
 int potrf_ld(int n);
 constexpr int DT = 256;
 
@@ -64,28 +64,33 @@ void center_kernel(MomView mv, const double* __restrict__ shift, const double* _
     const double div = unbiased ? N - 1.0 : N;
     const double* sa = mv.sa();
     const double* sb = mv.sb();
-    const long long pp = (long long)p * p, pn = (long long)p * n, nn = (long long)n * n;
-    const long long gid = (long long)blockIdx.x * DT + threadIdx.x, gsz = (long long)gridDim.x * DT;
+    // 32-bit index arithmetic (p, n < 32768): a 64-bit divide per element used to dominate this kernel
+    const unsigned pp = (unsigned)p * p, pn = (unsigned)p * n, nn = (unsigned)n * n;
+    const unsigned gid = blockIdx.x * DT + threadIdx.x, gsz = gridDim.x * DT;
     double tr = 0.0, b2 = 0.0, fr = 0.0;
-    const long long lo = (what & 1) ? 0 : pp, hi = (what & 2) ? pp + pn + nn : pp;
-    for (long long idx = lo + gid; idx < hi; idx += gsz) {
-        if (idx < pp) {
-            const int i = (int)(idx / p), j = (int)(idx % p);
-            const double suu = mv.Saa()[idx] - sa[i] * sa[j] / N;
+    if (what & 1) {
+        const double* Saa = mv.Saa();
+        for (unsigned idx = gid; idx < pp; idx += gsz) {
+            const unsigned i = idx / (unsigned)p, j = idx - i * (unsigned)p;
+            const double suu = Saa[idx] - sa[i] * sa[j] / N;
             const double c = suu / div + (i == j ? 1e-8 : 0.0);
             C[idx] = c;
             if (sw) M[idx] = c * sw[j];              // M = C Sigma^{-1}, diagonal Sigma
             if (i == j) tr += suu;
-        } else if (idx < pp + pn) {
-            const long long k = idx - pp;
-            const int i = (int)(k / n), j = (int)(k % n);
-            const double cug = (mv.Sab()[k] - sa[i] * sb[j] / N) / N;
+        }
+    }
+    if (what & 2) {
+        const double* Sab = mv.Sab();
+        const double* Sbb = mv.Sbb();
+        for (unsigned k = gid; k < pn; k += gsz) {
+            const unsigned i = k / (unsigned)n, j = k - i * (unsigned)n;
+            const double cug = (Sab[k] - sa[i] * sb[j] / N) / N;
             Cug[k] = cug;
             if (gw) K[k] = cug * gw[j];              // K = C_ug Gamma^{-1}, diagonal Gamma
-        } else {
-            const long long k = idx - pp - pn;
-            const int i = (int)(k / n), j = (int)(k % n);
-            const double see = mv.Sbb()[k] - sb[i] * sb[j] / N;
+        }
+        for (unsigned k = gid; k < nn; k += gsz) {
+            const unsigned i = k / (unsigned)n, j = k - i * (unsigned)n;
+            const double see = Sbb[k] - sb[i] * sb[j] / N;
             const double mi = shift[p + i] + sb[i] / N - y[i], mj = shift[p + j] + sb[j] / N - y[j];
             const double srr = see + N * mi * mj;
             See[k] = see;

@@ -22,6 +22,8 @@ CPU tests).
 The engine object only needs the split entry points of the C ABI, so the same
 driver is exercised on CPU with an oracle-backed stand-in (tests/).
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -39,11 +41,20 @@ def shard_range(J, world, rank):
 class ShardedUpdate:
     """Drives one engine (this rank's shard) through sharded steps."""
 
-    def __init__(self, engine, group=None):
+    def __init__(self, engine, group=None, overlap_comm=None):
         self.engine = engine
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._recentered = False
+        # On GPUs the first all-reduce (the U x U head of the moment buffer) and chol(C) run on a
+        # second stream while the main stream goes on with the rest of the Gram: the collective
+        # costs no GPU idle time.  CESX_FORCE_COMM_OVERLAP=1 takes that path on one rank too (tests).
+        if overlap_comm is None:
+            dev = getattr(engine, "device", None)
+            overlap_comm = (isinstance(dev, torch.device) and dev.type == "cuda" and
+                            (self.world > 1 or os.environ.get("CESX_FORCE_COMM_OVERLAP") == "1"))
+        self.overlap_comm = bool(overlap_comm)
+        self._cs = None
 
     def _all_reduce(self, t, op=dist.ReduceOp.SUM):
         if self.world > 1:
@@ -67,10 +78,21 @@ class ShardedUpdate:
             self.recenter(U, G)
         nuu = eng.moments_uu_len()
         mom = eng.moments_uu(U, G)
-        self._all_reduce(mom[:nuu])             # N, sum(u - s), S_aa: all chol(C) needs
-        eng.chol_async(prm, mom)                # C, then L = chol(C) on the side stream ...
-        eng.moments_rest(U, G, mom)             # ... beside the rest of the Gram
-        self._all_reduce(mom[nuu:])
+        if self.overlap_comm:
+            cur = torch.cuda.current_stream(eng.device)
+            if self._cs is None:
+                self._cs = torch.cuda.Stream(device=eng.device)
+            self._cs.wait_stream(cur)                # the head of the buffer is complete
+            with torch.cuda.stream(self._cs):
+                self._all_reduce(mom[:nuu])          # N, sum(u - s), S_aa: all chol(C) needs ...
+                eng.chol_async(prm, mom)             # ... C, L = chol(C): engine side stream, behind this one
+            mom.record_stream(self._cs)
+            eng.moments_rest(U, G, mom)              # main stream: beside the collective and the Cholesky
+        else:
+            self._all_reduce(mom[:nuu])
+            eng.chol_async(prm, mom)                 # C, then L = chol(C) on the side stream ...
+            eng.moments_rest(U, G, mom)              # ... beside the rest of the Gram
+        self._all_reduce(mom[nuu:])                  # apply() joins the side stream before K2 reads the head
         self._mom = mom
         return mom
 

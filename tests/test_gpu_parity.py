@@ -364,3 +364,27 @@ def test_update_kernels_v1_v2_match(eng_mod, monkeypatch, update, shape):
         outs.append((out.cpu().numpy(), res.hk, res.bias_data, res.self_bias_data))
     assert rel_err(outs[1][0], outs[0][0]) < 1e-5
     assert outs[1][1:] == pytest.approx(outs[0][1:], rel=1e-5)
+
+
+def test_comm_overlap_stream_path_matches(eng_mod):
+    """ShardedUpdate with the head all-reduce + chol(C) on a second stream (the multi-GPU path,
+    forced here on one rank) gives bit-identical steps to the in-order path."""
+    from ces_amd.dist import ShardedUpdate
+    p, n, J = 128, 96, 8192
+    d = _synthetic(p, n, J, seed=31)
+    outs = []
+    for ov in (False, True):
+        eng = eng_mod.Engine(p, n, J, dtype="float32", seed=9)
+        eng.set_problem(d["y"], d["Gamma"], d["mu"], d["sigma"], d["ustar"])
+        sh = ShardedUpdate(eng, overlap_comm=ov)
+        U, G = eng.to_device(d["U0"]), eng.to_device(d["G"])
+        t_last, chain = 0.0, []
+        for i in range(4):
+            prm = eng_mod.step_params(update="aldi", first_step=(i == 0), t_len=min(i, 1), t_last=t_last, step_index=i)
+            U = sh.step(prm, U, G, xi=None, recenter=(i == 0))
+            res = sh.result()
+            t_last = res.t_new
+            chain.append((res.hk, res.t_new, res.bias_data))
+        outs.append((U.cpu().numpy(), chain))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert outs[0][1] == outs[1][1]
