@@ -232,8 +232,9 @@ def main():
                                     "(J_global=%d), d=p=%d, n_obs=%d, update=%s, default Frobenius time step, "
                                     "on-device Philox noise" % (J, Jg, p, n, args.update),
                            J_per_gpu=J, J_global=Jg, p=p, n_obs=n, update=args.update,
-                           parallelism="particle-sharded dp%d, one all-reduce(sum) of %d fp64 per step"
-                                       % (world, eng.moments_len())),
+                           parallelism="particle-sharded dp%d, all-reduce(sum) of the %d-double fp64 moment buffer "
+                                       "per step in two pieces (%d-double head beside the second Gram launch)"
+                                       % (world, eng.moments_len(), eng.moments_uu_len())),
                roofline=roofline)
     if world == 1 and not args.no_cpu_baseline:
         rec["cpu_baseline"] = cpu_baseline(prob, p, n, J, np.dtype(args.dtype).type)

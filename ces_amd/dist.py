@@ -7,8 +7,12 @@ all-reduce(sum) of the packed fp64 moment buffer between the two halves of the
 step (``cesx_moments`` -> all-reduce -> ``cesx_apply``).  The buffer is sent in
 two pieces -- first the part that depends on U alone (N, sum u, S_uu: 0.5 MB
 at p = 256), then the rest -- so that every rank can start chol(C) on its side
-stream while the remaining 74 % of the Gram is still being computed; the total
-payload is that of one all-reduce.  Rule-specific extras:
+stream while the remaining 74 % of the Gram is still being computed; on GPUs the
+first piece is itself reduced on a second stream beside that Gram launch, and the
+total payload is that of one all-reduce.  A step is exposed as two halves,
+``begin`` (moments, all-reduces, chol(C)) and ``finish`` (K2 with the pseudo-time
+of the previous step, K3), so that a driver can enqueue ``begin`` of step i+1
+before it reads the result of step i.  Rule-specific extras:
 a (1+p+n)-double all-reduce when the centring shift is (re)computed from the
 data (first step of a run), and a one-scalar all-reduce(max) for
 ``eks_update_aldi_constant`` (ces/calibrate.py:519 takes max|drift| over the
