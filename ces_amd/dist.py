@@ -82,15 +82,22 @@ class ShardedUpdate:
             self.recenter(U, G)
         nuu = eng.moments_uu_len()
         mom = eng.moments_uu(U, G)
+        done = False
         if self.overlap_comm:
             cur = torch.cuda.current_stream(eng.device)
             if self._cs is None:
                 self._cs = torch.cuda.Stream(device=eng.device)
             self._cs.wait_stream(cur)                # the head of the buffer is complete
-            with torch.cuda.stream(self._cs):
-                self._all_reduce(mom[:nuu])          # N, sum(u - s), S_aa: all chol(C) needs ...
-                eng.chol_async(prm, mom)             # ... C, L = chol(C): engine side stream, behind this one
-            mom.record_stream(self._cs)
+            try:
+                with torch.cuda.stream(self._cs):
+                    self._all_reduce(mom[:nuu])      # N, sum(u - s), S_aa: all chol(C) needs ...
+                    eng.chol_async(prm, mom)         # ... C, L = chol(C): engine side stream, behind this one
+                mom.record_stream(self._cs)
+                done = True
+            except RuntimeError:                     # a backend that cannot run on a second stream:
+                self.overlap_comm = False            # fall back to the in-order form for good
+                cur.wait_stream(self._cs)
+        if done:
             eng.moments_rest(U, G, mom)              # main stream: beside the collective and the Cholesky
         else:
             self._all_reduce(mom[:nuu])
