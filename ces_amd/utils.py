@@ -1,7 +1,9 @@
 """Forward maps of the hot-path configs (ces/utils.py:5-31).
 
-Only ``lineal`` is on the path BASELINE.json names (configs 1-3); the other toy
-models of ces/utils.py are host-side forward maps outside the scope table.
+``lineal`` is the forward map of the path BASELINE.json names (configs 1-3) and the
+one with a device hook; the other forward models of ces/utils.py (host code, SURVEY.md
+8f rank 4) live in ces_amd/models.py and are re-exported here, so that
+``import ces_amd.utils as utils`` offers what ``import ces.utils as utils`` does.
 """
 import numpy as np
 
@@ -38,3 +40,12 @@ class lineal(object):
         if np.ndim(self.b) > 0 or self.b != 0:
             b = np.broadcast_to(np.asarray(self.b, dtype=np.float64), (self.n_obs,))
         return engine.forward_lineal(self.A, U_dev, b=b, out=out)
+
+
+def __getattr__(name):
+    # re-export ces_amd.models lazily (it imports ``lineal`` from this module)
+    from . import models
+    try:
+        return getattr(models, name)
+    except AttributeError:
+        raise AttributeError("module %r has no attribute %r" % (__name__, name)) from None

@@ -5,6 +5,8 @@ Tolerances are BASELINE.json's: 1e-6 relative in fp64, 1e-3 relative in fp32
 (measured errors are far below both; the tighter internal bounds used for fp64
 are stated per test).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -388,3 +390,28 @@ def test_comm_overlap_stream_path_matches(eng_mod):
         outs.append((U.cpu().numpy(), chain))
     assert np.array_equal(outs[0][0], outs[1][0])
     assert outs[0][1] == outs[1][1]
+
+
+@pytest.mark.parametrize("update", ["aldi", "eks"])
+def test_pde_model_run_drop_in(eng_mod, update):
+    """A ``type == 'pde'`` forward model (Lorenz '63 with carried state W0)
+    through the drop-in ``sampling.run``: same seeds as the reference run of
+    oracle/make_golden_models.py -> same ensembles, carried states and metrics."""
+    from ces_amd.calibrate import sampling
+    from ces_amd.utils import lorenz63
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pde_run.npz"))
+    model = lorenz63(l_window=int(g["l_window"]), freq=int(g["freq"]))
+    p, J = g["U0"].shape
+    eks = sampling(p=p, n_obs=model.n_obs, J=J)
+    eks.ustar, eks.mu, eks.sigma, eks.T = g["ustar"], g["mu"], g["sigma"], int(g["T"])
+    eks.parallel, eks.mute_bar = False, True
+    np.random.seed(int(g["seed"]))
+    eks.run(g["y"], np.copy(g["U0"]), model, g["Gamma"], np.linalg.cholesky(g["Gamma"]), wt=g["wt"], t=g["t"],
+            update=update, t_tol=1e9)
+    assert eks.Uall.shape == g[update + "_Uall"].shape and eks.Gall.shape == g[update + "_Gall"].shape
+    # the ODE solves amplify the update's last-bit differences a little: 1e-6 on the ensembles
+    assert rel_err(eks.Uall, g[update + "_Uall"]) < 1e-6
+    assert rel_err(eks.Gall, g[update + "_Gall"]) < 1e-5
+    assert rel_err(eks.W0, g[update + "_W0"]) < 1e-5 and rel_err(eks.Gstar, g[update + "_Gstar"]) < 1e-5
+    for k in ("self-bias", "self-bias-data", "bias-data", "bias", "t"):
+        assert np.allclose(eks.metrics[k], g[update + "_metric_" + k], rtol=1e-5), k
