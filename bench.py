@@ -91,9 +91,16 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    rehearse = world == 1 and os.environ.get("CESX_FORCE_COLLECTIVES") == "1"   # one-rank run of the N > 1 code path
+    if world > 1 or rehearse:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            os.environ["CESX_FORCE_COMM_OVERLAP"] = "1"
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from ces_amd import build, engine
     from ces_amd.dist import ShardedUpdate
@@ -239,7 +246,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         rec["cpu_baseline"] = cpu_baseline(prob, p, n, J, np.dtype(args.dtype).type)
     print(json.dumps(rec), flush=True)
-    if world > 1:
+    if world > 1 or rehearse:
         dist.destroy_process_group()
 
 

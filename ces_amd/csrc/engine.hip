@@ -149,6 +149,19 @@ const char* cesx_last_error(cesx_handle h) {
     return reinterpret_cast<Engine*>(h)->err.c_str();
 }
 
+// The side stream carries the one-workgroup Cholesky beside the second Gram launch.  It is a
+// HIGH-PRIORITY stream: HIP multiplexes the streams of a priority level onto a few hardware
+// queues (4 by default), and once a communicator library has created its own streams the side
+// stream would share a queue with the caller's stream -- two streams on one queue run one after
+// the other.  Priority levels have their own queues.
+static hipError_t create_side_stream(Engine& e) {
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo &&
+        hipStreamCreateWithPriority(&e.side, hipStreamNonBlocking, hi) == hipSuccess)
+        return hipSuccess;
+    return hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking);
+}
+
 int cesx_create(const cesx_config* cfg, cesx_handle* out) {
     if (out) *out = nullptr;
     if (!cfg || !out || cfg->struct_bytes != sizeof(cesx_config)) { g_create_err = "bad cesx_config"; return CESX_EINVAL; }
@@ -265,7 +278,7 @@ int cesx_create(const cesx_config* cfg, cesx_handle* out) {
         hipEventCreateWithFlags(&e.ev_a, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e.ev_b, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e.ev_c, hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking) != hipSuccess) {
+        create_side_stream(e) != hipSuccess) {
         e.err = "pinned host buffer / event creation failed";
         return fail(CESX_EHIP);
     }
@@ -337,6 +350,8 @@ int cesx_set_problem(cesx_handle h, const double* y, const double* Gamma, const 
 
 size_t cesx_moments_len(cesx_handle h) { return h ? reinterpret_cast<Engine*>(h)->mom_len : 0; }
 size_t cesx_moments_uu_len(cesx_handle h) { return h ? reinterpret_cast<Engine*>(h)->ml.uu_len() : 0; }
+
+void* cesx_side_stream(cesx_handle h) { return h ? (void*)reinterpret_cast<Engine*>(h)->side : nullptr; }
 
 int cesx_colsum(cesx_handle h, const void* U, const void* G, double* sums, void* stream) {
     if (!h) return CESX_EINVAL;

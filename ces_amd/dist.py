@@ -59,9 +59,11 @@ class ShardedUpdate:
                             (self.world > 1 or os.environ.get("CESX_FORCE_COMM_OVERLAP") == "1"))
         self.overlap_comm = bool(overlap_comm)
         self._cs = None
+        # one-rank rehearsal of the multi-GPU path: issue the collectives even though world == 1
+        self._force_collectives = dist.is_initialized() and os.environ.get("CESX_FORCE_COLLECTIVES") == "1"
 
     def _all_reduce(self, t, op=dist.ReduceOp.SUM):
-        if self.world > 1:
+        if self.world > 1 or self._force_collectives:
             dist.all_reduce(t, op=op, group=self.group)
         return t
 
@@ -85,21 +87,25 @@ class ShardedUpdate:
         done = False
         if self.overlap_comm:
             cur = torch.cuda.current_stream(eng.device)
-            if self._cs is None:
-                self._cs = torch.cuda.Stream(device=eng.device)
+            if self._cs is None:        # the engine's own side stream: no third stream to share a hardware queue
+                self._cs = eng.side_stream() if hasattr(eng, "side_stream") else torch.cuda.Stream(device=eng.device)
             self._cs.wait_stream(cur)                # the head of the buffer is complete
+            # the rest of the Gram goes to the main stream FIRST: it does not depend on the collective,
+            # and a Gram launch dispatched behind the one-workgroup Cholesky waits for it
+            eng.moments_rest(U, G, mom)
             try:
                 with torch.cuda.stream(self._cs):
                     self._all_reduce(mom[:nuu])      # N, sum(u - s), S_aa: all chol(C) needs ...
-                    eng.chol_async(prm, mom)         # ... C, L = chol(C): engine side stream, behind this one
-                mom.record_stream(self._cs)
+                    eng.chol_async(prm, mom)         # ... C, L = chol(C): behind the collective on the side stream
+                self._keep_mom = getattr(self, "_mom", None)   # the side stream may still read the previous buffer
                 done = True
             except RuntimeError:                     # a backend that cannot run on a second stream:
-                self.overlap_comm = False            # fall back to the in-order form for good
+                self.overlap_comm = False            # in-order form from now on (this step: Cholesky after the Gram)
                 cur.wait_stream(self._cs)
-        if done:
-            eng.moments_rest(U, G, mom)              # main stream: beside the collective and the Cholesky
-        else:
+                self._all_reduce(mom[:nuu])
+                eng.chol_async(prm, mom)
+                done = True
+        if not done:
             self._all_reduce(mom[:nuu])
             eng.chol_async(prm, mom)                 # C, then L = chol(C) on the side stream ...
             eng.moments_rest(U, G, mom)              # ... beside the rest of the Gram

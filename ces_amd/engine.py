@@ -24,7 +24,7 @@ EXPORTS = ("cesx_abi_version", "cesx_create", "cesx_destroy", "cesx_last_error",
            "cesx_step", "cesx_result", "cesx_moments_len", "cesx_colsum", "cesx_set_shift",
            "cesx_moments", "cesx_apply", "cesx_apply_drift", "cesx_apply_finish", "cesx_draw_noise",
            "cesx_forward_lineal", "cesx_debug_dense", "cesx_profile_enable", "cesx_profile_read",
-           "cesx_moments_uu_len", "cesx_moments_uu", "cesx_chol_async", "cesx_moments_rest")
+           "cesx_moments_uu_len", "cesx_moments_uu", "cesx_chol_async", "cesx_moments_rest", "cesx_side_stream")
 
 
 class Config(C.Structure):
@@ -86,6 +86,8 @@ def load_library(path=None):
     lib.cesx_moments_uu.argtypes = [vp, vp, vp, vp, vp]
     lib.cesx_moments_rest.argtypes = [vp, vp, vp, vp, vp]
     lib.cesx_chol_async.argtypes = [vp, i32, vp, vp]
+    lib.cesx_side_stream.argtypes = [vp]
+    lib.cesx_side_stream.restype = vp
     lib.cesx_apply.argtypes = [vp, C.POINTER(StepParams), vp, vp, vp, vp, vp, vp]
     lib.cesx_apply_drift.argtypes = [vp, C.POINTER(StepParams), vp, vp, vp, vp, vp, vp]
     lib.cesx_apply_finish.argtypes = [vp, C.POINTER(StepParams), vp, vp, vp, vp, vp]
@@ -247,6 +249,10 @@ class Engine:
 
     def moments_uu_len(self):
         return int(self.lib.cesx_moments_uu_len(self._h))
+
+    def side_stream(self):
+        """The engine's side stream as a torch stream (cesx_side_stream)."""
+        return torch.cuda.ExternalStream(int(self.lib.cesx_side_stream(self._h)), device=self.device)
 
     def moments_uu(self, U, G, out=None):
         """U x U part of the moments into the leading moments_uu_len() entries of the buffer."""

@@ -183,6 +183,13 @@ int cesx_moments_uu(cesx_handle h, const void* U_dev, const void* G_dev, double*
 int cesx_chol_async(cesx_handle h, int update, const double* mom_dev, void* stream);
 int cesx_moments_rest(cesx_handle h, const void* U_dev, const void* G_dev, double* mom_dev, void* stream);
 
+/* The engine's side stream (a hipStream_t).  A sharded driver issues the all-reduce of the
+   leading part of the moment buffer on it (and then calls cesx_chol_async with it as
+   `stream`), so that collective and chol(C) both run beside cesx_moments_rest without a third
+   stream: HIP multiplexes streams onto a few hardware queues, and two streams that share
+   one serialise. */
+void* cesx_side_stream(cesx_handle h);
+
 /* Second half: small dense algebra on the (summed) moments -- covariance,
    Cholesky, gain, time step (ces/calibrate.py:243-267, :437-446, :469-487) --
    and the fused drift + diffusion update of the shard (:443-447, :484-488). */
