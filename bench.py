@@ -218,7 +218,8 @@ def main():
     peak = MFMA_PEAK_TF[np.dtype(args.dtype).name]
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
+    is_c2 = (p, n, J, np.dtype(args.dtype).name, args.update) == (256, 256, 65536, "float32", "aldi")
+    if os.path.exists(tpath) and is_c2:          # the PMC passes were taken on C2
         try:
             traffic = json.load(open(tpath)).get(dom.split("(")[0])
         except Exception:
@@ -235,9 +236,11 @@ def main():
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps,
                higher_is_better=True, scaling="weak", vs_baseline=None,
                dtype={"float32": "f32", "float64": "f64"}[np.dtype(args.dtype).name], data="synthetic",
-               config=dict(workload="C2 per GPU: synthetic linear-Gaussian forward map, J=%d particles/GPU "
+               config=dict(workload="%s per GPU: synthetic linear-Gaussian forward map, J=%d particles/GPU "
                                     "(J_global=%d), d=p=%d, n_obs=%d, update=%s, default Frobenius time step, "
-                                    "on-device Philox noise" % (J, Jg, p, n, args.update),
+                                    "on-device Philox noise"
+                                    % ("C2" if is_c2 else "C5" if (p, n, J, args.dtype) == (512, 512, 32768, "float64")
+                                       else "custom", J, Jg, p, n, args.update),
                            J_per_gpu=J, J_global=Jg, p=p, n_obs=n, update=args.update,
                            parallelism="particle-sharded dp%d, all-reduce(sum) of the %d-double fp64 moment buffer "
                                        "per step in two pieces (%d-double head beside the second Gram launch)"
