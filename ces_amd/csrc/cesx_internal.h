@@ -167,7 +167,6 @@ struct Engine {
     bool chol_inflight = false;    // cesx_chol_async ran for the current moments; cesx_apply joins the side stream
     bool overlap_chol = true;      // run chol(C) on the side stream beside the second (non U x U) part of the Gram
                                    // (CESX_OVERLAP=0 disables)
-    bool split_update = false;     // ALDI: split K3 into drift + noise launches (CESX_SPLIT_UPDATE=1; measured: no gain)
     int p = 0, n = 0, P = 0;
     int64_t J = 0, Jg = 0;
     size_t esz = 4;               // sizeof(T)
@@ -256,11 +255,9 @@ int launch_colsum(Engine& e, const void* U, const void* G, double* sums, hipStre
 int launch_set_shift(Engine& e, const double* sums, hipStream_t s);
 int launch_gram(Engine& e, int part, const void* U, const void* G, double* mom, hipStream_t s);   // part 0 / 1
 int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int phase, hipStream_t s);
-int launch_assemble_noise(Engine& e, hipStream_t s);
 int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s);
 struct UpdateOpt {
     int ldw = 0;          // row stride of W (0: = ktot)
-    bool narrow = false;  // narrow particle tile (more, shorter workgroups)
     int metric_seg = 1;   // K-segment that holds G (data metrics)
     const void* wf = nullptr;  // fragment-major copy of the WHOLE W (fp32): enables the LDS-DMA kernel
     int prof = -1;        // profiling slot (1 = K3) or -1

@@ -113,25 +113,6 @@ int run_update_main(Engine& e, const cesx_step_params& prm, const void* U, const
     return rc;
 }
 
-// ALDI with the Cholesky overlapped: drift part W_UG [U; G] + b (K3a, beside chol(C) on the side
-// stream), then U_next += sqrt(2 hk) L xi (K3b)
-int run_update_split(Engine& e, const cesx_step_params& prm, const void* U, const void* G, const void* xi,
-                     void* Unext, hipStream_t s) {
-    UpdateSrc src_a[2] = {{U, e.p, 0, 0}, {G, e.n, 0, 0}};
-    UpdateOpt oa;
-    oa.ldw = e.ktot; oa.narrow = true; oa.prof = 1;
-    TRY(launch_update(e, e.p, e.d_W, e.kp + e.kn, e.d_bias, src_a, 2, nullptr, nullptr, 0.0, nullptr, nullptr, 0.0,
-                      Unext, nullptr, prm.step_index, e.diag_gamma, oa, s));
-    e.last_metric_parts = e.last_update_grid_x;
-    TRY(launch_assemble_noise(e, s));
-    UpdateSrc src_b[1] = {{xi, e.p, xi ? 0 : 1, 1}};
-    UpdateOpt ob;
-    ob.ldw = e.ktot; ob.narrow = true; ob.prof = 1;
-    const char* Wn = (const char*)e.d_W + (size_t)(e.kp + e.kn) * e.esz;
-    return launch_update(e, e.p, Wn, e.kp, nullptr, src_b, 1, Unext, nullptr, 1.0, nullptr, nullptr, 0.0,
-                         Unext, nullptr, prm.step_index, false, ob, s);
-}
-
 // data metrics: K3 accumulated them (diagonal Gamma) or a separate pass does (dense Gamma)
 int finish_metrics(Engine& e, const double* mom, const void* G, bool publish, hipStream_t s) {
     if (!e.diag_gamma) TRY(launch_data_metrics(e, G, s));
@@ -182,7 +163,6 @@ int cesx_create(const cesx_config* cfg, cesx_handle* out) {
     e.J = cfg->J_local; e.Jg = cfg->J_global;
     e.esz = cfg->dtype == CESX_F32 ? 4 : 8;
     if (const char* ov = std::getenv("CESX_OVERLAP")) e.overlap_chol = ov[0] != '0';
-    if (const char* sv = std::getenv("CESX_SPLIT_UPDATE")) e.split_update = sv[0] != '0';
     if (const char* uv = std::getenv("CESX_UPDATE_V1")) e.update_v2 = uv[0] == '0';
     auto fail = [&](int rc) { g_create_err = e.err; cesx_destroy(reinterpret_cast<cesx_handle>(ep)); return rc; };
     int rc;
@@ -458,13 +438,8 @@ int cesx_apply(cesx_handle h, const cesx_step_params* prm, const double* mom, co
     }
     TRY(set_device(e));
     hipStream_t s = (hipStream_t)stream;
-    if (prm->update == CESX_UPDATE_ALDI && e.split_update) {
-        TRY(launch_dense(e, *prm, mom, 3, s));
-        TRY(run_update_split(e, *prm, U, G, xi, Unext, s));
-    } else {
-        TRY(launch_dense(e, *prm, mom, 0, s));
-        TRY(run_update_main(e, *prm, U, G, xi, Unext, s));
-    }
+    TRY(launch_dense(e, *prm, mom, 0, s));
+    TRY(run_update_main(e, *prm, U, G, xi, Unext, s));
     TRY(finish_metrics(e, mom, G, true, s));     // also publishes the step result to the host
     e.pending = true;
     e.last_prm = *prm;

@@ -690,7 +690,7 @@ __global__ void constant_hk_kernel(cesx_step_params prm, const double* __restric
 // and the next centring shift (predicted mean for ALDI, current mean otherwise).
 // ---------------------------------------------------------------------------
 template <typename T>
-__global__ void assemble_kernel(int mode, int part, int p, int n, int kp, int kn, int rpad, int ktot, double sw,
+__global__ void assemble_kernel(int mode, int p, int n, int kp, int kn, int rpad, int ktot, double sw,
                                 const Scalars* __restrict__ sc, const double* __restrict__ M,
                                 const double* __restrict__ K, const double* __restrict__ L, int ldl,
                                 const double* __restrict__ P, const double* __restrict__ PK,
@@ -706,12 +706,8 @@ __global__ void assemble_kernel(int mode, int part, int p, int n, int kp, int kn
     const double* Mm = mvs + 2 * mx;   // M mu
     const double* Mu = mvs + 3 * mx;   // M ubar
     const double* Pv = mvs + 4 * mx;   // P (hk (Ky + M mu))
-    // part 0: everything; 1: all but the noise columns (they wait for the Cholesky on the side
-    // stream); 2: only the noise columns
     if (idx < (long long)rpad * ktot) {
         const int i = (int)(idx / ktot), k = (int)(idx % ktot);
-        const bool noise_col = mode != 3 && k >= kp + kn;
-        if ((part == 1 && noise_col) || (part == 2 && !noise_col)) return;
         double v = 0.0;
         if (i < p) {
             if (mode == 3) {
@@ -737,7 +733,6 @@ __global__ void assemble_kernel(int mode, int part, int p, int n, int kp, int kn
         W[idx] = (T)v;
         if (Wf) Wf[wf_index(i, k, ktot / 16)] = (float)v;     // fragment-major copy for the fp32 LDS-DMA kernel
     }
-    if (part == 2) return;
     if (idx < rpad) {
         const int i = (int)idx;
         double b = 0.0;
@@ -836,10 +831,10 @@ static int spd_inverse(Engine& e, hipStream_t s, int n, const double* A, double*
 }
 
 template <typename T>
-static int assemble(Engine& e, hipStream_t s, int mode, int ktot, double sw, int part = 0) {
+static int assemble(Engine& e, hipStream_t s, int mode, int ktot, double sw) {
     const int mx = e.p > e.n ? e.p : e.n;
     const long long len = (long long)e.rpad * ktot;
-    hipLaunchKernelGGL(assemble_kernel<T>, g1(len), dim3(256), 0, s, mode, part, e.p, e.n, e.kp, e.kn, e.rpad, ktot,
+    hipLaunchKernelGGL(assemble_kernel<T>, g1(len), dim3(256), 0, s, mode, e.p, e.n, e.kp, e.kn, e.rpad, ktot,
                        sw, e.d_scal, e.d_M, e.d_K, e.d_L, potrf_ld(e.p), e.d_P, e.d_PK, e.d_mv, mx, e.d_ubar, e.d_gbar,
                        e.d_y, e.diag_gamma ? e.d_gw : (const double*)nullptr, (T*)e.d_W, (T*)e.d_bias,
                        (T*)e.d_shiftT, e.d_shift64, (T*)e.d_rowc, (T*)e.d_gbarT,
@@ -904,7 +899,7 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
     scalars_and_matvecs();
     CESX_HIP(hipGetLastError());
 
-    if ((phase == 0 || phase == 3) && (prm.time_step == CESX_TS_CONSTANT || (prm.time_step == CESX_TS_MIX && prm.update == CESX_UPDATE_ALDI))) {
+    if (phase == 0 && (prm.time_step == CESX_TS_CONSTANT || (prm.time_step == CESX_TS_MIX && prm.update == CESX_UPDATE_ALDI))) {
         // K' = C_ug (hk C_gg + Gamma)^{-1},  C_gg = See / N   (:440-441, :472-473)
         hipLaunchKernelGGL(axpb_kernel, g1((long long)n * n), dim3(256), 0, s, (long long)n * n, &e.d_scal->hk,
                            mom, e.d_See, e.d_Gamma, e.d_t3);
@@ -932,8 +927,6 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
         hipLaunchKernelGGL(matvec_kernel, g1(p, 4), dim3(DT), 0, s, p, p, e.d_P, e.d_mv + 5 * mx, e.d_mv + 4 * mx);
         CESX_HIP(hipGetLastError());
     }
-    if (phase == 3)
-        return f32 ? assemble<float>(e, s, 0, e.ktot, prm.switch_mult, 1) : assemble<double>(e, s, 0, e.ktot, prm.switch_mult, 1);
     if (early) {                                     // join the side-stream Cholesky before W needs L
         CESX_HIP(hipStreamWaitEvent(s, e.ev_b, 0));
         e.chol_inflight = false;
@@ -964,13 +957,6 @@ int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s) {
     CESX_HIP(hipEventRecord(e.ev_b, e.side));
     e.chol_inflight = true;
     return CESX_OK;
-}
-
-// second half of the overlapped ALDI K2: the sqrt(2 hk) L columns of W, after the side-stream Cholesky
-int launch_assemble_noise(Engine& e, hipStream_t s) {
-    CESX_HIP(hipStreamWaitEvent(s, e.ev_b, 0));
-    e.chol_inflight = false;
-    return e.cfg.dtype == CESX_F32 ? assemble<float>(e, s, 0, e.ktot, 0.0, 2) : assemble<double>(e, s, 0, e.ktot, 0.0, 2);
 }
 
 }  // namespace cesx

@@ -386,9 +386,6 @@ __global__ void noise_kernel(T* __restrict__ xi, int p, long long J, long long j
 
 // ---------------------------------------------------------------------------
 // opt.ldw    row stride of W (0: = ktot)
-// opt.narrow use the narrow particle tile (f32: 64 instead of 128 particles per workgroup):
-//            twice as many, shorter workgroups, so that a launch running beside the
-//            single-workgroup Cholesky still load-balances over the CUs
 template <typename T, int WCT>
 static int update_launch(Engine& e, UpdArgs<T>& a, bool aligned, int out_rows, int prof_which, hipStream_t s) {
     using C = UpdCfg<T>;
@@ -442,7 +439,6 @@ static int update_t(Engine& e, int out_rows, const void* W, int ktot, const void
     for (int i = 0; i < nsrc; ++i)
         if (src[i].tri) a.tri_seg = i;
     a.seed_lo = (unsigned)e.cfg.seed; a.seed_hi = (unsigned)(e.cfg.seed >> 32); a.step = (unsigned)step_index;
-    if (opt.narrow && sizeof(T) == 4) return update_launch<T, UpdCfg<T>::WC / 2>(e, a, aligned, out_rows, opt.prof, s);
     return update_launch<T, UpdCfg<T>::WC>(e, a, aligned, out_rows, opt.prof, s);
 }
 
@@ -463,7 +459,7 @@ int launch_update(Engine& e, int out_rows, const void* W, int ktot, const void* 
 
 // upper bound of the number of workgroups of any update launch (sizes the partial-result buffers)
 int update_grid_blocks(Engine& e, int out_rows) {
-    const int bn = e.cfg.dtype == CESX_F32 ? UpdCfg<float>::WC * 32 / 2 : UpdCfg<double>::WC * 16;
+    const int bn = e.cfg.dtype == CESX_F32 ? UpdCfg<float>::WC * 32 : UpdCfg<double>::WC * 16;
     const int rc = 256;
     return (int)((e.J + bn - 1) / bn) * ((out_rows + rc - 1) / rc);
 }

@@ -465,7 +465,7 @@ int launch_update2(Engine& e, int out_rows, const void* Wf, int ktot, const void
                    void* out, double* absmax_part, uint64_t step_index, bool metrics,
                    const UpdateOpt& opt, hipStream_t s) {
     // qualifies: fp32, whole W, 16-byte aligned rows everywhere, LDS budget for two workgroups per CU
-    if (e.cfg.dtype != CESX_F32 || !Wf || opt.ldw != 0 || opt.narrow || nsrc < 1 || nsrc > 3) return -1;
+    if (e.cfg.dtype != CESX_F32 || !Wf || opt.ldw != 0 || nsrc < 1 || nsrc > 3) return -1;
     if (e.J % 4 != 0 || e.J < 4 || ktot % U2_BK != 0) return -1;
     const int lds = U2_RING * (U2_WSLOT + U2_XSLOT) + e.kn * 16;
     if (lds > 80 * 1024) return -1;
