@@ -1,5 +1,6 @@
 // dev tool: time update_kernel<float> alone (C2 shape) with ablation switches.
 #include "../ces_amd/csrc/kernels_update.hip"
+#include "../ces_amd/csrc/kernels_update2.hip"
 #include <cstdio>
 #include <vector>
 #include <cstring>
