@@ -214,7 +214,7 @@ class sampling(enka):
         m["t"].append(res.t_new)
         self._last_hk = res.hk
         if isinstance(U0, np.ndarray):
-            return U_next.to("cpu", dtype=_engine.torch.float64).numpy()
+            return eng.to_host(U_next)
         return U_next
 
     # -- reference API ---------------------------------------------------
