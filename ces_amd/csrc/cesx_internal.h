@@ -127,25 +127,30 @@ struct GramPlan {
     int ntypes;          // workgroup types
     int max_rb;          // max staged row blocks over types
     int nbw;             // per-wave block capacity (compile-time constant of the kernel)
+    // Every type gets a number of J-slices (workgroups) proportional to its block count, so that
+    // all workgroups of a launch carry the same amount of MFMA work whatever the shape of the types.
     // flattened tables uploaded to the device:
-    //  type_hdr[type*4 + {0: nrb, 1: rows_off, 2: blocks_off, 3: unused}]
-    //  rows[rows_off + i]            = global block row of compact row i
-    //  wblk[(blocks_off + wave*nbw + b)*3 + {0,1,2}] = {ia, ib, out block id} or ia = -1
-    //  blk_rc[out*2 + {0,1}] = (R, C) of output block
-    std::vector<int> type_hdr, rows, wblk, blk_rc;
+    //  type_hdr[type*8 + {0: nrb, 1: rows_off, 2: blocks_off, 3: blocks of the type, 4: first workgroup,
+    //                     5: slices, 6: first slab (in blocks), 7: first row-sum slot}]
+    //  rows[rows_off + i]            = global block row of compact row i (| 1<<16: this type reports its sums)
+    //  wblk[(blocks_off + wave*nbw + b)*3 + {0,1,2}] = {ia, ib, block index inside the type} or ia = -1
+    //  blk_rc[out*5 + {0..4}] = (R, C) of output block, its first slab, slab stride (blocks), slices
+    //  row_own[br*2 + {0,1}]  = first row-sum slot and slices of the type that owns block row br (slices 0: not owned)
+    std::vector<int> type_hdr, rows, wblk, blk_rc, row_own;
+    int total_wgs = 0, total_slabs = 0, total_rs = 0;
     int own_lo = 0, own_hi = 0;   // block rows [own_lo, own_hi) whose row sums this plan reports
 };
 // subset: 0 = all lower-triangular blocks, 1 = the blocks that only involve the first pbU
 // block rows (U x U: everything chol(C) needs), 2 = all the others
-GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset = 0, int pbU = 0, int min_types = 1);
+GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset = 0, int pbU = 0, int min_types = 1,
+                        int wg_budget = 256, long long ntiles = 1 << 30);
 
 // one Gram launch: plan + its device tables and partial-result buffers
 struct GramPart {
     GramPlan plan;
-    int *d_type_hdr = nullptr, *d_rows = nullptr, *d_wblk = nullptr, *d_blk_rc = nullptr;
-    int nslices = 0;
-    void* d_slabs = nullptr;            // [nslices][nblocks][tile*tile] engine dtype
-    double* d_rowsum_part = nullptr;    // [nslices][p+n]
+    int *d_type_hdr = nullptr, *d_rows = nullptr, *d_wblk = nullptr, *d_blk_rc = nullptr, *d_row_own = nullptr;
+    void* d_slabs = nullptr;            // per type [slices][blocks of the type][tile*tile] engine dtype
+    double* d_rowsum_part = nullptr;    // [row-sum slots][p+n]
 };
 
 // ---------------------------------------------------------------------------

@@ -187,14 +187,10 @@ int cesx_create(const cesx_config* cfg, cesx_handle* out) {
             GramPart& gp = e.gp[part];
             int min_types = 1;
             if (part == 0) if (const char* gv = std::getenv("CESX_GRAM_UU_TYPES")) min_types = std::atoi(gv);
-            gp.plan = make_gram_plan(P, tile, gram_nbw(cfg->dtype), gram_max_stage_rows(), part + 1, pbU, min_types);
+            // part 1: 7 workgroups per shader engine (8 CUs), so that the Cholesky always finds a free CU
+            gp.plan = make_gram_plan(P, tile, gram_nbw(cfg->dtype), gram_max_stage_rows(), part + 1, pbU, min_types,
+                                     part == 0 ? 256 : 224, ntiles);
             if (gp.plan.max_rb * tile > gram_max_stage_rows()) { e.err = "gram plan exceeds LDS"; return fail(CESX_EINVAL); }
-            if (gp.plan.nblocks == 0) { gp.nslices = 1; continue; }
-            int nsl = (part == 0 ? 256 : 224) / gp.plan.ntypes;      // part 1: 7 workgroups per shader engine (8 CUs), so that the Cholesky always finds a free CU
-            if (nsl < 1) nsl = 1;
-            if (nsl > 8) nsl -= nsl % 4;
-            if (nsl > ntiles) nsl = (int)ntiles;
-            gp.nslices = nsl;
         }
     }
     e.colsum_slices = (int)std::min<long long>(16, (e.J + 1023) / 1024);
@@ -220,7 +216,7 @@ int cesx_create(const cesx_config* cfg, cesx_handle* out) {
         DM(t, (size_t)e.kn * 4 * e.esz); e.d_rowc = t;
         for (int part = 0; part < 2; ++part) {
             const GramPlan& pl = e.gp[part].plan;
-            DM(t, (size_t)e.gp[part].nslices * pl.nblocks * pl.tile * pl.tile * e.esz); e.gp[part].d_slabs = t;
+            DM(t, (size_t)std::max(pl.total_slabs, 1) * pl.tile * pl.tile * e.esz); e.gp[part].d_slabs = t;
         }
         DM(t, (size_t)e.rpad * e.ktot * e.esz); e.d_W = t;
         if (e.cfg.dtype == CESX_F32) { DM(t, (size_t)e.rpad * e.ktot * e.esz); e.d_Wf = t; }
@@ -231,12 +227,13 @@ int cesx_create(const cesx_config* cfg, cesx_handle* out) {
         GramPart& gp = e.gp[part];
         const GramPlan& pl = gp.plan;
         DM(gp.d_type_hdr, pl.type_hdr.size() * 4); DM(gp.d_rows, pl.rows.size() * 4);
-        DM(gp.d_wblk, pl.wblk.size() * 4); DM(gp.d_blk_rc, pl.blk_rc.size() * 4);
+        DM(gp.d_wblk, pl.wblk.size() * 4); DM(gp.d_blk_rc, pl.blk_rc.size() * 4); DM(gp.d_row_own, pl.row_own.size() * 4);
         if ((rc = upload(e, gp.d_type_hdr, pl.type_hdr.data(), pl.type_hdr.size() * 4))) return fail(rc);
         if ((rc = upload(e, gp.d_rows, pl.rows.data(), pl.rows.size() * 4))) return fail(rc);
         if ((rc = upload(e, gp.d_wblk, pl.wblk.data(), pl.wblk.size() * 4))) return fail(rc);
         if ((rc = upload(e, gp.d_blk_rc, pl.blk_rc.data(), pl.blk_rc.size() * 4))) return fail(rc);
-        DM(gp.d_rowsum_part, (size_t)gp.nslices * P * 8);
+        if ((rc = upload(e, gp.d_row_own, pl.row_own.data(), pl.row_own.size() * 4))) return fail(rc);
+        DM(gp.d_rowsum_part, (size_t)pl.total_rs * P * 8);
     }
     DM(e.d_metric_part, ((size_t)((e.J + 63) / 64) + 8) * 2 * 8);
     DM(e.d_metric_sums, 2 * 8);
@@ -276,8 +273,8 @@ void cesx_destroy(cesx_handle h) {
                     e.d_bias, e.d_Wfwd, e.d_metric_part, e.d_metric_sums,
                     e.d_gbarT, e.d_rowc,
                     e.d_colsum_part, e.d_mom,
-                    e.gp[0].d_type_hdr, e.gp[0].d_rows, e.gp[0].d_wblk, e.gp[0].d_blk_rc, e.gp[0].d_slabs, e.gp[0].d_rowsum_part,
-                    e.gp[1].d_type_hdr, e.gp[1].d_rows, e.gp[1].d_wblk, e.gp[1].d_blk_rc, e.gp[1].d_slabs, e.gp[1].d_rowsum_part, e.d_sums, e.d_ubar, e.d_gbar, e.d_m, e.d_dg,
+                    e.gp[0].d_type_hdr, e.gp[0].d_rows, e.gp[0].d_wblk, e.gp[0].d_blk_rc, e.gp[0].d_row_own, e.gp[0].d_slabs, e.gp[0].d_rowsum_part,
+                    e.gp[1].d_type_hdr, e.gp[1].d_rows, e.gp[1].d_wblk, e.gp[1].d_blk_rc, e.gp[1].d_row_own, e.gp[1].d_slabs, e.gp[1].d_rowsum_part, e.d_sums, e.d_ubar, e.d_gbar, e.d_m, e.d_dg,
                     e.d_wdel, e.d_C, e.d_L, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_Kp, e.d_M, e.d_P, e.d_PK,
                     e.d_t1, e.d_t2, e.d_t3, e.d_t4, e.d_Lp, e.d_lanczos, e.d_mv, e.d_part, e.d_scal, e.d_absmax,
                     e.d_c0, e.d_absmax_part};

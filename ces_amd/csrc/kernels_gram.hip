@@ -44,9 +44,9 @@ __device__ long long g_gram_clk[4096 * 4];
 template <typename T, bool ALIGNED>
 __global__ __launch_bounds__(GRAM_THREADS, 4)
 void gram_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __restrict__ shift,
-                 int p, int n, long long J, const int* __restrict__ type_hdr,
+                 int p, int n, long long J, const int* __restrict__ type_hdr, int ntypes,
                  const int* __restrict__ rows_tab, const int* __restrict__ wblk,
-                 int nslices, int nblocks, T* __restrict__ slabs, double* __restrict__ rowsum_part) {
+                 T* __restrict__ slabs, double* __restrict__ rowsum_part) {
     using M = Mfma<T>;
     using vec_t = typename M::vec_t;
     using acc_t = typename M::acc_t;
@@ -61,10 +61,13 @@ void gram_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __re
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int type = blockIdx.x / nslices, slice = blockIdx.x % nslices;
-    const int nrb = type_hdr[type * 4 + 0];
-    const int rows_off = type_hdr[type * 4 + 1];
-    const int blocks_off = type_hdr[type * 4 + 2];
+    int type = 0;                                   // the type whose workgroup range holds blockIdx.x
+    for (int t = 1; t < ntypes; ++t)
+        if ((int)blockIdx.x >= type_hdr[t * 8 + 4]) type = t;
+    const int* hdr = type_hdr + type * 8;
+    const int nrb = hdr[0], rows_off = hdr[1], blocks_off = hdr[2], nblk_t = hdr[3];
+    const int slice = (int)blockIdx.x - hdr[4], nslices = hdr[5];
+    const int slab0 = hdr[6], rs0 = hdr[7];
     const int nrows = nrb * TILE;
     const int P = p + n;
     const int buf_bytes = nrows * ROW_STRIDE;
@@ -232,7 +235,7 @@ void gram_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __re
             v += __shfl_xor(v, 4, 64);
             const int ent = rows_tab[rows_off + row / TILE];
             const int gr = (ent & 0xffff) * TILE + row % TILE;
-            if (part == 0 && (ent >> 16) != 0 && gr < P) rowsum_part[(size_t)slice * P + gr] = v;
+            if (part == 0 && (ent >> 16) != 0 && gr < P) rowsum_part[(size_t)(rs0 + slice) * P + gr] = v;
         }
     }
 
@@ -241,7 +244,7 @@ void gram_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __re
     for (int b = 0; b < NBW; ++b) {
         if (b < nb) {
             const int ob = __builtin_amdgcn_readfirstlane(wblk[(size_t)(blocks_off + wave * NBW + b) * 3 + 2]);
-            T* out = slabs + ((size_t)slice * nblocks + ob) * (TILE * TILE);
+            T* out = slabs + ((size_t)slab0 + (size_t)slice * nblk_t + ob) * (TILE * TILE);
 #pragma unroll
             for (int r = 0; r < M::NACC; ++r)
                 out[M::crow(lane, r) * TILE + M::ccol(lane)] = acc[b][r];
@@ -263,8 +266,8 @@ void gram_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __re
 constexpr int RED_G = 16, RED_S = 16;
 template <typename T>
 __global__ __launch_bounds__(256)
-void gram_reduce_kernel(const T* __restrict__ slabs, const int* __restrict__ blk_rc,
-                        int nslices, int nblocks, int tile, MomLayout ml, long long J, int row_lo, int row_hi,
+void gram_reduce_kernel(const T* __restrict__ slabs, const int* __restrict__ blk_rc, const int* __restrict__ row_own,
+                        int nblocks, int tile, MomLayout ml, long long J, int row_lo, int row_hi,
                         int write_N, const double* __restrict__ rowsum_part, const double* __restrict__ tail_src,
                         double* __restrict__ mom) {
     using vec_t = typename Mfma<T>::vec_t;
@@ -287,10 +290,11 @@ void gram_reduce_kernel(const T* __restrict__ slabs, const int* __restrict__ blk
         }
         double s = 0.0;
         if (r < row_hi) {
+            const int rs0 = row_own[(r / tile) * 2], nslices = row_own[(r / tile) * 2 + 1];
             const int per = (nslices + RED_S - 1) / RED_S;
             const int k1 = min(nslices, (gq + 1) * per);
 #pragma unroll 8
-            for (int k = gq * per; k < k1; ++k) s += rowsum_part[(size_t)k * (p + n) + r];
+            for (int k = gq * per; k < k1; ++k) s += rowsum_part[(size_t)(rs0 + k) * (p + n) + r];
         }
         part[gq][gl][0] = s;
         __syncthreads();
@@ -307,8 +311,10 @@ void gram_reduce_kernel(const T* __restrict__ slabs, const int* __restrict__ blk
     double acc[VEC];
 #pragma unroll
     for (int c = 0; c < VEC; ++c) acc[c] = 0.0;
-    const T* src = slabs + (size_t)blk * tt + e0;
-    const size_t stride = (size_t)nblocks * tt;
+    const int* info = blk_rc + blk * 5;
+    const T* src = slabs + (size_t)info[2] * tt + e0;
+    const size_t stride = (size_t)info[3] * tt;
+    const int nslices = info[4];
     const int per = (nslices + RED_S - 1) / RED_S;
     const int k1 = min(nslices, (gq + 1) * per);
     int k = gq * per;
@@ -332,7 +338,7 @@ void gram_reduce_kernel(const T* __restrict__ slabs, const int* __restrict__ blk
     for (int c = 0; c < VEC; ++c) part[gq][gl][c] = acc[c];
     __syncthreads();
     if (gq != 0 || !on) return;
-    const int R = blk_rc[blk * 2], C = blk_rc[blk * 2 + 1];
+    const int R = info[0], C = info[1];
     const int P = p + n;
     double* Saa = mom + ml.Saa();
     double* Sab = mom + ml.Sab();
@@ -361,7 +367,8 @@ void gram_reduce_kernel(const T* __restrict__ slabs, const int* __restrict__ blk
 // ---------------------------------------------------------------------------
 // host: work partition
 // ---------------------------------------------------------------------------
-GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset, int pbU, int min_types) {
+GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset, int pbU, int min_types,
+                        int wg_budget, long long ntiles) {
     GramPlan pl;
     pl.tile = tile;
     pl.nbw = nbw;
@@ -405,6 +412,36 @@ GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset, 
     }
     pl.ntypes = (int)types.size();
     pl.max_rb = 0;
+    // Slices per type, proportional to the cycles one J tile costs a workgroup of that type: the
+    // MFMAs of its busiest SIMD (blocks / 4 SIMDs, 64 cycles per MFMA, tile-width / k MFMAs per
+    // block) plus the part that does not shrink with the block count -- staging the type's rows
+    // (16 B per lane-store, ~80 B/clk/CU) and the barrier.  Largest-remainder rounding within the
+    // workgroup budget; never more slices than J tiles.
+    std::vector<int> nsl(pl.ntypes, 1);
+    {
+        const double mfma_cyc = tile == 32 ? 16 * 64.0 : 4 * 64.0;      // f32: 32 j / k=2; f64: 16 j / k=4
+        std::vector<double> w(pl.ntypes);
+        double total = 0.0;
+        for (int t = 0; t < pl.ntypes; ++t) {
+            std::set<int> rws;
+            for (auto& rc : types[t]) { rws.insert(rc.first); rws.insert(rc.second); }
+            w[t] = mfma_cyc * (double)((types[t].size() + 3) / 4) + 300.0 + 1.6 * (double)(rws.size() * tile);
+            total += w[t];
+        }
+        const int budget = std::max(wg_budget, pl.ntypes);
+        std::vector<std::pair<double, int>> frac;
+        int used = 0;
+        for (int t = 0; t < pl.ntypes; ++t) {
+            const double want = total > 0 ? (double)budget * w[t] / total : 1.0;
+            nsl[t] = std::max(1, (int)std::floor(want));
+            used += nsl[t];
+            frac.push_back({want - std::floor(want), t});
+        }
+        std::sort(frac.begin(), frac.end(), [](auto& a, auto& b) { return a.first > b.first; });
+        for (size_t i = 0; i < frac.size() && used < budget; ++i) { ++nsl[frac[i].second]; ++used; }
+        for (int t = 0; t < pl.ntypes; ++t)
+            if ((long long)nsl[t] > ntiles) nsl[t] = (int)std::max<long long>(1, ntiles);
+    }
     // output block ids: position in the row-major list of this plan's blocks
     std::vector<int> idmap((size_t)pl.nbr * pl.nbr, -1);
     pl.nblocks = 0;
@@ -413,11 +450,12 @@ GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset, 
         for (int C = 0; C <= R; ++C)
             if (wanted(R, C)) {
                 idmap[(size_t)R * pl.nbr + C] = pl.nblocks++;
-                pl.blk_rc.push_back(R);
-                pl.blk_rc.push_back(C);
+                for (int q : {R, C, 0, 0, 0}) pl.blk_rc.push_back(q);
             }
     auto out_id = [&](int R, int C) { return idmap[(size_t)R * pl.nbr + C]; };
+    pl.row_own.assign((size_t)pl.nbr * 2, 0);
     std::set<int> owned;
+    int wg0 = 0, slab0 = 0, rs0 = 0;
     for (int t = 0; t < pl.ntypes; ++t) {
         const auto& v = types[t];
         std::vector<int> rows;
@@ -426,16 +464,15 @@ GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset, 
         rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
         auto compact = [&](int r) { return (int)(std::lower_bound(rows.begin(), rows.end(), r) - rows.begin()); };
         pl.max_rb = std::max(pl.max_rb, (int)rows.size());
-        pl.type_hdr.push_back((int)rows.size());
-        pl.type_hdr.push_back((int)pl.rows.size());
-        pl.type_hdr.push_back((int)(pl.wblk.size() / 3));
-        pl.type_hdr.push_back((int)v.size());
+        const int nv = (int)v.size();
+        for (int q : {(int)rows.size(), (int)pl.rows.size(), (int)(pl.wblk.size() / 3), nv, wg0, nsl[t], slab0, rs0})
+            pl.type_hdr.push_back(q);
         for (int r : rows) {
             // the first type that stages an owned block row reports its sums
             const bool first = r >= pl.own_lo && r < pl.own_hi && owned.insert(r).second;
             pl.rows.push_back(r | (first ? 1 << 16 : 0));
+            if (first) { pl.row_own[(size_t)r * 2] = rs0; pl.row_own[(size_t)r * 2 + 1] = nsl[t]; }
         }
-        const int nv = (int)v.size();
         // waves w, w+4, w+8, ... share a SIMD: the first (nv % waves) waves take one extra
         // block, which keeps the per-SIMD totals within one block of each other
         int next = 0;
@@ -447,13 +484,19 @@ GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset, 
                 if (lo + b < hi) {
                     pl.wblk.push_back(compact(v[lo + b].first));
                     pl.wblk.push_back(compact(v[lo + b].second));
-                    pl.wblk.push_back(out_id(v[lo + b].first, v[lo + b].second));
+                    pl.wblk.push_back(lo + b);                      // block index inside the type
+                    int* info = &pl.blk_rc[(size_t)out_id(v[lo + b].first, v[lo + b].second) * 5];
+                    info[2] = slab0 + lo + b; info[3] = nv; info[4] = nsl[t];
                 } else {
                     pl.wblk.push_back(-1); pl.wblk.push_back(-1); pl.wblk.push_back(-1);
                 }
             }
         }
+        wg0 += nsl[t];
+        slab0 += nsl[t] * nv;
+        rs0 += nsl[t];
     }
+    pl.total_wgs = wg0; pl.total_slabs = slab0; pl.total_rs = std::max(rs0, 1);
     return pl;
 }
 
@@ -463,7 +506,7 @@ static int launch_gram_t(Engine& e, int part, const void* U, const void* G, doub
     const GramPlan& pl = gp.plan;
     const int lds = 2 * pl.max_rb * pl.tile * ROW_STRIDE + pl.max_rb * pl.tile * 16;
     const bool aligned = (e.J % Mfma<T>::VEC == 0) && ((uintptr_t)U % 16 == 0) && ((uintptr_t)G % 16 == 0);
-    dim3 grid(pl.ntypes * gp.nslices), block(GRAM_THREADS);
+    dim3 grid(pl.total_wgs), block(GRAM_THREADS);
     auto kern = aligned ? gram_kernel<T, true> : gram_kernel<T, false>;
     CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -471,15 +514,15 @@ static int launch_gram_t(Engine& e, int part, const void* U, const void* G, doub
                                 //  writes part 1's share of the buffer: row sums it owns and the lagged tail)
         ProfScope prof(e, 0, s);
         hipLaunchKernelGGL(kern, grid, block, lds, s, (const T*)U, (const T*)G, (const T*)e.d_shiftT,
-                           e.p, e.n, (long long)e.J, gp.d_type_hdr, gp.d_rows, gp.d_wblk, gp.nslices,
-                           pl.nblocks, (T*)gp.d_slabs, gp.d_rowsum_part);
+                           e.p, e.n, (long long)e.J, gp.d_type_hdr, pl.ntypes, gp.d_rows, gp.d_wblk,
+                           (T*)gp.d_slabs, gp.d_rowsum_part);
     }
     CESX_HIP(hipGetLastError());
     const long long ngroups = (long long)pl.nblocks * pl.tile * pl.tile / Mfma<T>::VEC;
     const int row_lo = std::min(pl.own_lo * pl.tile, e.p + e.n), row_hi = std::min(pl.own_hi * pl.tile, e.p + e.n);
     const long long wgs = (ngroups + RED_G - 1) / RED_G + std::max(1, (row_hi - row_lo + RED_G - 1) / RED_G);
     hipLaunchKernelGGL(gram_reduce_kernel<T>, dim3((unsigned)wgs), dim3(256), 0, s,
-                       (const T*)gp.d_slabs, gp.d_blk_rc, gp.nslices, pl.nblocks, pl.tile, e.ml,
+                       (const T*)gp.d_slabs, gp.d_blk_rc, gp.d_row_own, pl.nblocks, pl.tile, e.ml,
                        (long long)e.J, row_lo, row_hi, part == 0 ? 1 : 0, gp.d_rowsum_part,
                        part == 1 ? e.d_metric_sums : (const double*)nullptr, mom);
     CESX_HIP(hipGetLastError());

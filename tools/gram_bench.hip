@@ -6,11 +6,12 @@
 int main(int argc, char** argv) {
     using namespace cesx;
     const int p = 256, n = 256, P = 512; const long long J = 65536;
-    GramPlan pl = make_gram_plan(P, 32, GramCfg<float>::NBW, MAX_STAGE_ROWS, argc > 1 ? atoi(argv[1]) : 0, 8);
-    int nslices = (argc > 2 ? atoi(argv[2]) : 256) / pl.ntypes; nslices -= nslices % 4;
+    GramPlan pl = make_gram_plan(P, 32, GramCfg<float>::NBW, MAX_STAGE_ROWS, argc > 1 ? atoi(argv[1]) : 0, 8, 1,
+                                 argc > 2 ? atoi(argv[2]) : 256, (J + 31) / 32);
+    const int nslices = pl.total_wgs / pl.ntypes;
     float *U, *G, *shift, *slabs; double* rsp; int *th, *rows, *wblk;
     hipMalloc(&U, p * J * 4); hipMalloc(&G, n * J * 4); hipMalloc(&shift, P * 4);
-    hipMalloc(&slabs, (size_t)nslices * pl.nblocks * 1024 * 4); hipMalloc(&rsp, (size_t)nslices * P * 8);
+    hipMalloc(&slabs, (size_t)pl.total_slabs * 1024 * 4); hipMalloc(&rsp, (size_t)pl.total_rs * P * 8);
     std::vector<float> h((size_t)p * J);
     for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) % 2001) / 1000.f - 1.f;
     hipMemcpy(U, h.data(), h.size() * 4, hipMemcpyHostToDevice); hipMemcpy(G, h.data(), h.size() * 4, hipMemcpyHostToDevice);
@@ -22,11 +23,11 @@ int main(int argc, char** argv) {
     const int lds = 2 * pl.max_rb * pl.tile * ROW_STRIDE + pl.max_rb * pl.tile * 16;
     auto kern = gram_kernel<float, true>;
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    dim3 grid(pl.ntypes * nslices), block(GRAM_THREADS);
+    dim3 grid(pl.total_wgs), block(GRAM_THREADS);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, grid, block, lds, 0, U, G, shift, p, n, J, th, rows, wblk, nslices, pl.nblocks, slabs, rsp);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, grid, block, lds, 0, U, G, shift, p, n, J, th, pl.ntypes, rows, wblk, slabs, rsp);
     hipEventRecord(e0);
-    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, grid, block, lds, 0, U, G, shift, p, n, J, th, rows, wblk, nslices, pl.nblocks, slabs, rsp);
+    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, grid, block, lds, 0, U, G, shift, p, n, J, th, pl.ntypes, rows, wblk, slabs, rsp);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
 #ifdef GRAM_CLOCKS
