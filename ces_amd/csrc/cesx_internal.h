@@ -224,6 +224,7 @@ struct Engine {
     double* d_absmax_part = nullptr;
     // update coefficients (engine dtype)
     int bk = 16, kp = 0, kn = 0, ktot = 0, rpad = 0;
+    double* d_Lwork = nullptr;     // p > 256: work copy of C for the blocked Cholesky [potrf_ld(p)]^2
     void* d_W = nullptr;           // [rpad][ktot]
     void* d_Wf = nullptr;          // fp32 engines: the same matrix in the fragment-major order of kernels_update2.hip
     bool update_v2 = true;         // fp32 K3 through the LDS-DMA kernel (CESX_UPDATE_V1=1 switches back)

@@ -243,6 +243,7 @@ int cesx_create(const cesx_config* cfg, cesx_handle* out) {
     DM(e.d_C, pp * 8); DM(e.d_L, (size_t)potrf_ld(p) * potrf_ld(p) * 8); DM(e.d_Cug, pn * 8); DM(e.d_See, nn * 8); DM(e.d_Srr, nn * 8);
     DM(e.d_K, pn * 8); DM(e.d_Kp, pn * 8); DM(e.d_M, pp * 8); DM(e.d_P, pp * 8); DM(e.d_PK, pn * 8);
     { const size_t np_ = (size_t)(mx + 31) / 32 * 32; DM(e.d_Lp, np_ * np_ * 8); }
+    if (potrf_ld(mx) > 256) DM(e.d_Lwork, (size_t)potrf_ld(mx) * potrf_ld(mx) * 8);
     DM(e.d_t1, mm * 8); DM(e.d_t2, mm * 8); DM(e.d_t3, mm * 8); DM(e.d_t4, mm * 8);
     DM(e.d_lanczos, ((size_t)(e.lanczos_steps + 1) * n + 2 * e.lanczos_steps) * 8);
     DM(e.d_mv, (size_t)6 * mx * 8); DM(e.d_part, 256 * 4 * 8);
@@ -269,7 +270,7 @@ void cesx_destroy(cesx_handle h) {
     Engine& e = *reinterpret_cast<Engine*>(h);
     (void)hipSetDevice(e.cfg.device);
     void* ptrs[] = {e.d_y, e.d_mu, e.d_ustar, e.d_Gamma, e.d_Ginv, e.d_gw, e.d_Wh, e.d_Sigma, e.d_Sinv, e.d_sw,
-                    e.d_shift64, e.d_shiftT, e.d_yT, e.d_gwT, e.d_GinvT, e.d_wdT, e.d_W, e.d_Wf,
+                    e.d_shift64, e.d_shiftT, e.d_yT, e.d_gwT, e.d_GinvT, e.d_wdT, e.d_W, e.d_Wf, e.d_Lwork,
                     e.d_bias, e.d_Wfwd, e.d_metric_part, e.d_metric_sums,
                     e.d_gbarT, e.d_rowc,
                     e.d_colsum_part, e.d_mom,

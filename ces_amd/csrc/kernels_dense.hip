@@ -143,7 +143,8 @@ __global__ void scale_cols_kernel(int rows, int cols, const double* __restrict__
 // C(m x n) = alpha * A(m x k) * B(k x n) with arbitrary element strides
 __global__ __launch_bounds__(DT)
 void gemm_kernel(int m, int n, int k, double alpha, const double* __restrict__ A, long long a0, long long a1,
-                 const double* __restrict__ B, long long b0, long long b1, double* __restrict__ Cm, int ldc) {
+                 const double* __restrict__ B, long long b0, long long b1, double* Cm, int ldc,
+                 const double* Cin = nullptr) {       // Cin (may be Cm itself): C = Cin + alpha A B
     __shared__ double sA[32][33], sB[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // ty in 0..7
     const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
@@ -167,7 +168,7 @@ void gemm_kernel(int m, int n, int k, double alpha, const double* __restrict__ A
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int i = i0 + ty + 8 * r, j = j0 + tx;
-        if (i < m && j < n) Cm[(size_t)i * ldc + j] = alpha * acc[r];
+        if (i < m && j < n) Cm[(size_t)i * ldc + j] = (Cin ? Cin[(size_t)i * ldc + j] : 0.0) + alpha * acc[r];
     }
 }
 
@@ -357,7 +358,10 @@ __device__ __forceinline__ double rsqrt_nr(double a) {
 template <int SLOTS>
 __global__ __launch_bounds__(PRT, 2)
 void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __restrict__ Lp, int* status,
-                      long long* dbg = nullptr) {   // dbg: per-phase cycle counts (tools/potrf_bench only)
+                      long long* dbg = nullptr,     // dbg: per-phase cycle counts (tools/potrf_bench only)
+                      int lda = 0, int ldl = 0) {   // row strides of A / Lp (0: n / np); a diagonal block of a larger matrix
+    if (lda == 0) lda = n;
+    if (ldl == 0) ldl = np;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ldt = np + 4;
     double* PnT = reinterpret_cast<double*>(smem);        // [2][8][ldt]
@@ -384,7 +388,7 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
             int i = R * 16 + lr + 4 * e, j = Cc * 16 + lc;
             double v = (i == j) ? 1.0 : 0.0;              // identity padding
             if (j > i) { const int t = i; i = j; j = t; } // diagonal tiles are kept fully symmetric
-            if (on && i < n) v = A[(size_t)i * n + j];
+            if (on && i < n) v = A[(size_t)i * lda + j];
             Pt[s][e] = v;
         }
     }
@@ -443,7 +447,7 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
                 for (int k = 0; k < j; ++k) sacc -= x[k] * readlane_d(d[k], j);      // L11[j][k]
                 x[j] = sacc * rinv[j];
             }
-            double* dst = Lp + (size_t)(kb + r) * np + kb;
+            double* dst = Lp + (size_t)(kb + r) * ldl + kb;
 #pragma clang loop unroll(full)
             for (int j = 0; j < QNB; ++j) {
                 cur[j * ldt + r] = x[j];
@@ -451,7 +455,7 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
             }
         }
         if (tid < QNB) {                                   // the factored diagonal block itself
-            double* dst = Lp + (size_t)(kb + tid) * np + kb;
+            double* dst = Lp + (size_t)(kb + tid) * ldl + kb;
 #pragma clang loop unroll(full)
             for (int j = 0; j < QNB; ++j) {
                 const double v = j <= tid ? d[j] : 0.0;
@@ -782,41 +786,171 @@ static inline dim3 g1(long long len, int bs = 256) { return dim3((unsigned)((len
 static int gemm(Engine& e, hipStream_t s, int m, int n, int k, double alpha, const double* A, long long a0,
                 long long a1, const double* B, long long b0, long long b1, double* C) {
     hipLaunchKernelGGL(gemm_kernel, dim3((n + 31) / 32, (m + 31) / 32), dim3(DT), 0, s, m, n, k, alpha, A, a0,
-                       a1, B, b0, b1, C, n);
+                       a1, B, b0, b1, C, n, (const double*)nullptr);
     CESX_HIP(hipGetLastError());
     return CESX_OK;
 }
 
 template <int SLOTS>
-static int potrf_reg_launch(Engine& e, hipStream_t s, int n, int np, const double* A, double* Lp) {
+static int potrf_reg_launch(Engine& e, hipStream_t s, int n, int np, const double* A, double* Lp, int lda = 0, int ldl = 0) {
     const size_t lds = (size_t)2 * QNB * (np + 4) * 8;
     CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_reg_kernel<SLOTS>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(potrf_reg_kernel<SLOTS>, dim3(1), dim3(PRT), lds, s, n, np, A, Lp, &e.d_scal->status, (long long*)nullptr);
+    hipLaunchKernelGGL(potrf_reg_kernel<SLOTS>, dim3(1), dim3(PRT), lds, s, n, np, A, Lp, &e.d_scal->status, (long long*)nullptr,
+                       lda, ldl);
     CESX_HIP(hipGetLastError());
     return CESX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Rows below a factored diagonal block of the blocked Cholesky (p > 256):  X L^T = A, L the
+// nc x nc lower-triangular block just factored (nc <= 256, a multiple of 32), A the nr x nc
+// block under it, X -> the same rows of the factor.  Rows are independent, so a workgroup
+// takes 64 of them; like potrf_reg_kernel it keeps its 64 x nc block in MFMA accumulator
+// registers (4 x nc/16 tiles over 8 waves), walks 8-column panels, solves the panel against
+// the 8 x 8 diagonal block (one row per thread) and applies the rank-8 update to the columns
+// right of it with v_mfma_f64_16x16x4_f64.  Two barriers per panel.
+// ---------------------------------------------------------------------------
+template <int SLOTS>
+__global__ __launch_bounds__(PRT, 2)
+void trsm_reg_kernel(int nr, int nc, const double* __restrict__ A, int lda, const double* __restrict__ L, int ldl,
+                     double* __restrict__ X, int ldx) {
+    __shared__ double XP[QNB][64 + 4];        // the panel: current values, then the solution (column major)
+    __shared__ double LB[QNB][256 + 4];       // L[r][kb + j] for r >= kb + j, 0 above the diagonal
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = nc / 16;                    // tile columns
+    const int lc = lane & 15, lr = lane >> 4; // C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg
+    const int rw0 = blockIdx.x * 64;
+
+    d4_t Pt[SLOTS];
+    int tR[SLOTS], tC[SLOTS];
+#pragma clang loop unroll(full)
+    for (int s = 0; s < SLOTS; ++s) {
+        const int q = wave + 8 * s;           // tiles dealt round-robin: every wave owns tiles in every column band
+        const bool on = q < 4 * T;
+        tR[s] = __builtin_amdgcn_readfirstlane(on ? q / T : -1);
+        tC[s] = __builtin_amdgcn_readfirstlane(on ? q % T : 0);
+#pragma clang loop unroll(full)
+        for (int e = 0; e < 4; ++e) {
+            const int i = rw0 + (q / T) * 16 + lr + 4 * e, j = (q % T) * 16 + lc;
+            Pt[s][e] = (on && i < nr) ? A[(size_t)i * lda + j] : 0.0;
+        }
+    }
+    for (int kb = 0; kb < nc; kb += QNB) {
+        const int kn = kb + QNB;
+        // (a) the panel's columns of the tiles that hold them -> XP; L[., kb .. kb+7] -> LB
+#pragma clang loop unroll(full)
+        for (int s = 0; s < SLOTS; ++s) {
+            if (tR[s] >= 0 && tC[s] == kb / 16) {
+                const int col = lc - (kb & 15);
+                if (col >= 0 && col < QNB) {
+#pragma clang loop unroll(full)
+                    for (int e = 0; e < 4; ++e) XP[col][tR[s] * 16 + lr + 4 * e] = Pt[s][e];
+                }
+            }
+        }
+        for (int r = (kb & ~15) + (tid >> 3); r < nc; r += PRT / 8) {
+            const int j = tid & 7;
+            LB[j][r] = r >= kb + j ? L[(size_t)r * ldl + kb + j] : 0.0;
+        }
+        __syncthreads();
+        // (b) one row per thread: x L_kk^T = a
+        if (tid < 64) {
+            double x[QNB];
+#pragma clang loop unroll(full)
+            for (int j = 0; j < QNB; ++j) {
+                double sacc = XP[j][tid];
+#pragma clang loop unroll(full)
+                for (int k = 0; k < j; ++k) sacc -= x[k] * LB[k][kb + j];       // L_kk[j][k]
+                x[j] = sacc / LB[j][kb + j];
+            }
+            const int i = rw0 + tid;
+#pragma clang loop unroll(full)
+            for (int j = 0; j < QNB; ++j) {
+                XP[j][tid] = x[j];
+                if (i < nr) X[(size_t)i * ldx + kb + j] = x[j];
+            }
+        }
+        __syncthreads();
+        // (c) rank-8 update of the tiles with columns right of the panel (the tile that holds the
+        //     panel is updated too: its remaining columns need it, the solved ones are never read again)
+#pragma clang loop unroll(full)
+        for (int s = 0; s < SLOTS; ++s) {
+            if (tR[s] >= 0 && tC[s] * 16 + 15 >= kn) {
+                double av[2], bv[2];
+#pragma clang loop unroll(full)
+                for (int h = 0; h < 2; ++h) {
+                    av[h] = XP[4 * h + lr][tR[s] * 16 + lc];
+                    bv[h] = LB[4 * h + lr][tC[s] * 16 + lc];
+                }
+#pragma clang loop unroll(full)
+                for (int h = 0; h < 2; ++h)
+                    Pt[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[h], bv[h], Pt[s], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// W (np x np) = A (n x n) bordered by the identity: the padded problem the blocked factorisation works on
+__global__ void pad_copy_kernel(int n, int np, const double* __restrict__ A, double* __restrict__ W) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)np * np) return;
+    const int i = (int)(idx / np), j = (int)(idx % np);
+    W[idx] = (i < n && j < n) ? A[(size_t)i * n + j] : (i == j ? 1.0 : 0.0);
 }
 
 // Cholesky factor of the n x n SPD matrix A into Lp (leading dimension
 // potrf_ld(n) = n rounded up to 32; entries above the diagonal are undefined).
 int potrf_ld(int n) { return (n + PNB - 1) / PNB * PNB; }
 
+static int potrf_reg_any(Engine& e, hipStream_t s, int n, int np, const double* A, double* Lp, int lda, int ldl) {
+    const int T = np / 16, ntile = T * (T + 1) / 2, slots = (ntile + 7) / 8;
+    if (slots <= 2) return potrf_reg_launch<2>(e, s, n, np, A, Lp, lda, ldl);       // np <= 64
+    if (slots <= 5) return potrf_reg_launch<5>(e, s, n, np, A, Lp, lda, ldl);       // np <= 128
+    if (slots <= 10) return potrf_reg_launch<10>(e, s, n, np, A, Lp, lda, ldl);     // np <= 192
+    if (slots <= 17) return potrf_reg_launch<17>(e, s, n, np, A, Lp, lda, ldl);     // np <= 256
+    e.err = "potrf: diagonal block too large for the register kernel";
+    return CESX_EINVAL;
+}
+
+static int trsm_reg(Engine& e, hipStream_t s, int nr, int nc, const double* A, int lda, const double* L, int ldl,
+                    double* X, int ldx) {
+    const dim3 grid((nr + 63) / 64), block(PRT);
+    const int slots = (4 * (nc / 16) + 7) / 8;
+    if (slots <= 2) hipLaunchKernelGGL(trsm_reg_kernel<2>, grid, block, 0, s, nr, nc, A, lda, L, ldl, X, ldx);
+    else if (slots <= 4) hipLaunchKernelGGL(trsm_reg_kernel<4>, grid, block, 0, s, nr, nc, A, lda, L, ldl, X, ldx);
+    else if (slots <= 6) hipLaunchKernelGGL(trsm_reg_kernel<6>, grid, block, 0, s, nr, nc, A, lda, L, ldl, X, ldx);
+    else hipLaunchKernelGGL(trsm_reg_kernel<8>, grid, block, 0, s, nr, nc, A, lda, L, ldl, X, ldx);
+    CESX_HIP(hipGetLastError());
+    return CESX_OK;
+}
+
 static int potrf(Engine& e, hipStream_t s, int n, const double* A, double* Lp) {
     const int np = potrf_ld(n);
-    {
-        const int T = np / 16, ntile = T * (T + 1) / 2, slots = (ntile + 7) / 8;
-        if (slots <= 2) return potrf_reg_launch<2>(e, s, n, np, A, Lp);       // np <= 64
-        if (slots <= 5) return potrf_reg_launch<5>(e, s, n, np, A, Lp);       // np <= 128
-        if (slots <= 10) return potrf_reg_launch<10>(e, s, n, np, A, Lp);     // np <= 192
-        if (slots <= 17) return potrf_reg_launch<17>(e, s, n, np, A, Lp);     // np <= 256
-        // larger matrices: global-memory version below
-    }
-    const size_t lds = ((size_t)(np + PNB) * (PNB + 1) + PNB) * 8;
-    if (lds > 160 * 1024) { e.err = "potrf: matrix too large for the single-workgroup kernel"; return CESX_EINVAL; }
-    CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(potrf_kernel, dim3(1), dim3(PT), lds, s, n, np, A, Lp, (double*)nullptr, &e.d_scal->status);
+    if (np <= 256) return potrf_reg_any(e, s, n, np, A, Lp, 0, 0);
+    // Blocked right-looking factorisation with 256-wide diagonal blocks (p > 256): register
+    // Cholesky of the diagonal block, register TRSM of the rows below it (64 rows per
+    // workgroup), fp64 GEMM for the trailing update -- on a work copy bordered by the identity.
+    if (!e.d_Lwork) { e.err = "potrf: no workspace for the blocked factorisation"; return CESX_EINVAL; }
+    double* W = e.d_Lwork;
+    hipLaunchKernelGGL(pad_copy_kernel, g1((long long)np * np), dim3(256), 0, s, n, np, A, W);
     CESX_HIP(hipGetLastError());
+    int rc;
+    for (int k0 = 0; k0 < np; k0 += 256) {
+        const int nb = std::min(256, np - k0), below = np - k0 - nb;
+        double* Lkk = Lp + (size_t)k0 * np + k0;
+        if ((rc = potrf_reg_any(e, s, nb, nb, W + (size_t)k0 * np + k0, Lkk, np, np))) return rc;
+        if (below > 0) {
+            double* X = Lp + (size_t)(k0 + nb) * np + k0;
+            if ((rc = trsm_reg(e, s, below, nb, W + (size_t)(k0 + nb) * np + k0, np, Lkk, np, X, np))) return rc;
+            double* W22 = W + (size_t)(k0 + nb) * np + k0 + nb;
+            hipLaunchKernelGGL(gemm_kernel, dim3((below + 31) / 32, (below + 31) / 32), dim3(DT), 0, s, below, below, nb, -1.0,
+                               X, (long long)np, 1LL, X, 1LL, (long long)np, W22, np, W22);
+            CESX_HIP(hipGetLastError());
+        }
+    }
     return CESX_OK;
 }
 
@@ -860,6 +994,9 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
     // is done or in flight on the side stream; otherwise do it here, in line.
     const bool early = e.chol_inflight;
     if (early) CESX_HIP(hipStreamWaitEvent(s, e.ev_c, 0));
+    // p or n > 256: every Cholesky goes through the one blocked-factorisation workspace, so the rest of K2
+    // (which may factor hk C_gg + Gamma or Sigma + hk C) starts only after the side-stream chol(C)
+    if (early && e.d_Lwork) CESX_HIP(hipStreamWaitEvent(s, e.ev_b, 0));
     hipLaunchKernelGGL(center_kernel, dim3(NPB), dim3(DT), 0, s, mv, e.d_shift64, e.d_y, e.d_ustar,
                        e.diag_gamma ? e.d_gw : (const double*)nullptr,
                        e.diag_sigma ? e.d_sw : (const double*)nullptr, unbiased, early ? 2 : 3, e.d_ubar, e.d_gbar,

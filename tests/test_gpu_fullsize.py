@@ -181,3 +181,33 @@ def test_c5_dimensions_p512(dtype, tol):
     ref, hk, met = torch_factored_aldi(prob, Ud.double(), Gd.double(), xid.double())
     assert ((out.double() - ref).abs().max() / ref.abs().max()).item() < tol
     assert res.hk == pytest.approx(hk, rel=1e-4 if dtype == "float32" else 1e-9)
+
+
+@pytest.mark.parametrize("p", [260, 300, 384, 512, 700])
+@pytest.mark.parametrize("update", ["aldi", "eks"])
+def test_blocked_cholesky_large_p(p, update):
+    """p > 256: chol(C) through the blocked factorisation (256-wide register Cholesky of the diagonal
+    blocks, register TRSM of the rows below, fp64 GEMM trailing update) against numpy, for matrix
+    sizes that are / are not multiples of the block and tile sizes, and the step that uses it
+    (eks also factors Sigma + hk C through the same workspace)."""
+    import torch
+    from ces_amd import engine
+    n, J = 40, 2048
+    rng = np.random.default_rng(p)
+    A = rng.standard_normal((n, p)) / np.sqrt(p)
+    ustar = rng.standard_normal((p, 1))
+    U = ustar + rng.standard_normal((p, J))
+    G = A @ U
+    eng = engine.Engine(p, n, J, dtype="float64")
+    eng.set_problem((A @ ustar).ravel(), 0.01 * np.eye(n), np.zeros((p, 1)), 100.0 * np.eye(p), ustar)
+    out = eng.step(engine.step_params(update=update, time_step="constant" if update == "eks" else None, delta_t=0.01),
+                   eng.to_device(U), eng.to_device(G), xi=eng.to_device(rng.standard_normal((p, J))))
+    res = eng.result()
+    assert np.isfinite(res.hk) and bool(torch.isfinite(out).all())
+    dd = eng.debug_dense()
+    div = J if update == "eks" else J - 1
+    Uc = U - U.mean(axis=1, keepdims=True)
+    C = Uc @ Uc.T / div + 1e-8 * np.eye(p)
+    assert np.abs(dd["C"] - C).max() / np.abs(C).max() < 1e-10
+    L = np.linalg.cholesky(dd["C"])
+    assert np.abs(np.tril(dd["L"]) - L).max() / np.abs(L).max() < 1e-9
