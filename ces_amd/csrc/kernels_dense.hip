@@ -186,146 +186,6 @@ void matvec_kernel(int rows, int cols, const double* __restrict__ A, const doubl
 }
 
 // ---------------------------------------------------------------------------
-// Cholesky A = L L^T of an n x n SPD matrix, one workgroup, blocked
-// right-looking with the current panel in LDS.  L gets the lower factor and a
-// zero strict upper triangle.  A non-positive pivot sets *status = CESX_ENOTPD
-// (np.linalg.LinAlgError at ces/calibrate.py:446/:487/:526).
-// ---------------------------------------------------------------------------
-constexpr int PT = 512;    // threads (<= 256 VGPRs each: a 32-value row lives in registers)
-constexpr int PNB = 32;    // panel width
-#ifndef POTRF_S1      // dev switches of tools/potrf_bench.hip (timing ablation only)
-#define POTRF_S1 1
-#define POTRF_S2 1
-#define POTRF_S3 1
-#endif
-
-__device__ __forceinline__ double readlane_d(double v, int lane) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_readlane(lo, lane);
-    hi = __builtin_amdgcn_readlane(hi, lane);
-    return __hiloint2double(hi, lo);
-}
-
-// One workgroup, right-looking, 32-column panels:
-//   1. the 32 x 32 diagonal block is factored by ONE wave with row i in the
-//      registers of lane i (column values broadcast with v_readlane, no LDS
-//      round trips, no barriers inside the block)
-//   2. every row below solves x L11^T = a with its 32 values in registers
-//      (L11 read from LDS as broadcasts)
-//   3. trailing update A22 -= L21 L21^T in 4 x 4 register patches from LDS.
-__global__ __launch_bounds__(PT)
-void potrf_kernel(int n, int np, const double* __restrict__ A, double* __restrict__ Lp,
-                  double* __restrict__ L, int* status) {
-    // Lp: np x np workspace, np = n rounded up to 32; the padding is an identity
-    // block so that every panel is exactly 32 wide (no ragged-edge branches in
-    // the fully unrolled register code).
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int ldp = PNB + 1;
-    double* D = reinterpret_cast<double*>(smem);          // [32][33] diagonal block (factor)
-    double* rinv = D + PNB * ldp;                         // [32] 1 / l_jj
-    double* Pn = rinv + PNB;                              // [np][33] panel below it
-    const int tid = threadIdx.x;
-    for (long long idx = tid; idx < (long long)np * np; idx += PT) {
-        const int i = (int)(idx / np), j = (int)(idx % np);
-        Lp[idx] = (i < n && j <= i) ? A[(size_t)i * n + j] : ((i == j) ? 1.0 : 0.0);
-    }
-    __syncthreads();
-    for (int kb = 0; kb < np; kb += PNB) {
-        const int m = np - kb - PNB;
-        // ---- 1. diagonal block, wave 0, lane = row
-        if (POTRF_S1 && tid < 64) {
-            const int i = tid & 31;
-            const double* src = Lp + (size_t)(kb + i) * np + kb;
-            double d[PNB];
-#pragma clang loop unroll(full)
-            for (int j = 0; j < PNB; ++j) d[j] = src[j];
-            bool bad = false;
-#pragma clang loop unroll(full)
-            for (int j = 0; j < PNB; ++j) {
-                double djj = readlane_d(d[j], j);
-                if (!(djj > 0.0)) { bad = true; djj = 1.0; }
-                const double rs = 1.0 / sqrt(djj);
-                const double lij = (i == j) ? djj * rs : d[j] * rs;
-                d[j] = lij;
-                if (i == j) rinv[j] = rs;
-#pragma clang loop unroll(full)
-                for (int k = j + 1; k < PNB; ++k) {
-                    // no lane predicate: entries above the diagonal of a lane's row
-                    // collect garbage that nothing ever reads
-                    d[k] -= lij * readlane_d(lij, k);
-                }
-            }
-            if (bad && tid == 0) *status = CESX_ENOTPD;
-            if (tid < 32) {
-                double* dst = Lp + (size_t)(kb + i) * np + kb;
-#pragma clang loop unroll(full)
-                for (int j = 0; j < PNB; ++j) {
-                    const double v = j <= i ? d[j] : 0.0;
-                    D[i * ldp + j] = v;
-                    dst[j] = v;
-                }
-            }
-        }
-        __syncthreads();
-        // ---- 2. panel rows: x L11^T = a, one row per thread, row in registers
-        for (int r = tid; POTRF_S2 && r < m; r += PT) {
-            double* row = Lp + (size_t)(kb + PNB + r) * np + kb;
-            double x[PNB];
-#pragma clang loop unroll(full)
-            for (int j = 0; j < PNB; ++j) x[j] = row[j];
-#pragma clang loop unroll(full)
-            for (int j = 0; j < PNB; ++j) {
-                double sacc = x[j];
-#pragma clang loop unroll(full)
-                for (int k = 0; k < j; ++k) sacc -= x[k] * D[j * ldp + k];
-                x[j] = sacc * rinv[j];
-                asm volatile("" ::: "memory");           // stop LICM from hoisting all 496 LDS reads of D
-            }
-#pragma clang loop unroll(full)
-            for (int j = 0; j < PNB; ++j) {
-                Pn[r * ldp + j] = x[j];
-                row[j] = x[j];
-            }
-        }
-        __syncthreads();
-        // ---- 3. trailing update (lower part), 4 x 4 patches (m is a multiple of 32)
-        const int mb = m / 4;
-        const int npatch = mb * (mb + 1) / 2;
-        for (int pt = tid; POTRF_S3 && pt < npatch; pt += PT) {
-            int bi = (int)((sqrt(8.0 * pt + 1.0) - 1.0) * 0.5);
-            while ((bi + 1) * (bi + 2) / 2 <= pt) ++bi;
-            while (bi * (bi + 1) / 2 > pt) --bi;
-            const int bj = pt - bi * (bi + 1) / 2;
-            double acc[4][4] = {};
-            const double* pa = Pn + bi * 4 * ldp;
-            const double* pb = Pn + bj * 4 * ldp;
-#pragma unroll 8
-            for (int k = 0; k < PNB; ++k) {
-                double a[4], b[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { a[e] = pa[e * ldp + k]; b[e] = pb[e * ldp + k]; }
-#pragma unroll
-                for (int x = 0; x < 4; ++x)
-#pragma unroll
-                    for (int z = 0; z < 4; ++z) acc[x][z] += a[x] * b[z];
-            }
-            double* dst = Lp + (size_t)(kb + PNB + bi * 4) * np + kb + PNB + bj * 4;
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int z = 0; z < 4; ++z)
-                    if (bj * 4 + z <= bi * 4 + x) dst[(size_t)x * np + z] -= acc[x][z];
-        }
-        __syncthreads();
-    }
-    if (L != nullptr)
-        for (long long idx = tid; idx < (long long)n * n; idx += PT) {
-            const int i = (int)(idx / n), j = (int)(idx % n);
-            L[idx] = j <= i ? Lp[(size_t)i * np + j] : 0.0;
-        }
-}
-
-// ---------------------------------------------------------------------------
 // Register-resident Cholesky for np <= 256 (np = n rounded up to 32).  The
 // lower triangle lives in the accumulator registers of 8 waves as 16 x 16
 // tiles in v_mfma_f64_16x16x4_f64 C/D layout (np = 256: 136 tiles, 17 per
@@ -344,9 +204,17 @@ void potrf_kernel(int n, int np, const double* __restrict__ A, double* __restric
 // Two barriers per panel.  A : n x n (lower part read); Lp : np x np, leading
 // dimension np, entries above the diagonal are left undefined.
 // ---------------------------------------------------------------------------
+constexpr int PNB = 32;    // leading dimensions of Cholesky factors are rounded up to this
 constexpr int PRT = 512;
 constexpr int QNB = 8;
 using d4_t = double __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
 
 __device__ __forceinline__ double rsqrt_nr(double a) {
     double y = __builtin_amdgcn_rsq(a);                   // v_rsq_f64: ~26 good bits
@@ -494,19 +362,6 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
     if (dbg && tid == 0)
         for (int i = 0; i < 5; ++i) dbg[i] = tph[i];
 #undef PH
-}
-
-// Linv = L^{-1} for lower-triangular L, one column per thread (forward substitution).
-__global__ __launch_bounds__(PT)
-void trtri_kernel(int n, const double* __restrict__ L, int ldl, double* __restrict__ Linv) {
-    for (int j = threadIdx.x; j < n; j += PT) {
-        for (int i = 0; i < j; ++i) Linv[(size_t)i * n + j] = 0.0;
-        for (int i = j; i < n; ++i) {
-            double s = (i == j) ? 1.0 : 0.0;
-            for (int k = j; k < i; ++k) s -= L[(size_t)i * ldl + k] * Linv[(size_t)k * n + j];
-            Linv[(size_t)i * n + j] = s / L[(size_t)i * ldl + i];
-        }
-    }
 }
 
 // X = a * A + B with a = (*ap) / (*divp)  (both on device; divp may be null)
@@ -834,7 +689,8 @@ void trsm_reg_kernel(int nr, int nc, const double* __restrict__ A, int lda, cons
 #pragma clang loop unroll(full)
         for (int e = 0; e < 4; ++e) {
             const int i = rw0 + (q / T) * 16 + lr + 4 * e, j = (q % T) * 16 + lc;
-            Pt[s][e] = (on && i < nr) ? A[(size_t)i * lda + j] : 0.0;
+            // A == nullptr: the right-hand side is the identity (columns ioff .. of it): X = L^{-T}
+            Pt[s][e] = (on && i < nr) ? (A ? A[(size_t)i * lda + j] : (i == j + lda ? 1.0 : 0.0)) : 0.0;
         }
     }
     for (int kb = 0; kb < nc; kb += QNB) {
@@ -955,13 +811,49 @@ static int potrf(Engine& e, hipStream_t s, int n, const double* A, double* Lp) {
 }
 
 // Ainv = A^{-1} for SPD A (n x n); uses t1 (chol), t2 (tri inverse)
+// R (nr x nb, row stride nb) = columns c0 .. c0+nb-1 of A (row stride lda), or of the identity (A == nullptr)
+__global__ void block_copy_kernel(int nr, int nb, const double* __restrict__ A, int lda, int c0, double* __restrict__ R) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)nr * nb) return;
+    const int i = (int)(idx / nb), j = (int)(idx % nb);
+    R[idx] = A ? A[(size_t)i * lda + c0 + j] : (i == c0 + j ? 1.0 : 0.0);
+}
+
+// X L^T = A (A == nullptr: the identity, i.e. X = L^{-T}) for the np x np lower-triangular L (np a
+// multiple of 32, padding = identity), nr rows.  np <= 256: one register TRSM; larger: column blocks
+// of 256, X_k = (A_k - sum_{j<k} X_j L_kj^T) L_kk^{-T}, the sum by fp64 GEMMs into the workspace.
+static int trsm_right_lt(Engine& e, hipStream_t s, int nr, int np, const double* A, int lda, const double* L, int ldl,
+                         double* X, int ldx) {
+    if (np <= 256) return trsm_reg(e, s, nr, np, A, A ? lda : 0, L, ldl, X, ldx);
+    if (!e.d_Lwork) { e.err = "trsm: no workspace"; return CESX_EINVAL; }
+    double* R = e.d_Lwork;
+    int rc;
+    for (int k0 = 0; k0 < np; k0 += 256) {
+        const int nb = std::min(256, np - k0);
+        hipLaunchKernelGGL(block_copy_kernel, g1((long long)nr * nb), dim3(256), 0, s, nr, nb, A, lda, k0, R);
+        CESX_HIP(hipGetLastError());
+        for (int j0 = 0; j0 < k0; j0 += 256) {
+            // R -= X[:, j0 .. j0+255] * L[k0 .. k0+nb-1, j0 .. j0+255]^T
+            hipLaunchKernelGGL(gemm_kernel, dim3((nb + 31) / 32, (nr + 31) / 32), dim3(DT), 0, s, nr, nb, 256, -1.0,
+                               X + j0, (long long)ldx, 1LL, L + (size_t)k0 * ldl + j0, 1LL, (long long)ldl, R, nb, R);
+            CESX_HIP(hipGetLastError());
+        }
+        if ((rc = trsm_reg(e, s, nr, nb, R, nb, L + (size_t)k0 * ldl + k0, ldl, X + k0, ldx))) return rc;
+    }
+    return CESX_OK;
+}
+
+// Ainv = A^{-1} for SPD A (n x n); uses t1 (chol), t2 (X = L^{-T}):  A^{-1} = L^{-T} L^{-1} = X X^T
 static int spd_inverse(Engine& e, hipStream_t s, int n, const double* A, double* Ainv) {
     int rc;
+    const int np = potrf_ld(n);
     if ((rc = potrf(e, s, n, A, e.d_t1))) return rc;
-    hipLaunchKernelGGL(trtri_kernel, dim3(1), dim3(PT), 0, s, n, e.d_t1, potrf_ld(n), e.d_t2);
+    if ((rc = trsm_right_lt(e, s, n, np, nullptr, 0, e.d_t1, np, e.d_t2, np))) return rc;
+    // X is upper triangular: X[i][k] = 0 for k < i; columns >= n of the rows < n are zero
+    hipLaunchKernelGGL(gemm_kernel, dim3((n + 31) / 32, (n + 31) / 32), dim3(DT), 0, s, n, n, n, 1.0,
+                       e.d_t2, (long long)np, 1LL, e.d_t2, 1LL, (long long)np, Ainv, n, (const double*)nullptr);
     CESX_HIP(hipGetLastError());
-    // Ainv = Linv^T Linv : A(i,k) = Linv[k][i]
-    return gemm(e, s, n, n, n, 1.0, e.d_t2, 1, n, e.d_t2, n, 1, Ainv);
+    return CESX_OK;
 }
 
 template <typename T>
