@@ -387,13 +387,40 @@ __global__ void select_kernel(long long len, const Scalars* __restrict__ sc, con
 // Lanczos with full re-orthogonalisation (m steps, one workgroup) followed by
 // bisection on the tridiagonal matrix.
 // ---------------------------------------------------------------------------
+// largest eigenvalue of tridiag(alpha[0..m), beta[0..m-1)) by bisection (Sturm count); one thread
+__device__ double tridiag_max_eig(const double* alpha, const double* beta, int m) {
+    double lo = alpha[0], hi = alpha[0];
+    for (int i = 0; i < m; ++i) {
+        const double bl = i > 0 ? fabs(beta[i - 1]) : 0.0, br = i + 1 < m ? fabs(beta[i]) : 0.0;
+        lo = fmin(lo, alpha[i] - bl - br);
+        hi = fmax(hi, alpha[i] + bl + br);
+    }
+    for (int it = 0; it < 200; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        if (mid == lo || mid == hi) break;
+        int cnt = 0;                                   // number of eigenvalues < mid
+        double d = 1.0;
+        for (int i = 0; i < m; ++i) {
+            const double b2 = i > 0 ? beta[i - 1] * beta[i - 1] : 0.0;
+            d = alpha[i] - mid - (i > 0 ? b2 / d : 0.0);
+            if (d == 0.0) d = 1e-300;
+            if (d < 0.0) ++cnt;
+        }
+        if (cnt >= m) hi = mid; else lo = mid;
+    }
+    return 0.5 * (lo + hi);
+}
+
 __global__ __launch_bounds__(DT)
 void lanczos_kernel(int n, const double* __restrict__ B, const double* __restrict__ divp, int msteps,
                     double* __restrict__ V, double* __restrict__ alpha, double* __restrict__ beta,
                     Scalars* __restrict__ sc) {
     __shared__ double red[DT / 64];
     __shared__ double s_val;
+    __shared__ double s_prev, s_done;
+    __shared__ double cq[128];                 // projections of one re-orthogonalisation pass (msteps <= 127)
     const int tid = threadIdx.x;
+    if (tid == 0) { s_prev = -1.0; s_done = 0.0; }
     // start vector: normalised ones + small ramp (generic direction)
     double nrm = 0.0;
     for (int i = tid; i < n; i += DT) { const double v = 1.0 + 0.01 * i; V[i] = v; nrm += v * v; }
@@ -404,27 +431,36 @@ void lanczos_kernel(int n, const double* __restrict__ B, const double* __restric
     for (int k = 0; k < msteps; ++k) {
         double* vk = V + (size_t)k * n;
         double* w = V + (size_t)(k + 1) * n;
-        // w = B vk
+        // w = B vk  (B is symmetric: column i of B read along rows, so that consecutive threads
+        // read consecutive addresses)
         for (int i = tid; i < n; i += DT) {
             double s = 0.0;
-            for (int c = 0; c < n; ++c) s += B[(size_t)i * n + c] * vk[c];
+#pragma unroll 8
+            for (int c = 0; c < n; ++c) s += B[(size_t)c * n + i] * vk[c];
             w[i] = s;
         }
         __syncthreads();
-        double a = 0.0;
-        for (int i = tid; i < n; i += DT) a += w[i] * vk[i];
-        a = dblock_sum(a, red);
-        if (tid == 0) alpha[k] = a;
-        // full re-orthogonalisation against v_0..v_k (twice is enough)
-        for (int pass = 0; pass < 2; ++pass)
-            for (int q = 0; q <= k; ++q) {
+        // full re-orthogonalisation against v_0..v_k, classical Gram-Schmidt done twice: all k+1
+        // projections of a pass first (one wave per dot product), then one update of w
+        for (int pass = 0; pass < 2; ++pass) {
+            const int lane = tid & 63, wv = tid >> 6;
+            for (int q = wv; q <= k; q += DT / 64) {
                 const double* vq = V + (size_t)q * n;
                 double d = 0.0;
-                for (int i = tid; i < n; i += DT) d += w[i] * vq[i];
-                d = dblock_sum(d, red);
-                for (int i = tid; i < n; i += DT) w[i] -= d * vq[i];
-                __syncthreads();
+                for (int i = lane; i < n; i += 64) d += w[i] * vq[i];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o, 64);
+                if (lane == 0) cq[q] = d;
             }
+            __syncthreads();
+            if (pass == 0 && tid == 0) alpha[k] = cq[k];        // alpha_k = (B v_k) . v_k
+            for (int i = tid; i < n; i += DT) {
+                double acc = 0.0;
+                for (int q = 0; q <= k; ++q) acc += cq[q] * V[(size_t)q * n + i];
+                w[i] -= acc;
+            }
+            __syncthreads();
+        }
         double b = 0.0;
         for (int i = tid; i < n; i += DT) b += w[i] * w[i];
         b = sqrt(dblock_sum(b, red));
@@ -433,31 +469,21 @@ void lanczos_kernel(int n, const double* __restrict__ B, const double* __restric
         if (!(b > 1e-14 * fabs(alpha[0]) + 1e-300)) break;      // invariant subspace found
         for (int i = tid; i < n; i += DT) w[i] /= b;
         __syncthreads();
+        // the largest Ritz value converges long before the Krylov space is exhausted: stop when it
+        // has not moved by more than a few ulps over 8 further steps
+        if ((k & 7) == 7) {
+            if (tid == 0) {
+                const double th = tridiag_max_eig(alpha, beta, m);
+                s_done = fabs(th - s_prev) <= 4e-16 * fabs(th) ? 1.0 : 0.0;
+                s_prev = th;
+            }
+            __syncthreads();
+            if (s_done != 0.0) break;
+        }
     }
     __syncthreads();
-    // largest eigenvalue of tridiag(alpha[0..m), beta[0..m-1)) by bisection (Sturm count)
     if (tid == 0) {
-        double lo = alpha[0], hi = alpha[0];
-        for (int i = 0; i < m; ++i) {
-            const double bl = i > 0 ? fabs(beta[i - 1]) : 0.0, br = i + 1 < m ? fabs(beta[i]) : 0.0;
-            lo = fmin(lo, alpha[i] - bl - br);
-            hi = fmax(hi, alpha[i] + bl + br);
-        }
-        for (int it = 0; it < 200; ++it) {
-            const double mid = 0.5 * (lo + hi);
-            if (mid == lo || mid == hi) break;
-            // number of eigenvalues < mid
-            int cnt = 0;
-            double d = 1.0;
-            for (int i = 0; i < m; ++i) {
-                const double b2 = i > 0 ? beta[i - 1] * beta[i - 1] : 0.0;
-                d = alpha[i] - mid - (i > 0 ? b2 / d : 0.0);
-                if (d == 0.0) d = 1e-300;
-                if (d < 0.0) ++cnt;
-            }
-            if (cnt >= m) hi = mid; else lo = mid;
-        }
-        s_val = 0.5 * (lo + hi) / (*divp);
+        s_val = tridiag_max_eig(alpha, beta, m) / (*divp);
         sc->radspec = s_val > 0.0 ? s_val : 0.0;
     }
 }
