@@ -169,8 +169,9 @@ def main():
             t_hist[0] = res.t_new
         return res
 
-    # untimed pre-warm (clocks, code objects, allocator) before the W warmup steps
-    run_steps(0, 8)
+    # untimed pre-warm before the W warmup steps: the first ~30 steps after start-up run 3-5 % slower
+    # (clock / power state, code objects, allocator); 64 steps = 32 ms reach the steady state
+    run_steps(0, int(os.environ.get("CESX_BENCH_PREWARM", "64")))
     t_hist[0] = 0.0
     if args.warmup:
         run_steps(0, args.warmup)
