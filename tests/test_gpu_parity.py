@@ -412,3 +412,30 @@ def test_pde_model_run_drop_in(eng_mod, update):
     assert rel_err(eks.W0, g[update + "_W0"]) < 1e-5 and rel_err(eks.Gstar, g[update + "_Gstar"]) < 1e-5
     for k in ("self-bias", "self-bias-data", "bias-data", "bias", "t"):
         assert np.allclose(eks.metrics[k], g[update + "_metric_" + k], rtol=1e-5), k
+
+
+def test_c_abi_argument_checks(eng_mod):
+    """Error behaviour of the C ABI itself (include/cesx.h): bad shapes, aliasing, call order."""
+    import ctypes as C
+    with pytest.raises(eng_mod.CesxError):
+        eng_mod.Engine(0, 3, 16)                                   # p < 1
+    with pytest.raises(eng_mod.CesxError):
+        eng_mod.Engine(20000, 3, 16)                               # p > 16384
+    eng = eng_mod.Engine(4, 3, 64, dtype="float64")
+    res = eng_mod.StepResult()
+    assert eng.lib.cesx_result(eng._h, C.byref(res)) == eng_mod.ESTATE      # no step enqueued yet
+    d = _synthetic(4, 3, 64, seed=1)
+    eng.set_problem(d["y"], d["Gamma"], d["mu"], d["sigma"], d["ustar"])
+    U, G = eng.to_device(d["U0"]), eng.to_device(d["G"])
+    prm = eng_mod.step_params(update="aldi")
+    with pytest.raises(ValueError, match="alias"):
+        eng.step(prm, U, G, xi=None, out=U)                        # U_next must not alias U (ces/calibrate.py:357)
+    with pytest.raises(ValueError):
+        eng.step(prm, U[:, :32].contiguous(), G, xi=None)          # wrong shard width
+    bad = eng_mod.step_params(update="aldi")
+    bad.update = 7
+    with pytest.raises(ValueError, match="update"):
+        eng.step(bad, U, G, xi=None)
+    assert eng.lib.cesx_abi_version() == eng_mod.ABI_VERSION
+    out = eng.step(prm, U, G, xi=None)                             # the handle is still usable afterwards
+    assert np.isfinite(eng.result().hk) and out.shape == (4, 64)
