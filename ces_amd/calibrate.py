@@ -160,9 +160,15 @@ class sampling(enka):
 
     # -- engine plumbing -------------------------------------------------
     def _get_engine(self):
-        key = (self.p, self.n_obs, self.J, str(self.engine_dtype), int(self.device), int(self.seed))
+        dtype = str(self.engine_dtype)
+        if dtype == "float32" and self.J <= self.p + 1:
+            # a rank-deficient ensemble covariance (J - 1 < p) is kept positive definite by the
+            # reference's 1e-8 jitter only (ces/calibrate.py:424/:476); fp32 moments cannot resolve
+            # that, so such runs use the fp64 engine
+            dtype = "float64"
+        key = (self.p, self.n_obs, self.J, dtype, int(self.device), int(self.seed))
         if getattr(self, "_engine_key", None) != key:
-            self._engine = _engine.Engine(self.p, self.n_obs, self.J, dtype=self.engine_dtype,
+            self._engine = _engine.Engine(self.p, self.n_obs, self.J, dtype=dtype,
                                           device=self.device, seed=self.seed)
             self._engine_key = key
             self._step_counter = 0

@@ -439,3 +439,20 @@ def test_c_abi_argument_checks(eng_mod):
     assert eng.lib.cesx_abi_version() == eng_mod.ABI_VERSION
     out = eng.step(prm, U, G, xi=None)                             # the handle is still usable afterwards
     assert np.isfinite(eng.result().hk) and out.shape == (4, 64)
+
+
+def test_rank_deficient_ensemble_fp32_request_runs_in_fp64(eng_mod):
+    """J - 1 < p: the covariance is PD only through the 1e-8 jitter (ces/calibrate.py:476); the drop-in
+    class then uses the fp64 engine even when 'float32' is requested, and matches the oracle."""
+    from ces_amd.calibrate import sampling
+    from oracle import ces_numpy as oc
+    p, n, J = 40, 6, 20
+    d = _synthetic(p, n, J, seed=41)
+    eks = sampling(p=p, n_obs=n, J=J)
+    eks.mu, eks.sigma, eks.ustar = d["mu"], d["sigma"], d["ustar"]
+    eks.engine_dtype = "float32"
+    eks.Uall = [d["U0"]]
+    Uk = eks.eks_update_aldi(d["y"], d["U0"], d["G"], d["Gamma"], 0, xi=d["xi"])
+    st = oc.OracleState(p, n, J, d["mu"], d["sigma"], d["ustar"])
+    want = oc.literal_step(st, d["y"], d["U0"], d["G"], d["Gamma"], d["xi"], update="aldi")
+    assert rel_err(Uk, want) < 1e-7
