@@ -161,10 +161,11 @@ class sampling(enka):
     # -- engine plumbing -------------------------------------------------
     def _get_engine(self):
         dtype = str(self.engine_dtype)
-        if dtype == "float32" and self.J <= self.p + 1:
+        if dtype == "float32" and self.J < 4 * self.p:
             # a rank-deficient ensemble covariance (J - 1 < p) is kept positive definite by the
-            # reference's 1e-8 jitter only (ces/calibrate.py:424/:476); fp32 moments cannot resolve
-            # that, so such runs use the fp64 engine
+            # reference's 1e-8 jitter only (ces/calibrate.py:424/:476), and one with few more particles
+            # than dimensions is close to that; fp32 moments cannot resolve it, so ensembles smaller
+            # than 4 p (cheap anyway) use the fp64 engine
             dtype = "float64"
         key = (self.p, self.n_obs, self.J, dtype, int(self.device), int(self.seed))
         if getattr(self, "_engine_key", None) != key:
