@@ -6,12 +6,15 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <sched.h>
+#include <stdexcept>
+#include <thread>
 
 using namespace cesx;
 
 namespace {
 
-std::string g_create_err;
+thread_local std::string g_create_err;      // per-thread: cesx_create has no handle to hang the message on
 
 // ---- tiny host-side dense helpers (set-up only: Gamma and Sigma are factorised once) ----
 bool host_chol(int n, const double* A, std::vector<double>& L) {
@@ -75,10 +78,25 @@ int upload_T(Engine& e, void* dst, const double* src, size_t len) {
 
 #define TRY(x) do { int _rc = (x); if (_rc != CESX_OK) return _rc; } while (0)
 
-int set_device(Engine& e) {
-    CESX_HIP(hipSetDevice(e.cfg.device));
-    return CESX_OK;
-}
+// Every entry point runs on the engine's device and gives the calling thread its own device
+// back on return (a process may hold engines on several devices; cesx_destroy runs from GC).
+struct DeviceGuard {
+    int prev = -1, dev;
+    hipError_t st = hipSuccess;
+    explicit DeviceGuard(int device) : dev(device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) st = hipSetDevice(dev);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+};
+#define SET_DEVICE(e)                                                               \
+    DeviceGuard _dg((e).cfg.device);                                                \
+    if (_dg.st != hipSuccess) {                                                     \
+        (e).err = std::string("hipSetDevice: ") + hipGetErrorString(_dg.st);        \
+        return CESX_EHIP;                                                           \
+    }
 
 int check_prm(Engine& e, const cesx_step_params* prm) {
     if (!prm || prm->struct_bytes != sizeof(cesx_step_params)) { e.err = "bad cesx_step_params"; return CESX_EINVAL; }
@@ -143,7 +161,7 @@ static hipError_t create_side_stream(Engine& e) {
     return hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking);
 }
 
-int cesx_create(const cesx_config* cfg, cesx_handle* out) {
+static int create_impl(const cesx_config* cfg, cesx_handle* out) {
     if (out) *out = nullptr;
     if (!cfg || !out || cfg->struct_bytes != sizeof(cesx_config)) { g_create_err = "bad cesx_config"; return CESX_EINVAL; }
     if (cfg->p < 1 || cfg->n_obs < 1 || cfg->J_local < 1 || cfg->J_global < cfg->J_local || cfg->j_offset < 0 ||
@@ -166,7 +184,8 @@ int cesx_create(const cesx_config* cfg, cesx_handle* out) {
     if (const char* uv = std::getenv("CESX_UPDATE_V1")) e.update_v2 = uv[0] == '0';
     auto fail = [&](int rc) { g_create_err = e.err; cesx_destroy(reinterpret_cast<cesx_handle>(ep)); return rc; };
     int rc;
-    if ((rc = set_device(e))) return fail(rc);
+    DeviceGuard dg(cfg->device);
+    if (dg.st != hipSuccess) { e.err = std::string("hipSetDevice: ") + hipGetErrorString(dg.st); return fail(CESX_EHIP); }
     {
         int ncu = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && ncu > 0) e.num_cus = ncu;
@@ -265,10 +284,23 @@ int cesx_create(const cesx_config* cfg, cesx_handle* out) {
     return CESX_OK;
 }
 
+int cesx_create(const cesx_config* cfg, cesx_handle* out) {
+    // no C++ exception may cross the C boundary (std::vector growth in the Gram plan, std::string)
+    try {
+        return create_impl(cfg, out);
+    } catch (const std::exception& ex) {
+        try { g_create_err = std::string("cesx_create: ") + ex.what(); } catch (...) {}
+    } catch (...) {
+        try { g_create_err = "cesx_create: unknown C++ exception"; } catch (...) {}
+    }
+    if (out) *out = nullptr;      // (a half-built engine is leaked rather than destroyed twice)
+    return CESX_EINVAL;
+}
+
 void cesx_destroy(cesx_handle h) {
     if (!h) return;
     Engine& e = *reinterpret_cast<Engine*>(h);
-    (void)hipSetDevice(e.cfg.device);
+    DeviceGuard dg(e.cfg.device);
     void* ptrs[] = {e.d_y, e.d_mu, e.d_ustar, e.d_Gamma, e.d_Ginv, e.d_gw, e.d_Wh, e.d_Sigma, e.d_Sinv, e.d_sw,
                     e.d_shift64, e.d_shiftT, e.d_yT, e.d_gwT, e.d_GinvT, e.d_wdT, e.d_W, e.d_Wf, e.d_Lwork,
                     e.d_bias, e.d_Wfwd, e.d_metric_part, e.d_metric_sums,
@@ -298,7 +330,7 @@ int cesx_set_problem(cesx_handle h, const double* y, const double* Gamma, const 
     if (!h) return CESX_EINVAL;
     Engine& e = *reinterpret_cast<Engine*>(h);
     if (!y || !Gamma || !mu || !Sigma || !ustar) { e.err = "cesx_set_problem: null pointer"; return CESX_EINVAL; }
-    TRY(set_device(e));
+    SET_DEVICE(e);
     const int p = e.p, n = e.n;
     std::vector<double> L, Li, inv;
     if (!host_chol(n, Gamma, L)) { e.err = "Gamma is not symmetric positive definite"; return CESX_ENOTPD; }
@@ -335,7 +367,7 @@ int cesx_colsum(cesx_handle h, const void* U, const void* G, double* sums, void*
     if (!h) return CESX_EINVAL;
     Engine& e = *reinterpret_cast<Engine*>(h);
     if (!U || !G || !sums) { e.err = "cesx_colsum: null pointer"; return CESX_EINVAL; }
-    TRY(set_device(e));
+    SET_DEVICE(e);
     return launch_colsum(e, U, G, sums, (hipStream_t)stream);
 }
 
@@ -343,7 +375,7 @@ int cesx_set_shift(cesx_handle h, const double* sums, void* stream) {
     if (!h) return CESX_EINVAL;
     Engine& e = *reinterpret_cast<Engine*>(h);
     if (!sums) { e.err = "cesx_set_shift: null pointer"; return CESX_EINVAL; }
-    TRY(set_device(e));
+    SET_DEVICE(e);
     return launch_set_shift(e, sums, (hipStream_t)stream);
 }
 
@@ -351,7 +383,7 @@ static int moments_check(Engine& e, const void* U, const void* G, double* mom) {
     if (!U || !G || !mom) { e.err = "cesx_moments: null pointer"; return CESX_EINVAL; }
     if (!e.problem_set) { e.err = "cesx_set_problem has not been called"; return CESX_ESTATE; }
     if (!e.shift_valid) { e.err = "no centring shift: call cesx_colsum + cesx_set_shift (or cesx_step with recenter) first"; return CESX_ESTATE; }
-    return set_device(e);
+    return CESX_OK;
 }
 
 int cesx_moments_uu(cesx_handle h, const void* U, const void* G, double* mom, void* stream) {
@@ -366,7 +398,7 @@ int cesx_chol_async(cesx_handle h, int update, const double* mom, void* stream) 
     Engine& e = *reinterpret_cast<Engine*>(h);
     if (!mom || update < 0 || update > 2) { e.err = "cesx_chol_async: bad argument"; return CESX_EINVAL; }
     if (!e.problem_set) { e.err = "cesx_set_problem has not been called"; return CESX_ESTATE; }
-    TRY(set_device(e));
+    SET_DEVICE(e);
     return launch_chol_async(e, update, mom, (hipStream_t)stream);
 }
 
@@ -390,7 +422,7 @@ int cesx_apply_drift(cesx_handle h, const cesx_step_params* prm, const double* m
     Engine& e = *reinterpret_cast<Engine*>(h);
     TRY(check_prm(e, prm));
     if (!mom || !U || !G || !Unext || !absmax) { e.err = "cesx_apply_drift: null pointer"; return CESX_EINVAL; }
-    TRY(set_device(e));
+    SET_DEVICE(e);
     hipStream_t s = (hipStream_t)stream;
     TRY(launch_dense(e, *prm, mom, 1, s));
     UpdateSrc src[2] = {{U, e.p, 0, 0}, {G, e.n, 0, 0}};
@@ -410,7 +442,7 @@ int cesx_apply_finish(cesx_handle h, const cesx_step_params* prm, const double* 
     Engine& e = *reinterpret_cast<Engine*>(h);
     TRY(check_prm(e, prm));
     if (!absmax || !U || !Unext) { e.err = "cesx_apply_finish: null pointer"; return CESX_EINVAL; }
-    TRY(set_device(e));
+    SET_DEVICE(e);
     hipStream_t s = (hipStream_t)stream;
     if (absmax != e.d_absmax) CESX_HIP(hipMemcpyAsync(e.d_absmax, absmax, 8, hipMemcpyDeviceToDevice, s));
     TRY(launch_dense(e, *prm, nullptr, 2, s));
@@ -434,7 +466,7 @@ int cesx_apply(cesx_handle h, const cesx_step_params* prm, const double* mom, co
         TRY(cesx_apply_drift(h, prm, mom, U, G, Unext, e.d_absmax, stream));
         return cesx_apply_finish(h, prm, e.d_absmax, U, xi, Unext, stream);
     }
-    TRY(set_device(e));
+    SET_DEVICE(e);
     hipStream_t s = (hipStream_t)stream;
     TRY(launch_dense(e, *prm, mom, 0, s));
     TRY(run_update_main(e, *prm, U, G, xi, Unext, s));
@@ -468,19 +500,23 @@ int cesx_result(cesx_handle h, cesx_step_result* out) {
     Engine& e = *reinterpret_cast<Engine*>(h);
     if (!out) { e.err = "cesx_result: null pointer"; return CESX_EINVAL; }
     if (!e.pending) { e.err = "cesx_result: no step has been enqueued"; return CESX_ESTATE; }
-    // spin on the sequence number the GPU writes last into pinned memory
+    // Wait for the sequence number the GPU writes last into pinned memory.  A step is a few
+    // hundred microseconds, so the first 100 us are a pause-spin (lowest latency); after that the
+    // thread yields its core, and from 2 ms on it sleeps in 100 us slices -- a long wait (large
+    // shards, a stalled collective) does not burn a host core.
     {
         volatile unsigned long long* seq = &e.h_scal->seq;
         const auto t0 = std::chrono::steady_clock::now();
         unsigned spins = 0;
         while (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != e.seq) {
-            if ((++spins & 0xfff) == 0) {
-                if (hipPeekAtLastError() != hipSuccess) { e.err = "HIP error while waiting for the step"; return CESX_EHIP; }
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
-                    e.err = "timed out waiting for the step result";
-                    return CESX_EHIP;
-                }
-            }
+            __builtin_ia32_pause();
+            if ((++spins & 0x3ff) != 0) continue;
+            const auto waited = std::chrono::steady_clock::now() - t0;
+            if (waited < std::chrono::microseconds(100)) continue;
+            if (waited < std::chrono::milliseconds(2)) { sched_yield(); continue; }
+            if (hipPeekAtLastError() != hipSuccess) { e.err = "HIP error while waiting for the step"; return CESX_EHIP; }
+            if (waited > std::chrono::seconds(120)) { e.err = "timed out waiting for the step result"; return CESX_EHIP; }
+            std::this_thread::sleep_for(std::chrono::microseconds(100));
         }
     }
     const Scalars& sc = *e.h_scal;
@@ -500,7 +536,7 @@ int cesx_draw_noise(cesx_handle h, uint64_t step_index, void* xi, void* stream) 
     if (!h) return CESX_EINVAL;
     Engine& e = *reinterpret_cast<Engine*>(h);
     if (!xi) { e.err = "cesx_draw_noise: null pointer"; return CESX_EINVAL; }
-    TRY(set_device(e));
+    SET_DEVICE(e);
     return launch_noise(e, step_index, xi, (hipStream_t)stream);
 }
 
@@ -508,7 +544,7 @@ int cesx_forward_lineal(cesx_handle h, const void* A, const void* b, const void*
     if (!h) return CESX_EINVAL;
     Engine& e = *reinterpret_cast<Engine*>(h);
     if (!A || !U || !G) { e.err = "cesx_forward_lineal: null pointer"; return CESX_EINVAL; }
-    TRY(set_device(e));
+    SET_DEVICE(e);
     hipStream_t s = (hipStream_t)stream;
     // stage A (n x p) into the zero-padded (rpad x kp) layout the update kernel reads
     CESX_HIP(hipMemsetAsync(e.d_Wfwd, 0, (size_t)e.rpad * e.kp * e.esz, s));
@@ -525,7 +561,7 @@ int cesx_profile_enable(cesx_handle h, int on) {
     Engine& e = *reinterpret_cast<Engine*>(h);
     e.profile = on != 0;
     if (e.profile) {
-        TRY(set_device(e));
+        SET_DEVICE(e);
         while (e.prof_pool.size() < 512) {        // created up front: no event creation in a timed region
             hipEvent_t ev = nullptr;
             CESX_HIP(hipEventCreate(&ev));
@@ -539,7 +575,7 @@ int cesx_profile_read(cesx_handle h, int which, double* total_ms, int* launches)
     if (!h) return CESX_EINVAL;
     Engine& e = *reinterpret_cast<Engine*>(h);
     if (which < 0 || which > 1 || !total_ms || !launches) { e.err = "cesx_profile_read: bad argument"; return CESX_EINVAL; }
-    TRY(set_device(e));
+    SET_DEVICE(e);
     double tot = 0.0;
     int cnt = 0;
     for (auto& pr : e.prof_ev[which]) {
@@ -560,7 +596,7 @@ int cesx_profile_read(cesx_handle h, int which, double* total_ms, int* launches)
 int cesx_debug_dense(cesx_handle h, double* ubar, double* gbar, double* C, double* L, double* K, double* M) {
     if (!h) return CESX_EINVAL;
     Engine& e = *reinterpret_cast<Engine*>(h);
-    TRY(set_device(e));
+    SET_DEVICE(e);
     CESX_HIP(hipDeviceSynchronize());
     const size_t p = e.p, n = e.n;
     if (ubar) CESX_HIP(hipMemcpy(ubar, e.d_ubar, p * 8, hipMemcpyDeviceToHost));

@@ -59,6 +59,7 @@ class ShardedUpdate:
                             (self.world > 1 or os.environ.get("CESX_FORCE_COMM_OVERLAP") == "1"))
         self.overlap_comm = bool(overlap_comm)
         self._cs = None
+        self._moms, self._mom_idx = None, 0
         # one-rank rehearsal of the multi-GPU path: issue the collectives even though world == 1
         self._force_collectives = dist.is_initialized() and os.environ.get("CESX_FORCE_COLLECTIVES") == "1"
 
@@ -73,18 +74,36 @@ class ShardedUpdate:
         self.engine.set_shift(sums)
         self._recentered = True
 
+    def _moment_buffer(self):
+        """Two persistent moment buffers, used alternately.  The buffer of a step is written on the
+        main stream and read / reduced on the side stream; owning the buffers for the lifetime of the
+        driver (instead of allocating one per step) means the caching allocator never hands a buffer
+        that a stream may still be reading to a new allocation."""
+        eng = self.engine
+        if self._moms is None:
+            if hasattr(eng, "device") and isinstance(eng.device, torch.device):
+                self._moms = [torch.zeros(eng.moments_len(), dtype=torch.float64, device=eng.device) for _ in range(2)]
+            else:
+                self._moms = [torch.zeros(eng.moments_len(), dtype=torch.float64) for _ in range(2)]
+        self._mom_idx ^= 1
+        return self._moms[self._mom_idx]
+
     def begin(self, prm, U, G, recenter=False):
         """First half of a step: everything that does not need the pseudo-time of the previous
         step -- the moments, their all-reduce and chol(C).  Only ``prm.update`` is read, so a
         driver may enqueue ``begin`` of step i+1 BEFORE it reads the result of step i: the
         host's read (ces/calibrate.py:387 tests ``t`` every iteration) then overlaps the Gram
-        of the next step instead of idling the GPU."""
+        of the next step instead of idling the GPU.
+
+        Whether the head all-reduce runs on the side stream is decided ONCE, at construction
+        (``overlap_comm``): a collective that may already have been enqueued is never retried,
+        and an error raised here (HIP, RCCL) propagates, so that all ranks fail together instead
+        of one rank issuing an extra collective."""
         eng = self.engine
         if recenter or not self._recentered:
             self.recenter(U, G)
         nuu = eng.moments_uu_len()
-        mom = eng.moments_uu(U, G)
-        done = False
+        mom = eng.moments_uu(U, G, out=self._moment_buffer())
         if self.overlap_comm:
             cur = torch.cuda.current_stream(eng.device)
             if self._cs is None:        # the engine's own side stream: no third stream to share a hardware queue
@@ -93,19 +112,10 @@ class ShardedUpdate:
             # the rest of the Gram goes to the main stream FIRST: it does not depend on the collective,
             # and a Gram launch dispatched behind the one-workgroup Cholesky waits for it
             eng.moments_rest(U, G, mom)
-            try:
-                with torch.cuda.stream(self._cs):
-                    self._all_reduce(mom[:nuu])      # N, sum(u - s), S_aa: all chol(C) needs ...
-                    eng.chol_async(prm, mom)         # ... C, L = chol(C): behind the collective on the side stream
-                self._keep_mom = getattr(self, "_mom", None)   # the side stream may still read the previous buffer
-                done = True
-            except RuntimeError:                     # a backend that cannot run on a second stream:
-                self.overlap_comm = False            # in-order form from now on (this step: Cholesky after the Gram)
-                cur.wait_stream(self._cs)
-                self._all_reduce(mom[:nuu])
-                eng.chol_async(prm, mom)
-                done = True
-        if not done:
+            with torch.cuda.stream(self._cs):
+                self._all_reduce(mom[:nuu])          # N, sum(u - s), S_aa: all chol(C) needs ...
+                eng.chol_async(prm, mom)             # ... C, L = chol(C): behind the collective on the side stream
+        else:
             self._all_reduce(mom[:nuu])
             eng.chol_async(prm, mom)                 # C, then L = chol(C) on the side stream ...
             eng.moments_rest(U, G, mom)              # ... beside the rest of the Gram
@@ -160,6 +170,7 @@ class ShardedSampler:
         self.T = 30
         self.metrics = {k: [] for k in _METRIC_KEYS}
         self.radspec = []
+        self._steps_done = 0           # Philox step counter: a resumed run() draws fresh noise
 
     def _forward(self, model, U):
         if hasattr(model, "forward_device"):
@@ -188,7 +199,8 @@ class ShardedSampler:
             prm = step_params(update=update, time_step=kwargs.get("time_step"), first_step=(i == 0 and not t),
                               t_len=len(t), t_last=t[-1] if t else 0.0, delta_t=kwargs.get("delta_t"),
                               spinup=kwargs.get("spinup", 4.0), switch=kwargs.get("switch", 1.0),
-                              step_index=i, T=self.T)
+                              step_index=self._steps_done, T=self.T)
+            self._steps_done += 1
             xi = None if xis is None else eng.to_device(xis[i])
             if pipelined:
                 U = self.sh.finish(prm, U, G, xi=xi)

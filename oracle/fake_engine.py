@@ -14,8 +14,10 @@ import torch
 
 
 class FakeEngine:
-    def __init__(self, p, n_obs, J, J_global=None, j_offset=0):
+    def __init__(self, p, n_obs, J, J_global=None, j_offset=0, seed=1234):
         self.p, self.n_obs, self.J = p, n_obs, J
+        self.seed = seed
+        self.drawn_steps = []           # Philox step indices the driver asked noise for
         self.J_global = J if J_global is None else J_global
         self.j_offset = j_offset
         self.shift = None
@@ -39,6 +41,15 @@ class FakeEngine:
         self.mu = np.asarray(mu, dtype=np.float64).reshape(-1, 1)
         self.sigma = np.asarray(sigma, dtype=np.float64)
         self.ustar = np.asarray(ustar, dtype=np.float64).reshape(-1, 1)
+
+    def _xi(self, prm, xi):
+        """Injected noise, or the block the device would draw (Philox keyed by the GLOBAL particle index)."""
+        if xi is not None:
+            return xi.numpy()
+        from . import philox
+        self.drawn_steps.append(int(prm.step_index))
+        return philox.noise_block(self.p, self.J, self.seed, int(prm.step_index), j_offset=self.j_offset,
+                                  dtype=np.float64)
 
     # -- split entry points --------------------------------------------------
     def colsum(self, U, G):
@@ -152,7 +163,7 @@ class FakeEngine:
             P = np.linalg.inv(np.eye(p) + hk * d.M)
             W = np.hstack([P, -hk * (P @ K), np.sqrt(2 * hk) * d.L])
             b = P @ (hk * (K @ self.y + d.M @ self.mu))
-        res = W @ np.vstack([U.numpy(), G.numpy(), xi.numpy()]) + b
+        res = W @ np.vstack([U.numpy(), G.numpy(), self._xi(prm, xi)]) + b
         self._data_metrics(G, d)
         self._finish(prm, d, hk, radspec)
         return torch.as_tensor(res)
@@ -172,7 +183,7 @@ class FakeEngine:
     def apply_finish(self, prm, absmax, U, xi, out):
         d = self._pending
         hk = 0.1 / float(absmax[0])
-        res = U.numpy() + hk * out.numpy() + np.sqrt(2 * hk) * (d.L @ xi.numpy())
+        res = U.numpy() + hk * out.numpy() + np.sqrt(2 * hk) * (d.L @ self._xi(prm, xi))
         self._finish(prm, d, hk, 0.0)
         out.copy_(torch.as_tensor(res))
         return out

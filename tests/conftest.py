@@ -15,6 +15,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """Without a HIP device the ``gpu``-marked tests are skipped, not failed (the product path itself
+    stays loud: ces_amd.engine raises when the device or libcesx.so is missing).  CESX_REQUIRE_GPU=1
+    turns the skip back into a failure for a box that is supposed to have the card."""
+    if os.environ.get("CESX_REQUIRE_GPU") == "1":
+        return
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no HIP device in this container (run on the MI355X box: pytest -m gpu)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def manifest():
     with open(os.path.join(GOLDEN, "manifest.json")) as fh:

@@ -35,13 +35,13 @@ def _problem(p, n, J, T, seed=3):
     return dict(A=A, ustar=ustar, Gamma=Gamma, sigma=sigma, mu=mu, y=y, U0=U0, xis=xis)
 
 
-def _worker(rank, world, port, update, kwargs, q, device_hook=False):
+def _worker(rank, world, port, update, kwargs, q, device_hook=False, dims=(5, 4, 37, 6)):
     sys.path.insert(0, ROOT)
     from ces_amd.dist import ShardedSampler, shard_range
     from ces_amd.utils import lineal
     from oracle.fake_engine import FakeEngine
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    p, n, J, T = 5, 4, 37, 6
+    p, n, J, T = dims
     d = _problem(p, n, J, T)
     lo, hi = shard_range(J, world, rank)
     eng = FakeEngine(p, n, hi - lo, J_global=J, j_offset=lo)
@@ -95,6 +95,61 @@ def test_two_ranks_match_single_process_oracle(update, kwargs, hook):
         assert np.allclose(metrics[k], st.metrics[k], rtol=1e-9), k
     if kwargs.get("time_step") == "spectral":
         assert np.allclose(radspec, st.radspec, rtol=1e-8)
+
+
+def _check_against_oracle(full, metrics, radspec, dims, update, kwargs):
+    from oracle import ces_numpy as oc
+    p, n, J, T = dims
+    d = _problem(p, n, J, T)
+    st = oc.OracleState(p, n, J, d["mu"], d["sigma"], d["ustar"], T=T)
+    Uall, _ = oc.run_chain(st, d["y"], d["U0"], lambda U: oc.lineal_forward(d["A"], U), d["Gamma"], d["xis"],
+                           update=update, step=oc.factored_step, t_tol=1e9, **kwargs)
+    assert np.allclose(full, Uall[-1], rtol=1e-9, atol=1e-12)
+    for k in ("self-bias", "self-bias-data", "bias-data", "bias", "t"):
+        assert len(metrics[k]) == T
+        assert np.allclose(metrics[k], st.metrics[k], rtol=1e-9), k
+
+
+@pytest.mark.parametrize("update,kwargs,hook", [("aldi_constant", {"switch": 0.5}, True), ("aldi", {}, False)])
+def test_eight_ranks_ragged_shards(update, kwargs, hook):
+    """World 8 (the node the driver scales to) with J = 43 not divisible by 8: shards of 6 and 5
+    particles, the aldi_constant max-reduction and the lagged data metrics over 8 ranks."""
+    world, port, dims = 8, _free_port(), (5, 4, 43, 4)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, update, kwargs, q, hook, dims)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    full, metrics, radspec = q.get(timeout=240)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    _check_against_oracle(full, metrics, radspec, dims, update, kwargs)
+
+
+def test_resumed_run_draws_fresh_noise():
+    """A second ShardedSampler.run on the same sampler continues the Philox step counter (the
+    single-device class keeps ``_step_counter``): it must not replay the first run's xi blocks."""
+    sys.path.insert(0, ROOT)
+    from ces_amd.dist import ShardedSampler
+    from ces_amd.utils import lineal
+    from oracle.fake_engine import FakeEngine
+    p, n, J, T = 5, 4, 37, 3
+    d = _problem(p, n, J, T)
+    eng = FakeEngine(p, n, J)
+    smp = ShardedSampler(eng, p, n, J)
+    smp.T = T
+    class model:                         # host loop per particle (the stand-in has no device hook)
+        type, n_obs, model_name = "map", n, "lineal"
+
+        def __call__(self, theta):
+            return lineal(d["A"])(theta)
+    model = model()
+    U1 = smp.run(d["y"], d["U0"], model, d["Gamma"], d["mu"], d["sigma"], d["ustar"], t_tol=1e9)
+    U2 = smp.run(d["y"], U1, model, d["Gamma"], d["mu"], d["sigma"], d["ustar"], t_tol=1e9)
+    assert eng.drawn_steps == list(range(2 * T))
+    assert len(smp.metrics["t"]) == 2 * T and smp.metrics["t"][T] > smp.metrics["t"][T - 1]
+    assert not np.allclose(U1.numpy(), U2.numpy())
 
 
 def test_shard_range_covers_everything():
