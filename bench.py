@@ -15,10 +15,17 @@ Frobenius time step), i.e. weak scaling; N = 8 is config C3.  Inputs are in HBM
 before the timed region; a ring of 4 distinct batches (537 MB > the 256 MB
 Infinity Cache) is cycled so that no step re-reads a cache-resident batch.
 Prints ONE JSON line on rank 0.
+
+``python bench.py --gpus N`` without a launcher starts the N ranks itself (a child
+``python -m torch.distributed.run`` started BEFORE this process touches the GPU) and relays
+rank 0's line.  ``--config C5`` runs BASELINE.json configs[4]'s per-GPU shape (fp64, p = n_obs =
+512, J = 32 768) instead of the headline C2.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -43,9 +50,25 @@ def synthetic_problem(p, n, seed=20240):
     return dict(A=A, ustar=ustar, Gamma=Gamma, y=y, mu=np.zeros((p, 1)), sigma=100.0 * np.eye(p))
 
 
-def cpu_baseline(prob, p, n, J, dtype, budget_s=12.0, max_steps=12):
-    """The numpy CPU path (oracle, factored form = the only form that fits in
-    host memory at J = 65 536) on this box's host cores."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(prob, p, n, J, dtype, budget_s=10.0, max_steps=12):
+    """The numpy CPU path on this box's host cores:
+    * ``value``        oracle.factored_step in the engine's dtype at the full J (the J x J-free form is
+                       the only one that fits in host memory at J = 65 536, SURVEY.md section 6);
+    * ``factored_f64`` the same in fp64 (the reference's own dtype);
+    * ``literal``      oracle.literal_step = ces/calibrate.py:451-490 line by line (forms the J x J
+                       matrix D), fp64, at J = 16 384 (2 x 8 J^2 = 4.3 GB); its cost grows as J^2, so the
+                       rate at the benchmark's J is an EXTRAPOLATION (measured rate x 16384 / J), labelled."""
     from oracle import ces_numpy as oc
     try:
         from threadpoolctl import threadpool_info
@@ -53,20 +76,131 @@ def cpu_baseline(prob, p, n, J, dtype, budget_s=12.0, max_steps=12):
     except Exception:
         cores = os.cpu_count() or 1
     rng = np.random.default_rng(1)
-    U = (prob["ustar"] + rng.standard_normal((p, J))).astype(dtype)
-    G = (prob["A"].astype(dtype) @ U)
-    st = oc.OracleState(p, n, J, prob["mu"], prob["sigma"], prob["ustar"])
-    steps, t0 = 0, time.perf_counter()
-    while steps < max_steps and (steps == 0 or time.perf_counter() - t0 < budget_s):
-        xi = np.random.normal(0, 1, [p, J])              # ces/calibrate.py:488 draws inside the update
-        st.trace_len = 1 if steps == 0 else 2
-        oc.factored_step(st, prob["y"], U, G, prob["Gamma"], xi, update="aldi", dtype=dtype)
-        steps += 1
-    el = time.perf_counter() - t0
-    return dict(value=J * steps / el, unit="particle-updates/s", cores=int(cores), kind="port",
-                sample="%d steps of oracle.factored_step (J x J-free numpy restatement of "
-                       "ces/calibrate.py:451-490, %s, incl. np.random.normal) at J=%d, p=%d, n_obs=%d; "
-                       "%.1f s" % (steps, np.dtype(dtype).name, J, p, n, el))
+
+    def leg(step, Jl, dt, budget, most):
+        U = (prob["ustar"] + rng.standard_normal((p, Jl))).astype(dt)
+        G = (prob["A"].astype(dt) @ U)
+        st = oc.OracleState(p, n, Jl, prob["mu"], prob["sigma"], prob["ustar"])
+        steps, t0 = 0, time.perf_counter()
+        while steps < most and (steps == 0 or time.perf_counter() - t0 < budget):
+            xi = np.random.normal(0, 1, [p, Jl])             # ces/calibrate.py:488 draws inside the update
+            st.trace_len = 1 if steps == 0 else 2
+            if step is oc.factored_step:
+                step(st, prob["y"], U, G, prob["Gamma"], xi, update="aldi", dtype=dt)
+            else:
+                step(st, prob["y"], U, G, prob["Gamma"], xi, update="aldi")
+            steps += 1
+        el = time.perf_counter() - t0
+        return Jl * steps / el, steps, el
+
+    v, steps, el = leg(oc.factored_step, J, dtype, budget_s, max_steps)
+    out = dict(value=v, unit="particle-updates/s", cores=int(cores), kind="port", cpu_model=_cpu_model(),
+               sample="%d steps of oracle.factored_step (J x J-free numpy restatement of "
+                      "ces/calibrate.py:451-490, %s, incl. np.random.normal) at J=%d, p=%d, n_obs=%d; "
+                      "%.1f s" % (steps, np.dtype(dtype).name, J, p, n, el))
+    if np.dtype(dtype) != np.dtype(np.float64):
+        v64, s64, e64 = leg(oc.factored_step, J, np.float64, 0.6 * budget_s, max_steps)
+        out["factored_f64"] = dict(value=v64, unit="particle-updates/s",
+                                   sample="%d steps, float64, J=%d; %.1f s" % (s64, J, e64))
+    Jl = min(J, 16384)
+    vl, sl, elit = leg(oc.literal_step, Jl, np.float64, 0.5 * budget_s, 3)
+    out["literal"] = dict(value=vl, unit="particle-updates/s", J=Jl,
+                          sample="%d steps of oracle.literal_step (ces/calibrate.py:451-490 as written, forms "
+                                 "the J x J matrix D), float64, J=%d; %.1f s" % (sl, Jl, elit),
+                          extrapolated_to_J=J, extrapolated_value=vl * Jl / J,
+                          extrapolation="O(J^2) per step: rate scaled by %d / %d; the literal form cannot run at "
+                                        "J = %d (%.1f GB per J x J matrix)" % (Jl, J, J, 8.0 * J * J / 1e9))
+    return out
+
+
+def parity_check(engine, prob, p, n, dtype, update):
+    """Max relative error of one step of the benchmarked configuration (same problem, same rule, injected
+    xi) against the pinned CPU oracle in fp64, on a J = 4 096 ensemble (SURVEY.md 8d "also report")."""
+    from oracle import ces_numpy as oc
+    Jc = 4096
+    rng = np.random.default_rng(7)
+    U = prob["ustar"] + rng.standard_normal((p, Jc))
+    G = prob["A"] @ U
+    xi = rng.standard_normal((p, Jc))
+    cast = (lambda a: a.astype(np.float32).astype(np.float64)) if np.dtype(dtype) == np.dtype(np.float32) else (lambda a: a)
+    U, G, xi = cast(U), cast(G), cast(xi)
+    st = oc.OracleState(p, n, Jc, prob["mu"], prob["sigma"], prob["ustar"])
+    ref = oc.factored_step(st, prob["y"], U, G, prob["Gamma"], xi, update=update)
+    eng = engine.Engine(p, n, Jc, dtype=dtype)
+    eng.set_problem(prob["y"], prob["Gamma"], prob["mu"], prob["sigma"], prob["ustar"])
+    out = eng.step(engine.step_params(update=update), U, G, xi=xi).cpu().numpy().astype(np.float64)
+    res = eng.result()
+    return dict(J=Jc, U_next_max_rel=float(np.max(np.abs(out - ref)) / np.max(np.abs(ref))),
+                hk_rel=float(abs(res.hk - st.metrics["t"][-1]) / st.metrics["t"][-1]),
+                bias_data_rel=float(abs(res.bias_data - st.metrics["bias-data"][-1]) / st.metrics["bias-data"][-1]),
+                against="oracle.factored_step float64 (pinned to the reference through tests/golden)",
+                bar=1e-3 if np.dtype(dtype) == np.dtype(np.float32) else 1e-6)
+
+
+def e2e_block(engine, prob, p, n, J, dtype, update, dev_index):
+    """End-to-end rates of the two ways a user drives the engine (SURVEY.md 8d "also report"; never `value`):
+    ``device_chain``  the ensemble stays in HBM for the whole run: forward map G = A U on the device every
+                      step (lineal.forward_device), update, U_next fed back (ShardedSampler.run);
+    ``host_arrays``   the reference's calling convention: float64 numpy U and G in, float64 numpy U_next out
+                      (sampling.eks_update_aldi), G = A U by host BLAS -- PCIe both ways every step."""
+    from ces_amd.calibrate import sampling
+    from ces_amd.dist import ShardedSampler
+    from ces_amd.utils import lineal
+    out = {}
+    rng = np.random.default_rng(3)
+    U0 = prob["ustar"] + rng.standard_normal((p, J))
+    model = lineal(prob["A"])
+    eng = engine.Engine(p, n, J, dtype=dtype, device=dev_index, seed=77)
+    for T, timed in ((8, False), (40, True)):
+        smp = ShardedSampler(eng, p, n, J)
+        smp.T = T
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        smp.run(prob["y"], U0, model, prob["Gamma"], prob["mu"], prob["sigma"], prob["ustar"], update=update,
+                t_tol=1e30)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if timed:
+            out["device_chain"] = dict(value=J * T / el, unit="particle-updates/s", ms_per_step=1e3 * el / T, steps=T,
+                                       includes="upload of U0 once, then per step: G = A U on device, update with "
+                                                "on-device noise, host read of t; U_next fed back")
+    del eng
+    eks = sampling(p=p, n_obs=n, J=J)
+    eks.mu, eks.sigma, eks.ustar = prob["mu"], prob["sigma"], prob["ustar"]
+    eks.engine_dtype, eks.noise, eks.device = np.dtype(dtype).name, "device", dev_index
+    eks.Uall = [U0]
+    U = U0
+    fwd = upd = 0.0
+    nst = 4
+    for i in range(nst + 1):
+        t0 = time.perf_counter()
+        G = prob["A"] @ U
+        t1 = time.perf_counter()
+        U = eks.eks_update_aldi(prob["y"], U, G, prob["Gamma"], i)
+        t2 = time.perf_counter()
+        eks.Uall.append(U)
+        if i > 0:                                            # first call builds the engine and the pinned buffers
+            fwd += t1 - t0
+            upd += t2 - t1
+    out["host_arrays"] = dict(value=J * nst / (fwd + upd), unit="particle-updates/s", steps=nst,
+                              ms_per_step=1e3 * (fwd + upd) / nst, host_forward_ms=1e3 * fwd / nst,
+                              update_call_ms=1e3 * upd / nst,
+                              includes="numpy A @ U on the host, float64 numpy arrays across PCIe in and out")
+    return out
+
+
+def self_launch(args):
+    """No launcher (WORLD_SIZE unset) and --gpus N > 1: start the N ranks as children of this process, which
+    has not touched the GPU, relay their output, exit with their status."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -79,21 +213,27 @@ def main():
     ap.add_argument("--n", type=int, default=256)
     ap.add_argument("--dtype", default="float32")
     ap.add_argument("--update", default="aldi")
+    ap.add_argument("--config", default="C2", choices=["C2", "C5"],
+                    help="C2: fp32, p=n=256, J=65536/GPU (headline); C5: fp64, p=n=512, J=32768/GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip parity_err and the e2e block")
     args = ap.parse_args()
+    if args.config == "C5":
+        args.J, args.p, args.n, args.dtype = 32768, 512, 512, "float64"
 
+    # the HSA / RCCL environment is fixed before anything can initialise the runtime
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-        args.gpus = world
+    args.gpus = world
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     rehearse = world == 1 and os.environ.get("CESX_FORCE_COLLECTIVES") == "1"   # one-rank run of the N > 1 code path
+    rccl_nranks = 0                               # ranks RCCL saw in an actual all-reduce (0: no communicator)
     if world > 1 or rehearse:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if rehearse:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
@@ -101,6 +241,9 @@ def main():
             os.environ["CESX_FORCE_COMM_OVERLAP"] = "1"
         else:
             dist.init_process_group("nccl", device_id=dev)
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)
+        rccl_nranks = int(one.item())
 
     from ces_amd import build, engine
     from ces_amd.dist import ShardedUpdate
@@ -158,6 +301,8 @@ def main():
                                  step_index=i)
         sh.finish(prm, U, G, xi=None, out=out)
 
+    stamps = []
+
     def run_steps(first, count):
         begin(first)
         res = None
@@ -166,12 +311,14 @@ def main():
             if i + 1 < first + count:
                 begin(i + 1)
             res = eng.result()
+            stamps.append(time.perf_counter())     # host time at which the result of step i was in hand
             t_hist[0] = res.t_new
         return res
 
     # untimed pre-warm before the W warmup steps: the first ~30 steps after start-up run 3-5 % slower
     # (clock / power state, code objects, allocator); 64 steps = 32 ms reach the steady state
-    run_steps(0, int(os.environ.get("CESX_BENCH_PREWARM", "64")))
+    prewarm = int(os.environ.get("CESX_BENCH_PREWARM", "64"))
+    run_steps(0, prewarm)
     t_hist[0] = 0.0
     if args.warmup:
         run_steps(0, args.warmup)
@@ -182,12 +329,14 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    del stamps[:]
     t0 = time.perf_counter()
     res = run_steps(args.warmup, args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    per_step = np.diff(np.array([t0] + stamps)) * 1e3       # ms between consecutive results (pipelined loop)
     prof["on"] = False
     eng.profile_enable(False)
     if world > 1:
@@ -217,36 +366,69 @@ def main():
         k["tflops"] = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
     dom = max(kern, key=lambda k: kern[k]["ms"])
     peak = MFMA_PEAK_TF[np.dtype(args.dtype).name]
-    traffic = None
+    dname = np.dtype(args.dtype).name
+    is_c2 = (p, n, J, dname, args.update) == (256, 256, 65536, "float32", "aldi")
+    is_c5 = (p, n, J, dname, args.update) == (512, 512, 32768, "float64", "aldi")
+    cfg_name = "C2" if is_c2 else "C5" if is_c5 else "custom"
+    # HBM bytes per step of each kernel from the rocprofv3 PMC passes (profiles/traffic.json, taken on the
+    # named config with tools/prof_summary.py; collected in separate --pmc runs as the guide prescribes)
+    traffic_tab = {}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    is_c2 = (p, n, J, np.dtype(args.dtype).name, args.update) == (256, 256, 65536, "float32", "aldi")
-    if os.path.exists(tpath) and is_c2:          # the PMC passes were taken on C2
+    if os.path.exists(tpath) and cfg_name != "custom":
         try:
-            traffic = json.load(open(tpath)).get(dom.split("(")[0])
+            tj = json.load(open(tpath))
+            traffic_tab = tj.get(cfg_name, tj if cfg_name == "C2" and "gram_kernel" in tj else {})
         except Exception:
-            traffic = None
+            traffic_tab = {}
+    tkey = {"gram_kernel(K1)": "gram_kernel", "update_kernel(K3)": "update2_kernel" if dname == "float32" else "update_kernel"}
+    traffic = traffic_tab.get(tkey[dom])
+    step_s = elapsed / args.steps
+    esz = np.dtype(args.dtype).itemsize
+    alg_bytes = float(esz * (3 * p + 2 * n)) * J               # s (3p + 2n) per particle-update
     roofline = dict(bound="mfma", kernel=dom, achieved=round(kern[dom]["tflops"], 2), peak=peak,
                     unit="TFLOP/s", frac=round(kern[dom]["tflops"] / peak, 4), traffic=traffic,
                     avg_launch_ms=round(kern[dom]["ms"], 4), profiled_steps=prof["steps"],
                     kernels={k: dict(avg_launch_ms=round(v["ms"], 4), launches_per_step=v["launches"],
-                                     tflops=round(v["tflops"], 2), frac=round(v["tflops"] / peak, 4))
+                                     tflops=round(v["tflops"], 2), frac=round(v["tflops"] / peak, 4),
+                                     traffic=traffic_tab.get(tkey[k]),
+                                     hbm_gbs=(round(traffic_tab[tkey[k]] / (v["ms"] * 1e-3) / 1e9, 1)
+                                              if traffic_tab.get(tkey[k]) and v["ms"] > 0 else None))
                              for k, v in kern.items()},
-                    step_flops_frac=round(sum(v["flops"] for v in kern.values()) /
-                                          (elapsed / args.steps) / 1e12 / peak, 4))
+                    step_flops_frac=round(sum(v["flops"] for v in kern.values()) / step_s / 1e12 / peak, 4),
+                    # the other roofline the north star asks for: HBM bytes (PMC counters) / kernel time / 8 TB/s
+                    hbm_gbs=(round(traffic / (kern[dom]["ms"] * 1e-3) / 1e9, 1) if traffic and kern[dom]["ms"] > 0 else None),
+                    hbm_frac=(round(traffic / (kern[dom]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                              if traffic and kern[dom]["ms"] > 0 else None),
+                    hbm_peak_gbs=HBM_PEAK_GBS,
+                    step_algorithmic_bytes=alg_bytes,
+                    step_algorithmic_hbm_frac=round(alg_bytes / step_s / 1e9 / HBM_PEAK_GBS, 4))
+    if world == 1 and not rehearse:
+        par = "dp1: one GPU holds the whole ensemble, no collective is issued"
+    else:
+        par = ("particle-sharded dp%d over RCCL: all-reduce(sum) of the %d-double fp64 moment buffer per step, sent in "
+               "two pieces (%d-double head on the side stream beside the second Gram launch, then the rest)"
+               % (world, eng.moments_len(), eng.moments_uu_len()))
     rec = dict(metric="EKS particle-updates/sec", value=Jg * args.steps / elapsed, unit="particle-updates/s",
-               n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps,
+               n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * step_s,
+               ms_per_step_median=float(np.median(per_step)), ms_per_step_min=float(np.min(per_step)),
+               prewarm_steps=prewarm, rccl_nranks=rccl_nranks,
                higher_is_better=True, scaling="weak", vs_baseline=None,
-               dtype={"float32": "f32", "float64": "f64"}[np.dtype(args.dtype).name], data="synthetic",
+               dtype={"float32": "f32", "float64": "f64"}[dname], data="synthetic",
                config=dict(workload="%s per GPU: synthetic linear-Gaussian forward map, J=%d particles/GPU "
                                     "(J_global=%d), d=p=%d, n_obs=%d, update=%s, default Frobenius time step, "
-                                    "on-device Philox noise"
-                                    % ("C2" if is_c2 else "C5" if (p, n, J, args.dtype) == (512, 512, 32768, "float64")
-                                       else "custom", J, Jg, p, n, args.update),
-                           J_per_gpu=J, J_global=Jg, p=p, n_obs=n, update=args.update,
-                           parallelism="particle-sharded dp%d, all-reduce(sum) of the %d-double fp64 moment buffer "
-                                       "per step in two pieces (%d-double head beside the second Gram launch)"
-                                       % (world, eng.moments_len(), eng.moments_uu_len())),
+                                    "on-device Philox noise" % (cfg_name, J, Jg, p, n, args.update),
+                           J_per_gpu=J, J_global=Jg, p=p, n_obs=n, update=args.update, parallelism=par,
+                           timed_region="the update engine on HBM-resident inputs: K1 moments, (all-reduce), K2, K3 "
+                                        "with on-device noise and the host's read of hk / t / metrics of every step. "
+                                        "A ring of 4 resident (U, G = A U) batches is cycled; the forward map and the "
+                                        "feedback of U_next are NOT in the timed step (see e2e.device_chain for the "
+                                        "chained loop); %d untimed pre-warm steps precede the warm-up" % prewarm),
                roofline=roofline)
+    if world == 1 and not rehearse and not args.no_extras:
+        del batches, out, sh, eng
+        torch.cuda.empty_cache()
+        rec["parity_err"] = parity_check(engine, prob, p, n, args.dtype, args.update)
+        rec["e2e"] = e2e_block(engine, prob, p, n, J, args.dtype, args.update, local)
     if world == 1 and not args.no_cpu_baseline:
         rec["cpu_baseline"] = cpu_baseline(prob, p, n, J, np.dtype(args.dtype).type)
     print(json.dumps(rec), flush=True)

@@ -208,7 +208,7 @@ struct Engine {
     double *d_Wh = nullptr;        // chol(Gamma)^{-1} (dense Gamma, spectral rule)
     double *d_Lp = nullptr;        // padded Cholesky workspace (round_up(max(p,n),32))^2
     double *d_lanczos = nullptr;
-    int lanczos_steps = 96;
+    int lanczos_steps = 512;       // cap on Krylov steps (min(n, this)); a run that exhausts it unconverged reports CESX_ENOCONV
     double *d_absmax = nullptr;    // [1]
     double *d_c0 = nullptr;        // [1]
     void   *d_qe = nullptr;        // [J] per-particle q^e (engine dtype)

@@ -1,6 +1,7 @@
 // C ABI of libcesx.so (include/cesx.h): handle lifetime, problem set-up and
 // the host-side sequencing of K1 (moments) -> K2 (dense) -> K3 (update).
 #include "cesx_internal.h"
+#include <algorithm>
 #include <cmath>
 #include <chrono>
 #include <cstdlib>
@@ -264,7 +265,11 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
     { const size_t np_ = (size_t)(mx + 31) / 32 * 32; DM(e.d_Lp, np_ * np_ * 8); }
     if (potrf_ld(mx) > 256) DM(e.d_Lwork, (size_t)potrf_ld(mx) * potrf_ld(mx) * 8);
     DM(e.d_t1, mm * 8); DM(e.d_t2, mm * 8); DM(e.d_t3, mm * 8); DM(e.d_t4, mm * 8);
-    DM(e.d_lanczos, ((size_t)(e.lanczos_steps + 1) * n + 2 * e.lanczos_steps) * 8);
+    {
+        if (const char* lv = std::getenv("CESX_LANCZOS_STEPS")) e.lanczos_steps = std::max(2, std::min(512, std::atoi(lv)));
+        const size_t ms = (size_t)std::min(n, e.lanczos_steps);
+        DM(e.d_lanczos, ((ms + 1) * n + 4 * ms) * 8);
+    }
     DM(e.d_mv, (size_t)6 * mx * 8); DM(e.d_part, 256 * 4 * 8);
     DM(e.d_scal, sizeof(Scalars)); DM(e.d_absmax, 8); DM(e.d_c0, 8);
     DM(e.d_absmax_part, (size_t)update_grid_blocks(e, p) * 8);
@@ -528,6 +533,11 @@ int cesx_result(cesx_handle h, cesx_step_result* out) {
     if (sc.status == CESX_ENOTPD) {
         e.err = "ensemble covariance is not positive definite (Cholesky failed)";
         return CESX_ENOTPD;
+    }
+    if (sc.status == CESX_ENOCONV) {
+        e.err = "time_step='spectral': the Lanczos iteration for the spectral radius did not converge "
+                "(residual > 1e-10 theta after the step cap); hk of this step is not reliable";
+        return CESX_ENOCONV;
     }
     return CESX_OK;
 }

@@ -387,17 +387,21 @@ __global__ void select_kernel(long long len, const Scalars* __restrict__ sc, con
 // Lanczos with full re-orthogonalisation (m steps, one workgroup) followed by
 // bisection on the tridiagonal matrix.
 // ---------------------------------------------------------------------------
-// largest eigenvalue of tridiag(alpha[0..m), beta[0..m-1)) by bisection (Sturm count); one thread
+// largest eigenvalue of tridiag(alpha[0..m), beta[0..m-1)) by 64-way multisection on Sturm counts:
+// called by the 64 lanes of ONE wave; lane l counts the eigenvalues below the l-th interior point of
+// the bracket, the bracket shrinks 65-fold per round (10 rounds reach the last bit).  Same value on
+// every lane.
 __device__ double tridiag_max_eig(const double* alpha, const double* beta, int m) {
+    const int lane = threadIdx.x & 63;
     double lo = alpha[0], hi = alpha[0];
     for (int i = 0; i < m; ++i) {
         const double bl = i > 0 ? fabs(beta[i - 1]) : 0.0, br = i + 1 < m ? fabs(beta[i]) : 0.0;
         lo = fmin(lo, alpha[i] - bl - br);
         hi = fmax(hi, alpha[i] + bl + br);
     }
-    for (int it = 0; it < 200; ++it) {
-        const double mid = 0.5 * (lo + hi);
-        if (mid == lo || mid == hi) break;
+    for (int it = 0; it < 16; ++it) {
+        const double w = hi - lo;
+        const double mid = lo + w * ((double)(lane + 1) / 65.0);
         int cnt = 0;                                   // number of eigenvalues < mid
         double d = 1.0;
         for (int i = 0; i < m; ++i) {
@@ -406,21 +410,57 @@ __device__ double tridiag_max_eig(const double* alpha, const double* beta, int m
             if (d == 0.0) d = 1e-300;
             if (d < 0.0) ++cnt;
         }
-        if (cnt >= m) hi = mid; else lo = mid;
+        // lanes whose point lies above the whole spectrum (the counts are monotone in the lane index)
+        const unsigned long long above = __ballot(cnt >= m);
+        const int first = above ? __ffsll((long long)above) - 1 : 64;     // first lane with mid > lambda_max
+        const double nlo = first > 0 ? __shfl(mid, first - 1, 64) : lo;
+        const double nhi = first < 64 ? __shfl(mid, first, 64) : hi;
+        if (!(nhi - nlo < w)) break;                   // the bracket no longer shrinks: last bit reached
+        lo = nlo; hi = nhi;
     }
     return 0.5 * (lo + hi);
 }
 
+// |last component| of the unit eigenvector of tridiag(alpha, beta) (order m) for the eigenvalue th:
+// two steps of inverse iteration with the shift nudged off the eigenvalue (LU of the shifted
+// tridiagonal without pivoting is safe above the spectrum: all pivots are negative).  d, x: scratch
+// of m doubles each.  One thread.  With full re-orthogonalisation the residual of the Ritz pair is
+// exactly  || B v - th v || = beta_m * |s_m|  (Paige), beta_m = norm of the next Lanczos vector.
+__device__ double tridiag_last_component(const double* alpha, const double* beta, int m, double th,
+                                         double* d, double* x) {
+    const double shift = th + 4e-16 * fabs(th) + 1e-300;
+    for (int i = 0; i < m; ++i) {
+        d[i] = alpha[i] - shift - (i > 0 ? beta[i - 1] * beta[i - 1] / d[i - 1] : 0.0);
+        if (d[i] == 0.0) d[i] = -1e-300;
+        x[i] = 1.0;
+    }
+    for (int it = 0; it < 3; ++it) {
+        // (T - shift) z = x: forward elimination with the stored pivots, back substitution
+        for (int i = 1; i < m; ++i) x[i] -= beta[i - 1] / d[i - 1] * x[i - 1];
+        x[m - 1] /= d[m - 1];
+        for (int i = m - 2; i >= 0; --i) x[i] = (x[i] - beta[i] * x[i + 1]) / d[i];
+        double nrm = 0.0;
+        for (int i = 0; i < m; ++i) nrm = fmax(nrm, fabs(x[i]));
+        double n2 = 0.0;
+        for (int i = 0; i < m; ++i) { x[i] /= nrm; n2 += x[i] * x[i]; }
+        n2 = sqrt(n2);
+        for (int i = 0; i < m; ++i) x[i] /= n2;
+    }
+    return fabs(x[m - 1]);
+}
+
+constexpr int LANCZOS_MAX = 512;     // Krylov steps (cq[] below, and the workspace engine.hip allocates)
+
 __global__ __launch_bounds__(DT)
 void lanczos_kernel(int n, const double* __restrict__ B, const double* __restrict__ divp, int msteps,
                     double* __restrict__ V, double* __restrict__ alpha, double* __restrict__ beta,
-                    Scalars* __restrict__ sc) {
+                    double* __restrict__ scratch, Scalars* __restrict__ sc) {
     __shared__ double red[DT / 64];
     __shared__ double s_val;
-    __shared__ double s_prev, s_done;
-    __shared__ double cq[128];                 // projections of one re-orthogonalisation pass (msteps <= 127)
+    __shared__ double s_done;
+    __shared__ double cq[LANCZOS_MAX];         // projections of one re-orthogonalisation pass
     const int tid = threadIdx.x;
-    if (tid == 0) { s_prev = -1.0; s_done = 0.0; }
+    if (tid == 0) s_done = 0.0;
     // start vector: normalised ones + small ramp (generic direction)
     double nrm = 0.0;
     for (int i = tid; i < n; i += DT) { const double v = 1.0 + 0.01 * i; V[i] = v; nrm += v * v; }
@@ -428,6 +468,7 @@ void lanczos_kernel(int n, const double* __restrict__ B, const double* __restric
     for (int i = tid; i < n; i += DT) V[i] /= sqrt(nrm);
     __syncthreads();
     int m = 0;
+    bool converged = false;
     for (int k = 0; k < msteps; ++k) {
         double* vk = V + (size_t)k * n;
         double* w = V + (size_t)(k + 1) * n;
@@ -466,25 +507,31 @@ void lanczos_kernel(int n, const double* __restrict__ B, const double* __restric
         b = sqrt(dblock_sum(b, red));
         m = k + 1;
         if (tid == 0) beta[k] = b;
-        if (!(b > 1e-14 * fabs(alpha[0]) + 1e-300)) break;      // invariant subspace found
+        // invariant subspace (or the whole space, m = n): the Ritz values are exact eigenvalues
+        if (!(b > 1e-14 * fabs(alpha[0]) + 1e-300) || m == n) { converged = true; break; }
         for (int i = tid; i < n; i += DT) w[i] /= b;
         __syncthreads();
-        // the largest Ritz value converges long before the Krylov space is exhausted: stop when it
-        // has not moved by more than a few ulps over 8 further steps
-        if ((k & 7) == 7) {
-            if (tid == 0) {
+        // Convergence test every 4 steps (the largest Ritz value converges long before the Krylov
+        // space is exhausted): residual of the Ritz pair  beta_m |s_m|  <=  1e-10 theta
+        if ((k & 3) == 3 || k + 1 == msteps) {
+            if (tid < 64) {
                 const double th = tridiag_max_eig(alpha, beta, m);
-                s_done = fabs(th - s_prev) <= 4e-16 * fabs(th) ? 1.0 : 0.0;
-                s_prev = th;
+                if (tid == 0) {
+                    const double sm = tridiag_last_component(alpha, beta, m, th, scratch, scratch + msteps);
+                    s_done = (b * sm <= 1e-10 * fabs(th)) ? 1.0 : 0.0;
+                }
             }
             __syncthreads();
-            if (s_done != 0.0) break;
+            if (s_done != 0.0) { converged = true; break; }
+            __syncthreads();
         }
     }
     __syncthreads();
+    if (tid < 64) s_val = tridiag_max_eig(alpha, beta, m) / (*divp);     // (every lane writes the same value)
     if (tid == 0) {
-        s_val = tridiag_max_eig(alpha, beta, m) / (*divp);
         sc->radspec = s_val > 0.0 ? s_val : 0.0;
+        sc->spare[3] = (double)m;                               // Krylov steps taken (diagnostic)
+        if (!converged && sc->status == CESX_OK) sc->status = CESX_ENOCONV;
     }
 }
 
@@ -941,10 +988,10 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
             if ((rc = gemm(e, s, n, n, n, 1.0, e.d_Wh, n, 1, e.d_See, n, 1, e.d_t1))) return rc;
             if ((rc = gemm(e, s, n, n, n, 1.0, e.d_t1, n, 1, e.d_Wh, 1, n, e.d_t3))) return rc;
         }
-        const int msteps = n < e.lanczos_steps ? n : e.lanczos_steps;
+        const int msteps = n < e.lanczos_steps ? n : e.lanczos_steps;      // <= LANCZOS_MAX (engine.hip)
+        double* lz = e.d_lanczos + (size_t)(msteps + 1) * n;               // [alpha | beta | 2 x scratch]
         hipLaunchKernelGGL(lanczos_kernel, dim3(1), dim3(DT), 0, s, n, e.d_t3, mom, msteps, e.d_lanczos,
-                           e.d_lanczos + (size_t)(msteps + 1) * n, e.d_lanczos + (size_t)(msteps + 1) * n + msteps,
-                           e.d_scal);
+                           lz, lz + msteps, lz + 2 * msteps, e.d_scal);
         CESX_HIP(hipGetLastError());
     }
     auto scalars_and_matvecs = [&]() {

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcesx.so")
 
-OK, EINVAL, ENOTPD, EHIP, ESTATE, EUNSUPPORTED = 0, 1, 2, 3, 4, 5
+OK, EINVAL, ENOTPD, EHIP, ESTATE, EUNSUPPORTED, ENOCONV = 0, 1, 2, 3, 4, 5, 6
 F32, F64 = 0, 1
 UPDATES = {"eks": 0, "aldi": 1, "aldi_constant": 2}
 TIME_STEPS = {None: 0, "spectral": 1, "constant": 2, "adaptive": 3, "mix": 4}
@@ -168,6 +168,8 @@ class Engine:
         msg = self.lib.cesx_last_error(self._h).decode()
         if rc == ENOTPD:
             raise np.linalg.LinAlgError(msg or "Matrix is not positive definite")
+        if rc == ENOCONV:                 # what np.linalg.eigvals (ces/calibrate.py:250) raises
+            raise np.linalg.LinAlgError("Eigenvalues did not converge: " + msg)
         if rc == EUNSUPPORTED:
             raise AttributeError("'sampling' object has no attribute 'LM_procedure'")
         if rc == EINVAL:

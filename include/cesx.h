@@ -42,6 +42,9 @@ extern "C" {
                                   ces/calibrate.py:446, :487, :526)                      */
 #define CESX_EHIP          3   /* HIP runtime failure                                     */
 #define CESX_ESTATE        4   /* call order violated (e.g. no problem set)              */
+#define CESX_ENOCONV       6   /* time_step='spectral': the eigenvalue iteration did not meet
+                                  its residual criterion (np.linalg.LinAlgError "Eigenvalues
+                                  did not converge", what np.linalg.eigvals of :250 raises)  */
 #define CESX_EUNSUPPORTED  5   /* time_step='adaptive': the reference calls the undefined
                                   self.LM_procedure (ces/calibrate.py:255)               */
 
@@ -110,7 +113,7 @@ typedef struct cesx_step_result {
        collective is needed.  On one device the values above are already complete. */
     double  lag_bias_data;
     double  lag_self_bias_data;
-    int32_t status;          /* CESX_OK or CESX_ENOTPD for this step                 */
+    int32_t status;          /* CESX_OK, CESX_ENOTPD or CESX_ENOCONV for this step   */
     int32_t reserved;
 } cesx_step_result;
 

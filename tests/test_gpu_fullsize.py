@@ -76,6 +76,111 @@ def test_c2_step_matches_fp64_restatement(setup, dtype, tol):
     assert torch.isfinite(out).all()
 
 
+@pytest.mark.parametrize("update,kw,t_prev", [("aldi", {}, []), ("eks", {}, [0.3]), ("aldi_constant", {"switch": 0.5}, [0.3]),
+                                              ("eks", {"time_step": "constant", "delta_t": 0.02}, [0.3]),
+                                              ("aldi", {"time_step": "mix", "delta_t": 0.05, "spinup": 1.0}, [0.9, 1.5])])
+def test_c2_fullsize_rules_match_pinned_oracle(setup, update, kw, t_prev):
+    """J = 65 536 (config C2) against the PINNED CPU oracle (oracle.factored_step, fp64) for every update
+    rule and the time-step rules that change the gain -- test_c2_step_matches_fp64_restatement and
+    test_repeated_step_is_bit_identical are a third restatement and a self-comparison respectively;
+    this is the independent check at full size.  fp32 engine, 1e-3 (north star)."""
+    from oracle import ces_numpy as oc
+    engine, prob, U, G, xi = setup
+    Uh, Gh, xih = (t.to(dtype=__import__("torch").float32).cpu().numpy().astype(np.float64) for t in (U, G, xi))
+    st = oc.OracleState(P, N, J, prob["mu"], prob["sigma"], prob["ustar"], T=30)
+    st.metrics["t"] = list(t_prev)
+    st.trace_len = 1 if not t_prev else 2
+    ref = oc.factored_step(st, prob["y"], Uh, Gh, prob["Gamma"], xih, update=update, **kw)
+    eng = engine.Engine(P, N, J, dtype="float32")
+    eng.set_problem(prob["y"], prob["Gamma"], prob["mu"], prob["sigma"], prob["ustar"])
+    prm = engine.step_params(update=update, time_step=kw.get("time_step"), first_step=not t_prev, t_len=len(t_prev),
+                             t_last=t_prev[-1] if t_prev else 0.0, delta_t=kw.get("delta_t"),
+                             spinup=kw.get("spinup", 4.0), switch=kw.get("switch", 1.0), T=30)
+    out = eng.step(prm, Uh, Gh, xi=xih)
+    res = eng.result()
+    got = out.cpu().numpy().astype(np.float64)
+    assert np.max(np.abs(got - ref)) / np.max(np.abs(ref)) < 1e-3
+    assert res.t_new == pytest.approx(st.metrics["t"][-1], rel=1e-3)
+    have = np.array([res.self_bias, res.self_bias_data, res.bias_data, res.bias])
+    want = np.array([st.metrics[k][-1] for k in ("self-bias", "self-bias-data", "bias-data", "bias")])
+    assert np.allclose(have, want, rtol=1e-3), (have, want)
+
+
+def test_c3_eight_logical_shards_of_524288(setup):
+    """Config C3's arithmetic at its real size on one device: J = 524 288 fp32 particles as 8 logical shards
+    of 65 536 (what each of the 8 GPUs holds), moments summed on the device (stand-in for the RCCL
+    all-reduce), apply per shard == the single-engine step over the whole ensemble."""
+    import torch
+    engine, prob, U, G, xi = setup
+    Jg, nsh = 8 * J, 8
+    g = torch.Generator(device="cuda").manual_seed(11)
+    Ug = torch.as_tensor(prob["ustar"], device="cuda", dtype=torch.float32) + \
+        torch.randn((P, Jg), generator=g, device="cuda", dtype=torch.float32)
+    whole = engine.Engine(P, N, Jg, dtype="float32")
+    whole.set_problem(prob["y"], prob["Gamma"], prob["mu"], prob["sigma"], prob["ustar"])
+    Gg = whole.forward_lineal(prob["A"], Ug)
+    prm = engine.step_params(update="aldi", step_index=3)
+    ref = whole.step(prm, Ug, Gg, xi=None)                  # on-device noise keyed by the global index
+    rw = whole.result()
+    shards = []
+    for k in range(nsh):
+        e = engine.Engine(P, N, J, dtype="float32", J_global=Jg, j_offset=k * J)
+        e.set_problem(prob["y"], prob["Gamma"], prob["mu"], prob["sigma"], prob["ustar"])
+        shards.append((e, Ug[:, k * J:(k + 1) * J].contiguous(), Gg[:, k * J:(k + 1) * J].contiguous()))
+    sums = sum(e.colsum(Us, Gs) for e, Us, Gs in shards)
+    for e, *_ in shards:
+        e.set_shift(sums)
+    mom = sum(e.moments(Us, Gs) for e, Us, Gs in shards)
+    assert float(mom[0]) == Jg
+    outs = [e.apply(prm, mom, Us, Gs, xi=None) for e, Us, Gs in shards]
+    share = [e.result() for e, *_ in shards]
+    got = torch.cat(outs, dim=1)
+    err = ((got - ref).abs().max() / ref.abs().max()).item()
+    assert err < 2e-5, err
+    assert all(s.hk == share[0].hk for s in share)          # every rank takes the same t_tol decision
+    assert share[0].hk == pytest.approx(rw.hk, rel=1e-6)
+    assert sum(s.bias_data for s in share) == pytest.approx(rw.bias_data, rel=1e-5)
+    assert sum(s.self_bias_data for s in share) == pytest.approx(rw.self_bias_data, rel=1e-5)
+
+
+def test_c5_per_gpu_shape_fp64():
+    """Config C5 as one GPU holds it: fp64, p = n_obs = 512, J = 32 768, ALDI with the on-device blocked
+    Cholesky, against the fp64 torch restatement on the device (1e-6, north star) -- plus the same problem
+    at J = 4 096 against the pinned oracle."""
+    import torch
+    from ces_amd import engine
+    from oracle import ces_numpy as oc
+    p = n = 512
+    rng = np.random.default_rng(1)
+    A = rng.standard_normal((n, p)) / np.sqrt(p)
+    ustar = rng.standard_normal((p, 1))
+    prob = dict(A=A, ustar=ustar, Gamma=0.01 * np.eye(n), y=(A @ ustar).ravel() + 0.1 * rng.standard_normal(n),
+                mu=np.zeros((p, 1)), sigma=100.0 * np.eye(p))
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for Jn, check in ((32768, "torch"), (4096, "oracle")):
+        U = torch.as_tensor(ustar, device="cuda") + torch.randn((p, Jn), generator=g, device="cuda", dtype=torch.float64)
+        G = torch.as_tensor(A, device="cuda") @ U
+        xi = torch.randn((p, Jn), generator=g, device="cuda", dtype=torch.float64)
+        eng = engine.Engine(p, n, Jn, dtype="float64")
+        eng.set_problem(prob["y"], prob["Gamma"], prob["mu"], prob["sigma"], prob["ustar"])
+        out = eng.step(engine.step_params(update="aldi"), U, G, xi=xi)
+        res = eng.result()
+        if check == "torch":
+            ref, hk, met = torch_factored_aldi(prob, U, G, xi)
+            assert ((out - ref).abs().max() / ref.abs().max()).item() < 1e-6
+            assert res.hk == pytest.approx(hk, rel=1e-9)
+            for k, v in met.items():
+                assert getattr(res, k) == pytest.approx(v, rel=1e-7), k
+        else:
+            st = oc.OracleState(p, n, Jn, prob["mu"], prob["sigma"], prob["ustar"])
+            ref = oc.factored_step(st, prob["y"], U.cpu().numpy(), G.cpu().numpy(), prob["Gamma"], xi.cpu().numpy())
+            assert np.max(np.abs(out.cpu().numpy() - ref)) / np.max(np.abs(ref)) < 1e-6
+            assert res.hk == pytest.approx(st.metrics["t"][-1], rel=1e-8)
+            assert res.bias_data == pytest.approx(st.metrics["bias-data"][-1], rel=1e-8)
+        del eng, U, G, xi, out
+        torch.cuda.empty_cache()
+
+
 def test_c3_logical_shards_match_whole_ensemble(setup):
     """configs[2] arithmetic on one device: 4 column shards, moments summed on device
     (stand-in for the RCCL all-reduce), apply per shard == single-shard step."""

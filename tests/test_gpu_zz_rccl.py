@@ -1,0 +1,174 @@
+"""RCCL inside ``pytest -m gpu``: the N > 1 code path of ces_amd.dist (head all-reduce + chol(C) on the
+engine's side stream beside the second Gram launch, tail all-reduce on the main stream, max-reduction for
+aldi_constant) with the collectives really issued through torch.distributed's "nccl" backend (= RCCL) on a
+ONE-rank communicator ("RCCL path exercised with nranks = 1"), and -- on a box with two
+devices -- a two-rank run against the single-rank result.  This file sorts last on purpose: RCCL creates its
+own streams when the communicator comes up."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _problem(p, n, J, seed=31):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((n, p)) / np.sqrt(p)
+    ustar = rng.standard_normal((p, 1))
+    y = (A @ ustar).ravel() + 0.1 * rng.standard_normal(n)
+    U0 = ustar + 0.5 * rng.standard_normal((p, J))
+    return dict(A=A, ustar=ustar, Gamma=0.01 * np.eye(n), sigma=100.0 * np.eye(p), mu=np.zeros((p, 1)), y=y, U0=U0)
+
+
+@pytest.fixture(scope="module")
+def rccl_one_rank():
+    import torch
+    import torch.distributed as dist
+    from ces_amd import build
+    build.build_lib()
+    assert torch.cuda.is_available()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    t = torch.ones(4, device="cuda")
+    dist.all_reduce(t)                                   # the communicator exists and sees one rank
+    assert float(t.sum()) == 4.0 and dist.get_world_size() == 1 and dist.get_backend() == "nccl"
+    yield dist
+    dist.destroy_process_group()
+
+
+def _chain(engine, d, update, p, n, J, steps, monkeypatch, collectives, counter):
+    import torch.distributed as dist
+    from ces_amd.dist import ShardedUpdate
+    if collectives:
+        monkeypatch.setenv("CESX_FORCE_COLLECTIVES", "1")
+        monkeypatch.setenv("CESX_FORCE_COMM_OVERLAP", "1")
+    else:
+        monkeypatch.delenv("CESX_FORCE_COLLECTIVES", raising=False)
+        monkeypatch.delenv("CESX_FORCE_COMM_OVERLAP", raising=False)
+    real = dist.all_reduce
+
+    def counted(t, *a, **k):
+        counter.append(int(t.numel()))
+        return real(t, *a, **k)
+    monkeypatch.setattr(dist, "all_reduce", counted)
+    eng = engine.Engine(p, n, J, dtype="float32", seed=9)
+    eng.set_problem(d["y"], d["Gamma"], d["mu"], d["sigma"], d["ustar"])
+    sh = ShardedUpdate(eng)
+    assert sh.overlap_comm == collectives
+    U = eng.to_device(d["U0"])
+    t_last, chain = 0.0, []
+    for i in range(steps):
+        G = eng.forward_lineal(d["A"], U)
+        prm = engine.step_params(update=update, first_step=(i == 0), t_len=min(i, 1), t_last=t_last, step_index=i)
+        U = sh.step(prm, U, G, xi=None, recenter=(i == 0))
+        res = sh.result()
+        t_last = res.t_new
+        chain.append((res.hk, res.t_new, res.bias_data, res.self_bias_data, res.lag_bias_data))
+    monkeypatch.setattr(dist, "all_reduce", real)
+    return U.cpu().numpy(), chain
+
+
+@pytest.mark.parametrize("update", ["aldi", "aldi_constant"])
+def test_one_rank_rccl_path_is_bit_identical(rccl_one_rank, monkeypatch, update):
+    from ces_amd import engine
+    p, n, J, steps = 128, 96, 8192, 4
+    d = _problem(p, n, J)
+    calls_plain, calls_rccl = [], []
+    ref = _chain(engine, d, update, p, n, J, steps, monkeypatch, False, calls_plain)
+    got = _chain(engine, d, update, p, n, J, steps, monkeypatch, True, calls_rccl)
+    assert calls_plain == []                               # world == 1: no collective unless forced
+    nuu, nall = 1 + p + p * p, 1 + p + n + p * p + p * n + n * n + 2
+    per_step = [nuu, nall - nuu] + ([1] if update == "aldi_constant" else [])
+    assert calls_rccl == [1 + p + n] + per_step * steps    # centring shift once, then head + tail (+ max) per step
+    assert np.array_equal(ref[0], got[0])
+    assert ref[1] == got[1]
+
+
+def test_one_rank_rccl_sharded_sampler(rccl_one_rank, monkeypatch):
+    """ShardedSampler.run (pipelined loop, device forward hook) with RCCL collectives == without."""
+    import torch
+    from ces_amd import engine
+    from ces_amd.dist import ShardedSampler
+    from ces_amd.utils import lineal
+    p, n, J, T = 64, 50, 4096, 5
+    d = _problem(p, n, J, seed=5)
+    outs = []
+    for coll in (False, True):
+        if coll:
+            monkeypatch.setenv("CESX_FORCE_COLLECTIVES", "1")
+            monkeypatch.setenv("CESX_FORCE_COMM_OVERLAP", "1")
+        eng = engine.Engine(p, n, J, dtype="float64", seed=3)
+        smp = ShardedSampler(eng, p, n, J)
+        smp.T = T
+        U = smp.run(d["y"], d["U0"], lineal(d["A"]), d["Gamma"], d["mu"], d["sigma"], d["ustar"], t_tol=1e9)
+        torch.cuda.synchronize()
+        outs.append((U.cpu().numpy(), dict(smp.metrics)))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert outs[0][1] == outs[1][1]
+
+
+def _two_rank_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world,
+                            device_id=torch.device("cuda", rank))
+    from ces_amd import engine
+    from ces_amd.dist import ShardedSampler, shard_range
+    from ces_amd.utils import lineal
+    p, n, J, T = 64, 50, 4097, 4
+    d = _problem(p, n, J, seed=5)
+    lo, hi = shard_range(J, world, rank)
+    eng = engine.Engine(p, n, hi - lo, dtype="float64", device=rank, J_global=J, j_offset=lo, seed=3)
+    smp = ShardedSampler(eng, p, n, J)
+    smp.T = T
+    U = smp.run(d["y"], d["U0"][:, lo:hi], lineal(d["A"]), d["Gamma"], d["mu"], d["sigma"], d["ustar"], t_tol=1e9)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (lo, U.cpu().numpy()))
+    if rank == 0:
+        q.put((np.concatenate([g[1] for g in sorted(gathered, key=lambda g: g[0])], axis=1), dict(smp.metrics)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_rccl_matches_single_rank():
+    """Two GPUs, two ranks over RCCL vs one rank holding the whole ensemble (fp64, on-device Philox noise
+    keyed by the global particle index): same trajectory.  Needs two devices -- skipped on a one-GPU box."""
+    import torch
+    import torch.multiprocessing as mp
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two HIP devices")
+    from ces_amd import engine
+    from ces_amd.dist import ShardedSampler
+    from ces_amd.utils import lineal
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    full, metrics = q.get(timeout=300)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    p, n, J, T = 64, 50, 4097, 4
+    d = _problem(p, n, J, seed=5)
+    eng = engine.Engine(p, n, J, dtype="float64", seed=3)
+    smp = ShardedSampler(eng, p, n, J)
+    smp.T = T
+    U = smp.run(d["y"], d["U0"], lineal(d["A"]), d["Gamma"], d["mu"], d["sigma"], d["ustar"], t_tol=1e9)
+    assert np.max(np.abs(U.cpu().numpy() - full)) / np.max(np.abs(full)) < 1e-9
+    for k in ("t", "bias", "self-bias", "bias-data", "self-bias-data"):
+        assert np.allclose(metrics[k], smp.metrics[k], rtol=1e-9), k
