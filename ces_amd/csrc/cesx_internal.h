@@ -49,6 +49,33 @@ template <> struct Mfma<double> {
     static __device__ __forceinline__ int ccol(int lane) { return lane & 15; }
 };
 
+// Gram kernels: blocks per wave (accumulator budget: 5 x 16 / 9 x 8 VGPRs of the 128 a wave has at
+// 4 waves per SIMD); the host's work partition and both Gram kernels use the same constant.
+template <typename T> struct GramCfg;
+template <> struct GramCfg<float>  { static constexpr int NBW = 4; };
+template <> struct GramCfg<double> { static constexpr int NBW = 8; };
+
+// one LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to lds_dst + 16 lane (M0 = the
+// wave-uniform LDS byte address; hipcc keeps nothing live in M0 across a statement).  The compiler's
+// s_waitcnt bookkeeping does not see these loads: callers wait with an explicit vmcnt.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// Slab layout of one partial Gram block ("accumulator-major"): element ((q * 64 + lane) * VEC + e)
+// is accumulator register VEC * q + e of lane `lane`, so a wave stores a block with 16-byte stores
+// of consecutive lanes (1 KiB per instruction).  (row, col) of the first element of group `grp`
+// (= q * 64 + lane); the VEC elements of a group are rows row0 + e (f32) / row0 + 4 e (f64).
+template <typename T> __host__ __device__ inline void slab_group_rc(int grp, int& row0, int& col, int& rstep);
+template <> __host__ __device__ inline void slab_group_rc<float>(int grp, int& row0, int& col, int& rstep) {
+    const int q = grp >> 6, lane = grp & 63;
+    row0 = 8 * q + 4 * (lane >> 5); col = lane & 31; rstep = 1;          // reg = 4 q + e: (reg & 3) + 8 (reg >> 2) + 4 lh
+}
+template <> __host__ __device__ inline void slab_group_rc<double>(int grp, int& row0, int& col, int& rstep) {
+    const int q = grp >> 6, lane = grp & 63;
+    row0 = (lane >> 4) + 8 * q; col = lane & 15; rstep = 4;              // reg = 2 q + e: (lane >> 4) + 4 reg
+}
+
 // j (or k) values covered by one 16-byte fragment read of every lane: the
 // KSTEP lane groups each take VEC consecutive values -> KSTEP * VEC = 8.
 constexpr int GROUP = 8;
@@ -228,6 +255,7 @@ struct Engine {
     void* d_W = nullptr;           // [rpad][ktot]
     void* d_Wf = nullptr;          // fp32 engines: the same matrix in the fragment-major order of kernels_update2.hip
     bool update_v2 = true;         // fp32 K3 through the LDS-DMA kernel (CESX_UPDATE_V1=1 switches back)
+    bool gram_v2 = true;           // K1 through the LDS-DMA kernel when the shapes allow (CESX_GRAM_V1=1 switches back)
     int num_cus = 256;
     void* d_bias = nullptr;        // [rpad]
     void* d_Wfwd = nullptr;        // forward-map staging [npad][kp]
@@ -260,6 +288,8 @@ struct UpdateSrc {            // one K-segment of the update GEMM
 int launch_colsum(Engine& e, const void* U, const void* G, double* sums, hipStream_t s);
 int launch_set_shift(Engine& e, const double* sums, hipStream_t s);
 int launch_gram(Engine& e, int part, const void* U, const void* G, double* mom, hipStream_t s);   // part 0 / 1
+// kernels_gram2.hip (LDS-DMA Gram): CESX_OK, an error, or -1 when the launch does not qualify (caller falls back)
+int launch_gram2(Engine& e, int part, const void* U, const void* G, hipStream_t s);
 int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int phase, hipStream_t s);
 int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s);
 struct UpdateOpt {

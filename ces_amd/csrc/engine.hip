@@ -183,6 +183,7 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
     e.esz = cfg->dtype == CESX_F32 ? 4 : 8;
     if (const char* ov = std::getenv("CESX_OVERLAP")) e.overlap_chol = ov[0] != '0';
     if (const char* uv = std::getenv("CESX_UPDATE_V1")) e.update_v2 = uv[0] == '0';
+    if (const char* gv = std::getenv("CESX_GRAM_V1")) e.gram_v2 = gv[0] == '0';
     auto fail = [&](int rc) { g_create_err = e.err; cesx_destroy(reinterpret_cast<cesx_handle>(ep)); return rc; };
     int rc;
     DeviceGuard dg(cfg->device);
@@ -208,8 +209,10 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
             int min_types = 1;
             if (part == 0) if (const char* gv = std::getenv("CESX_GRAM_UU_TYPES")) min_types = std::atoi(gv);
             // part 1: 7 workgroups per shader engine (8 CUs), so that the Cholesky always finds a free CU
+            int budget = part == 0 ? e.num_cus : e.num_cus - e.num_cus / 8;      // 256 / 224 on MI355X
+            if (part == 1) if (const char* bv = std::getenv("CESX_GRAM_B_WGS")) budget = std::max(8, std::atoi(bv));
             gp.plan = make_gram_plan(P, tile, gram_nbw(cfg->dtype), gram_max_stage_rows(), part + 1, pbU, min_types,
-                                     part == 0 ? 256 : 224, ntiles);
+                                     budget, ntiles);
             if (gp.plan.max_rb * tile > gram_max_stage_rows()) { e.err = "gram plan exceeds LDS"; return fail(CESX_EINVAL); }
         }
     }

@@ -33,9 +33,6 @@ constexpr int ROW_STRIDE = ROW_BYTES + 16;  // +16 B pad: conflict-free ds_read_
 constexpr int MAX_STAGE_ROWS = 512;
 constexpr int MAXCH = MAX_STAGE_ROWS * (ROW_BYTES / 16) / GRAM_THREADS;   // 16 chunks / thread
 
-template <typename T> struct GramCfg;
-template <> struct GramCfg<float>  { static constexpr int NBW = 5; };    // 5 x 16 accumulator VGPRs per wave
-template <> struct GramCfg<double> { static constexpr int NBW = 9; };    // 9 x 8
 
 #ifdef GRAM_CLOCKS   // dev instrumentation (tools/gram_bench.hip): per-workgroup cycle stamps
 __device__ long long g_gram_clk[4096 * 4];
@@ -244,10 +241,15 @@ void gram_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __re
     for (int b = 0; b < NBW; ++b) {
         if (b < nb) {
             const int ob = __builtin_amdgcn_readfirstlane(wblk[(size_t)(blocks_off + wave * NBW + b) * 3 + 2]);
+            // accumulator-major slab (slab_group_rc): 16-byte stores of consecutive lanes
             T* out = slabs + ((size_t)slab0 + (size_t)slice * nblk_t + ob) * (TILE * TILE);
 #pragma unroll
-            for (int r = 0; r < M::NACC; ++r)
-                out[M::crow(lane, r) * TILE + M::ccol(lane)] = acc[b][r];
+            for (int q = 0; q < M::NACC / VEC; ++q) {
+                vec_t v;
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) v[c] = acc[b][q * VEC + c];
+                *reinterpret_cast<vec_t*>(out + (size_t)(q * 64 + lane) * VEC) = v;
+            }
         }
     }
 #ifdef GRAM_CLOCKS
@@ -343,10 +345,11 @@ void gram_reduce_kernel(const T* __restrict__ slabs, const int* __restrict__ blk
     double* Saa = mom + ml.Saa();
     double* Sab = mom + ml.Sab();
     double* Sbb = mom + ml.Sbb();
+    int row0, col, rstep;
+    slab_group_rc<T>(e0 / VEC, row0, col, rstep);
 #pragma unroll
     for (int c = 0; c < VEC; ++c) {
-        const int e = e0 + c;
-        const int gr = R * tile + e / tile, gc = C * tile + e % tile;
+        const int gr = R * tile + row0 + c * rstep, gc = C * tile + col;
         if (gr >= P || gc >= P) continue;
         if (R == C && gc > gr) continue;          // diagonal block: lower half, mirrored below
         double s = 0.0;
@@ -388,11 +391,14 @@ GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset, 
             for (int C = 0; C <= R; ++C)
                 if (wanted(R, C)) all.push_back({R, C});
         const int nt = std::max(std::max(1, min_types), ((int)all.size() + cap - 1) / cap);
-        const int per = std::max(1, ((int)all.size() + nt - 1) / nt);
-        for (int t = 0; t < nt; ++t) {
-            std::vector<std::pair<int, int>> v(all.begin() + std::min<size_t>(all.size(), (size_t)t * per),
-                                               all.begin() + std::min<size_t>(all.size(), (size_t)(t + 1) * per));
-            if (!v.empty()) types.push_back(v);
+        // equal runs, rounded to multiples of 4 blocks: the 4 SIMDs of a workgroup then carry the same
+        // number of blocks (the barrier of every J tile waits for the busiest SIMD); the last type
+        // takes what is left
+        int per = std::max(1, ((int)all.size() + nt - 1) / nt);
+        if (per > 4) per = std::min(cap / 4 * 4, (per + 3) / 4 * 4);
+        for (size_t lo = 0; lo < all.size(); lo += per) {
+            std::vector<std::pair<int, int>> v(all.begin() + lo, all.begin() + std::min(all.size(), lo + (size_t)per));
+            types.push_back(v);
         }
     } else {
         // rectangles a x b of blocks with (a + b) * tile rows staged
@@ -542,10 +548,14 @@ static int launch_gram_t(Engine& e, int part, const void* U, const void* G, doub
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     if (pl.nblocks > 0) {       // (a tiny problem can have all its blocks in part 0; the reduce below still
                                 //  writes part 1's share of the buffer: row sums it owns and the lagged tail)
-        ProfScope prof(e, 0, s);
-        hipLaunchKernelGGL(kern, grid, block, lds, s, (const T*)U, (const T*)G, (const T*)e.d_shiftT,
-                           e.p, e.n, (long long)e.J, gp.d_type_hdr, pl.ntypes, gp.d_rows, gp.d_wblk,
-                           (T*)gp.d_slabs, gp.d_rowsum_part);
+        int rc2 = e.gram_v2 ? launch_gram2(e, part, U, G, s) : -1;      // LDS-DMA kernel when the shapes allow
+        if (rc2 > 0) return rc2;
+        if (rc2 < 0) {
+            ProfScope prof(e, 0, s);
+            hipLaunchKernelGGL(kern, grid, block, lds, s, (const T*)U, (const T*)G, (const T*)e.d_shiftT,
+                               e.p, e.n, (long long)e.J, gp.d_type_hdr, pl.ntypes, gp.d_rows, gp.d_wblk,
+                               (T*)gp.d_slabs, gp.d_rowsum_part);
+        }
     }
     CESX_HIP(hipGetLastError());
     const long long ngroups = (long long)pl.nblocks * pl.tile * pl.tile / Mfma<T>::VEC;

@@ -1,0 +1,314 @@
+// K1, LDS-DMA form -- the same split-K Gram of the shifted stacked ensemble Z = [U - s_u ; G - s_g]
+// as kernels_gram.hip (np.cov(U0) ces/calibrate.py:424/476/512, D = (1/J) E^T Gamma^{-1} R of
+// :429/:461/:503 and np.cov(Geval) :440/:472 all factor through Z Z^T), fed the way
+// K3 (kernels_update2.hip) is fed:
+//
+//  * raw rows of U / G go global -> LDS by DMA (global_load_lds_dwordx4), one piece = 8 rows x 128 B
+//    (a whole 128-B line per row and instruction: fully coalesced).  No staging registers, no
+//    ds_write pass, no subtract-and-store pass.
+//  * a DMA writes its 64 x 16 B contiguously (lds_base + 16 lane), so rows sit 128 B apart in LDS --
+//    a 4-way bank conflict for 16-byte fragment reads of 16 different rows.  The conflict is removed
+//    at the SOURCE: the lane that fills chunk c' of row r fetches global chunk c' ^ ((r >> 1) & 7),
+//    a permutation inside the row's 128-B line (coalescing unchanged); readers apply the same XOR.
+//    Every 16-lane group of a ds_read_b128 then covers all 64 banks exactly once (f32 and f64 maps).
+//  * the f32-input MFMA runs on the SIMD's f32 vector lanes: every VALU instruction in the K loop takes
+//    its issue cycles away from the matrix pipe (tools/mfma_rate.hip: 64.0 cycles per MFMA with LDS-fed
+//    operands, 72 with two v_sub per MFMA at 4 waves per SIMD, 89 at one).  So the centring shift is NOT
+//    subtracted on the fragments (2 subs per MFMA); the wave that issued a DMA piece subtracts the shift
+//    from it IN PLACE once it has landed (ds_read_b128 / 4 subs / ds_write_b128 per piece: 6x fewer
+//    VALU instructions than on the fragments) and accumulates the first moments (row sums) on the way.
+//    The MFMA loop is then LDS reads, one address add per read and MFMAs.
+//  * two LDS slots: the DMAs of tile t+1 are issued before the MFMAs of tile t; after its MFMAs a wave
+//    waits for its own pieces of tile t+1, shifts them, and joins the ONE barrier of the tile.
+//
+// Work partition, slab layout and the fp64 fixed-order reduce are those of kernels_gram.hip
+// (GramPlan, gram_reduce_kernel).  Qualifies when J is a multiple of the tile width (32 f32 / 16 f64)
+// and U, G are 16-byte aligned; otherwise the register-staged kernel runs.
+// Bound: MFMA (v_mfma_f32_32x32x2_f32 / v_mfma_f64_16x16x4_f64).
+#include "cesx_internal.h"
+
+namespace cesx {
+
+constexpr int G2_THREADS = 1024;           // 16 waves = 4 per SIMD
+constexpr int G2_WAVES = G2_THREADS / 64;
+constexpr int G2_ROWB = 128;               // bytes of one row in a tile: 32 f32 / 16 f64
+constexpr int G2_MAX_ROWS = 512;           // = MAX_STAGE_ROWS of kernels_gram.hip (the plans are shared)
+constexpr int G2_MAXP = G2_MAX_ROWS / 8 / G2_WAVES;      // DMA pieces per wave and tile (4)
+#ifndef G2_ABL      // timing ablations (tools/gram2_bench.hip); results are wrong when set
+#define G2_ABL 0
+#endif
+#ifdef G2_CLOCKS
+__device__ long long g_gram2_clk[4096 * 4];
+__device__ long long g_gram2_bar[4096 * 16];      // per wave: cycles spent in the per-tile barrier
+#endif
+
+template <typename T>
+__global__ __launch_bounds__(G2_THREADS, 4)
+void gram2_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __restrict__ shift,
+                  int p, int n, long long J, const int* __restrict__ type_hdr, int ntypes,
+                  const int* __restrict__ rows_tab, const int* __restrict__ wblk,
+                  T* __restrict__ slabs, double* __restrict__ rowsum_part) {
+    using M = Mfma<T>;
+    using vec_t = typename M::vec_t;
+    using acc_t = typename M::acc_t;
+    constexpr int TILE = M::TILE, VEC = M::VEC, NBW = GramCfg<T>::NBW;
+    constexpr int KT = G2_ROWB / (int)sizeof(T);         // particles per tile
+    constexpr int KL = 64 / TILE;                        // lane groups of a fragment read (k sub-blocks)
+    constexpr int NGROUP = 8 / KL;                       // fragment reads per row and tile
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef G2_CLOCKS
+    const long long gclk0 = clock64(), gw0 = wall_clock64();
+#endif
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int type = 0;
+    for (int t = 1; t < ntypes; ++t)
+        if ((int)blockIdx.x >= type_hdr[t * 8 + 4]) type = t;
+    const int* hdr = type_hdr + type * 8;
+    const int nrb = hdr[0], rows_off = hdr[1], blocks_off = hdr[2], nblk_t = hdr[3];
+    const int slice = (int)blockIdx.x - hdr[4], nslices = hdr[5];
+    const int slab0 = hdr[6], rs0 = hdr[7];
+    const int nrows = nrb * TILE;
+    const int P = p + n;
+    const int slot_bytes = nrows * G2_ROWB;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
+
+    // this wave's block list: (compact row block of A) | (of B) << 8, wave-uniform
+    int iab[NBW];
+    int nb = 0;
+#pragma unroll
+    for (int b = 0; b < NBW; ++b) {
+        const int* e = wblk + (size_t)(blocks_off + wave * NBW + b) * 3;
+        const int a = __builtin_amdgcn_readfirstlane(e[0]);
+        const int c = __builtin_amdgcn_readfirstlane(e[1]);
+        iab[b] = a | (c << 8);
+        if (a >= 0) nb = b + 1;
+    }
+    nb = __builtin_amdgcn_readfirstlane(nb);
+
+    acc_t acc[NBW];
+#pragma unroll
+    for (int b = 0; b < NBW; ++b)
+#pragma unroll
+        for (int r = 0; r < M::NACC; ++r) acc[b][r] = 0;
+
+    // J-slice of this workgroup in whole tiles (J % KT == 0)
+    const long long ntiles = J / KT;
+    const long long tps = (ntiles + nslices - 1) / nslices;
+    const long long t0 = (long long)slice * tps;
+    const long long t1 = t0 + tps < ntiles ? t0 + tps : ntiles;
+
+    // per staged row: source pointer and shift.  Rows past P (padding of the last block row) read row 0
+    // of U: their products land in rows / columns the reduce never reads.
+    const T** rowptr = reinterpret_cast<const T**>(smem + 2 * slot_bytes);
+    T* rowshift = reinterpret_cast<T*>(smem + 2 * slot_bytes + nrows * 8);
+    for (int row = tid; row < nrows; row += G2_THREADS) {
+        const int gr = (rows_tab[rows_off + row / TILE] & 0xffff) * TILE + row % TILE;
+        const T* ptr = U;
+        T sh = 0;
+        if (gr < P) {
+            ptr = gr < p ? U + (size_t)gr * J : G + (size_t)(gr - p) * J;
+            sh = shift[gr];
+        }
+        rowptr[row] = ptr;
+        rowshift[row] = sh;
+    }
+    __syncthreads();
+
+    // DMA pieces of this wave: piece q = wave + 16 i covers rows 8q .. 8q+7; lane = (row in piece, chunk).
+    // Per-lane source pointers live in registers and advance by one tile per issue (one 64-bit add per
+    // piece and tile: every VALU instruction in this loop is taken from the MFMA rate).
+    const int npieces = nrows >> 3;
+    const int prow = lane >> 3;
+    const T* gsrc[G2_MAXP];
+#pragma unroll
+    for (int i = 0; i < G2_MAXP; ++i) {
+        const int q = wave + G2_WAVES * i;
+        const int row = q < npieces ? 8 * q + prow : 0;
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);            // the swizzle (see the header)
+        gsrc[i] = rowptr[row] + t0 * KT + chunk * VEC;
+    }
+    auto issue_tile = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < G2_MAXP; ++i) {
+            const int q = wave + G2_WAVES * i;
+            if (q < npieces) {
+                if (!(G2_ABL & 1)) glds16(gsrc[i], lds0 + slot * slot_bytes + q * 1024);
+                gsrc[i] += KT;
+            }
+        }
+    };
+
+    // in-place shift of this wave's own pieces (the lane that fetched a 16-byte chunk also shifts it)
+    T psh[G2_MAXP], rs[G2_MAXP];
+#pragma unroll
+    for (int i = 0; i < G2_MAXP; ++i) {
+        const int q = wave + G2_WAVES * i;
+        psh[i] = q < npieces ? rowshift[8 * q + prow] : (T)0;
+        rs[i] = 0;
+    }
+    auto shift_tile = [&](int slot) {
+        char* sb = smem + slot * slot_bytes + lane * 16;
+        vec_t v[G2_MAXP];
+#pragma unroll
+        for (int i = 0; i < G2_MAXP; ++i) {
+            const int q = wave + G2_WAVES * i;
+            if (q < npieces) v[i] = *reinterpret_cast<const vec_t*>(sb + q * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < G2_MAXP; ++i) {
+            const int q = wave + G2_WAVES * i;
+            if (q < npieces) {
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) { v[i][c] -= psh[i]; rs[i] += v[i][c]; }
+                *reinterpret_cast<vec_t*>(sb + q * 1024) = v[i];
+            }
+        }
+    };
+
+    // fragment reads: lane = (k sub-block lk, row li of the block); group g reads chunk KL g + lk of the
+    // row, XOR-swizzled: byte offset foff0 ^ (g * KL * 16)  (KL g has no bit in common with lk)
+    const int li = lane % TILE, lk = lane / TILE;
+    const int foff0 = li * G2_ROWB + ((lk ^ ((li >> 1) & 7)) << 4);
+    int foff[NGROUP];
+#pragma unroll
+    for (int g = 0; g < NGROUP; ++g) foff[g] = foff0 ^ (g * KL * 16);
+
+    // One (block, group) step: VEC MFMAs on fragments that were loaded one step earlier.  The loads of
+    // the NEXT step are issued first (sched_barrier keeps them there), so every LDS read has VEC MFMAs
+    // (256 / 128 cycles) between issue and use instead of an exposed lgkmcnt(0) in front of each MFMA.
+    struct Frag { vec_t a, c; };
+    auto load_frag = [&](Frag& f, const char* base, int b, int g) {
+        if (G2_ABL & 4) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) { f.a[v] = (T)(lane + v + b); f.c[v] = (T)(lane - v + g); }
+            return;
+        }
+        f.a = *reinterpret_cast<const vec_t*>(base + (iab[b] & 0xff) * (TILE * G2_ROWB) + foff[g]);
+        f.c = *reinterpret_cast<const vec_t*>(base + (iab[b] >> 8) * (TILE * G2_ROWB) + foff[g]);
+    };
+
+    if (t0 < t1) {
+        issue_tile(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        shift_tile(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef G2_CLOCKS
+    const long long gclk1 = clock64();
+    long long gbar = 0;
+#endif
+    for (long long t = t0; t < t1; ++t) {
+        const int cur = (int)((t - t0) & 1);
+        if (t + 1 < t1) issue_tile(cur ^ 1);
+        const char* base = smem + cur * slot_bytes;
+        Frag f0, f1;
+        if (nb > 0) load_frag(f0, base, 0, 0);
+#pragma unroll
+        for (int b = 0; b < NBW; ++b) {
+            if (b < nb) {
+#pragma unroll
+                for (int g = 0; g < NGROUP; ++g) {
+                    Frag& fc = (g & 1) ? f1 : f0;
+                    Frag& fn = (g & 1) ? f0 : f1;
+                    // prefetch the next step: group g+1 of this block, or group 0 of the next block
+                    if (g + 1 < NGROUP) {
+                        load_frag(fn, base, b, g + 1);
+                    } else if (b + 1 < NBW) {
+                        if (b + 1 < nb) load_frag(fn, base, b + 1, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[b] = M::mma(fc.a[v], fc.c[v], acc[b]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        static_assert(NGROUP % 2 == 0, "the fragment double buffer returns to f0 at every block boundary");
+#ifdef G2_CLOCKS
+        const long long tb0 = clock64();
+#endif
+        // this wave's pieces of tile t+1 have landed: shift them in place; then the tile's one barrier
+        // (every wave has read slot `cur`, every piece of tile t+1 is shifted)
+        if (t + 1 < t1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(G2_ABL & 8)) shift_tile(cur ^ 1);
+        }
+        if (!(G2_ABL & 2)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef G2_CLOCKS
+        gbar += clock64() - tb0;
+#endif
+    }
+#ifdef G2_CLOCKS
+    const long long gclk2 = clock64();
+#endif
+
+    // first moments of this slice: the 8 lanes that share a row are adjacent; chunk 0's lane reports.
+    // Only the type that owns a block row reports it.
+#pragma unroll
+    for (int i = 0; i < G2_MAXP; ++i) {
+        const int q = wave + G2_WAVES * i;
+        double v = (double)rs[i];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        if (q < npieces && (lane & 7) == 0) {
+            const int row = 8 * q + prow;
+            const int ent = rows_tab[rows_off + row / TILE];
+            const int gr = (ent & 0xffff) * TILE + row % TILE;
+            if ((ent >> 16) != 0 && gr < P) rowsum_part[(size_t)(rs0 + slice) * P + gr] = v;
+        }
+    }
+
+    // partial blocks of this slice, accumulator-major (slab_group_rc): 16-byte stores of consecutive lanes
+#pragma unroll
+    for (int b = 0; b < NBW; ++b) {
+        if (b < nb) {
+            const int ob = __builtin_amdgcn_readfirstlane(wblk[(size_t)(blocks_off + wave * NBW + b) * 3 + 2]);
+            T* out = slabs + ((size_t)slab0 + (size_t)slice * nblk_t + ob) * (TILE * TILE);
+#pragma unroll
+            for (int q = 0; q < M::NACC / VEC; ++q) {
+                vec_t v;
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) v[c] = acc[b][q * VEC + c];
+                *reinterpret_cast<vec_t*>(out + (size_t)(q * 64 + lane) * VEC) = v;
+            }
+        }
+    }
+#ifdef G2_CLOCKS
+    if (lane == 0 && blockIdx.x < 4096) g_gram2_bar[blockIdx.x * 16 + wave] = gbar;
+    if (tid == 0 && blockIdx.x < 4096) {
+        g_gram2_clk[blockIdx.x * 4 + 0] = gclk1 - gclk0; g_gram2_clk[blockIdx.x * 4 + 1] = gclk2 - gclk1;
+        g_gram2_clk[blockIdx.x * 4 + 2] = clock64() - gclk2; g_gram2_clk[blockIdx.x * 4 + 3] = wall_clock64() - gw0;
+    }
+#endif
+}
+
+template <typename T>
+static int launch_gram2_t(Engine& e, int part, const void* U, const void* G, hipStream_t s) {
+    GramPart& gp = e.gp[part];
+    const GramPlan& pl = gp.plan;
+    constexpr int KT = G2_ROWB / (int)sizeof(T);
+    if (e.J % KT != 0 || e.J < KT || ((uintptr_t)U & 15) || ((uintptr_t)G & 15)) return -1;
+    const int nrows = pl.max_rb * pl.tile;
+    if (nrows > G2_MAX_ROWS || (nrows & 7)) return -1;
+    const int lds = 2 * nrows * G2_ROWB + nrows * 8 + nrows * (int)sizeof(T);
+    auto kern = gram2_kernel<T>;
+    CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    {
+        ProfScope prof(e, 0, s);
+        hipLaunchKernelGGL(kern, dim3(pl.total_wgs), dim3(G2_THREADS), lds, s, (const T*)U, (const T*)G,
+                           (const T*)e.d_shiftT, e.p, e.n, (long long)e.J, gp.d_type_hdr, pl.ntypes, gp.d_rows,
+                           gp.d_wblk, (T*)gp.d_slabs, gp.d_rowsum_part);
+    }
+    CESX_HIP(hipGetLastError());
+    return CESX_OK;
+}
+
+int launch_gram2(Engine& e, int part, const void* U, const void* G, hipStream_t s) {
+    return e.cfg.dtype == CESX_F32 ? launch_gram2_t<float>(e, part, U, G, s) : launch_gram2_t<double>(e, part, U, G, s);
+}
+
+}  // namespace cesx

@@ -49,12 +49,6 @@ struct Upd2Args {
     int stagger_from;     // workgroups with a linear index >= this start late (see the kernel)
 };
 
-// one LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to lds_dst + 16 lane (M0 = the
-// wave-uniform LDS byte address; hipcc keeps nothing live in M0 across a statement)
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(lds_dst) : "memory");
-}
-
 // wait until at most `n` of this wave's DMAs are outstanding, retire its LDS traffic, barrier
 __device__ __forceinline__ void ring_barrier(int n) {
     if (n >= 6)      asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
