@@ -290,7 +290,7 @@ def main():
         U, G = batches[i % NB]
         if prof["on"]:
             eng.profile_enable(i % PROF_EVERY == 0)
-        sh.begin(prm0, U, G, recenter=(i == 0))
+        sh.begin(prm0, U, G, recenter=(i == 0), noise_step=i)
 
     def finish(i):
         U, G = batches[i % NB]

@@ -269,7 +269,12 @@ struct Engine {
     Scalars* h_scal_dev = nullptr;       // device address of h_scal
     unsigned long long seq = 0;
     hipEvent_t ev = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;   // ev_c: side-stream centring done
-    hipStream_t side = nullptr;      // side stream: chol(C) runs beside the drift part of the update
+    hipStream_t side = nullptr;      // side stream (high priority): U x U Gram, chol(C), the step's last small kernel
+    hipStream_t bg = nullptr;        // background stream (low priority): noise blocks drawn ahead into idle CUs
+    hipEvent_t ev_in = nullptr, ev_k3 = nullptr, ev_m = nullptr, ev_x = nullptr;   // (spare)
+    void* d_xi = nullptr;            // [p][J] engine dtype: noise block drawn ahead by cesx_prefetch_noise
+    long long xi_step = -1;          // step index d_xi holds (-1: none)
+    long long xi_want = -1;          // step index asked for by cesx_prefetch_noise, drawn behind the next second Gram launch
     int last_update_grid_x = 0, last_update_grid = 0, last_metric_parts = 0;
     bool pending = false;
     cesx_step_params last_prm{};
@@ -287,7 +292,8 @@ struct UpdateSrc {            // one K-segment of the update GEMM
 
 int launch_colsum(Engine& e, const void* U, const void* G, double* sums, hipStream_t s);
 int launch_set_shift(Engine& e, const double* sums, hipStream_t s);
-int launch_gram(Engine& e, int part, const void* U, const void* G, double* mom, hipStream_t s);   // part 0 / 1
+int launch_gram(Engine& e, int part, const void* U, const void* G, double* mom, hipStream_t s, bool no_reduce = false);   // part 0 / 1
+int launch_gram_reduce(Engine& e, int part, double* mom, hipStream_t s);   // the fp64 slab reduce of that launch
 // kernels_gram2.hip (LDS-DMA Gram): CESX_OK, an error, or -1 when the launch does not qualify (caller falls back)
 int launch_gram2(Engine& e, int part, const void* U, const void* G, hipStream_t s);
 int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int phase, hipStream_t s);

@@ -120,8 +120,16 @@ int finish_step(Engine& e, const cesx_step_params& prm, hipStream_t s) {
     return CESX_OK;
 }
 
+// the noise block of this step drawn ahead by cesx_prefetch_noise (nullptr: draw inside the update kernel)
+const void* prefetched_noise(Engine& e, const cesx_step_params& prm, hipStream_t s) {
+    (void)s;      // drawn on the side stream behind chol(C); launch_dense has joined that stream already
+    if (!e.d_xi || e.xi_step != (long long)prm.step_index) return nullptr;
+    return e.d_xi;
+}
+
 int run_update_main(Engine& e, const cesx_step_params& prm, const void* U, const void* G, const void* xi,
                     void* Unext, hipStream_t s) {
+    if (!xi) xi = prefetched_noise(e, prm, s);
     UpdateSrc src[3] = {{U, e.p, 0, 0}, {G, e.n, 0, 0}, {xi, e.p, xi ? 0 : 1, 1}};
     UpdateOpt opt;
     opt.prof = 1;
@@ -156,9 +164,13 @@ const char* cesx_last_error(cesx_handle h) {
 // the other.  Priority levels have their own queues.
 static hipError_t create_side_stream(Engine& e) {
     int lo = 0, hi = 0;
-    if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo &&
-        hipStreamCreateWithPriority(&e.side, hipStreamNonBlocking, hi) == hipSuccess)
-        return hipSuccess;
+    const bool prio = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo;
+    // background stream: LOW priority (its own hardware queue); its kernels only take CUs nothing else wants
+    if (!(prio && hipStreamCreateWithPriority(&e.bg, hipStreamNonBlocking, lo) == hipSuccess)) {
+        hipError_t rc = hipStreamCreateWithFlags(&e.bg, hipStreamNonBlocking);
+        if (rc != hipSuccess) return rc;
+    }
+    if (prio && hipStreamCreateWithPriority(&e.side, hipStreamNonBlocking, hi) == hipSuccess) return hipSuccess;
     return hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking);
 }
 
@@ -283,6 +295,10 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
         hipEventCreateWithFlags(&e.ev_a, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e.ev_b, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e.ev_c, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e.ev_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e.ev_k3, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e.ev_m, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e.ev_x, hipEventDisableTiming) != hipSuccess ||
         create_side_stream(e) != hipSuccess) {
         e.err = "pinned host buffer / event creation failed";
         return fail(CESX_EHIP);
@@ -329,7 +345,11 @@ void cesx_destroy(cesx_handle h) {
     if (e.ev_a) (void)hipEventDestroy(e.ev_a);
     if (e.ev_b) (void)hipEventDestroy(e.ev_b);
     if (e.ev_c) (void)hipEventDestroy(e.ev_c);
+    for (hipEvent_t ev : {e.ev_in, e.ev_k3, e.ev_m, e.ev_x})
+        if (ev) (void)hipEventDestroy(ev);
     if (e.side) (void)hipStreamDestroy(e.side);
+    if (e.bg) (void)hipStreamDestroy(e.bg);
+    if (e.d_xi) (void)hipFree(e.d_xi);
     delete &e;
 }
 
@@ -398,6 +418,7 @@ int cesx_moments_uu(cesx_handle h, const void* U, const void* G, double* mom, vo
     if (!h) return CESX_EINVAL;
     Engine& e = *reinterpret_cast<Engine*>(h);
     TRY(moments_check(e, U, G, mom));
+    SET_DEVICE(e);
     return launch_gram(e, 0, U, G, mom, (hipStream_t)stream);
 }
 
@@ -414,6 +435,7 @@ int cesx_moments_rest(cesx_handle h, const void* U, const void* G, double* mom, 
     if (!h) return CESX_EINVAL;
     Engine& e = *reinterpret_cast<Engine*>(h);
     TRY(moments_check(e, U, G, mom));
+    SET_DEVICE(e);
     // (the reduce kernel of this launch also copies this shard's data-metric sums of the PREVIOUS
     //  apply to the tail of the buffer: they ride on this step's all-reduce)
     return launch_gram(e, 1, U, G, mom, (hipStream_t)stream);
@@ -455,6 +477,7 @@ int cesx_apply_finish(cesx_handle h, const cesx_step_params* prm, const double* 
     if (absmax != e.d_absmax) CESX_HIP(hipMemcpyAsync(e.d_absmax, absmax, 8, hipMemcpyDeviceToDevice, s));
     TRY(launch_dense(e, *prm, nullptr, 2, s));
     // U_next = sqrt(2hk) L xi + 1 * U + hk * drift   (drift currently lives in U_next)
+    if (!xi) xi = prefetched_noise(e, *prm, s);
     UpdateSrc src[1] = {{xi, e.p, xi ? 0 : 1, 1}};
     UpdateOpt opt;
     opt.wf = e.d_Wf;
@@ -478,6 +501,8 @@ int cesx_apply(cesx_handle h, const cesx_step_params* prm, const double* mom, co
     hipStream_t s = (hipStream_t)stream;
     TRY(launch_dense(e, *prm, mom, 0, s));
     TRY(run_update_main(e, *prm, U, G, xi, Unext, s));
+    // (Moving this last small kernel to the side stream was tried: the event record + wait pair costs
+    //  as much GPU idle time as the 7 us kernel itself.)
     TRY(finish_metrics(e, mom, G, true, s));     // also publishes the step result to the host
     e.pending = true;
     e.last_prm = *prm;
@@ -496,7 +521,9 @@ int cesx_step(cesx_handle h, const cesx_step_params* prm, const void* U, const v
         TRY(cesx_colsum(h, U, G, e.d_sums, stream));
         TRY(cesx_set_shift(h, e.d_sums, stream));
     }
-    // U x U moments -> chol(C) on the side stream, beside the rest of the Gram -> apply
+    if (!xi && e.overlap_chol) TRY(cesx_prefetch_noise(h, prm->step_index, stream));
+    // U x U moments -> chol(C) on the side stream, beside the rest of the Gram -> apply.  (Putting the
+    // U x U launch itself on the side stream too was measured slower: see ces_amd/dist.py.)
     TRY(cesx_moments_uu(h, U, G, e.d_mom, stream));
     if (e.overlap_chol) TRY(cesx_chol_async(h, prm->update, e.d_mom, stream));
     TRY(cesx_moments_rest(h, U, G, e.d_mom, stream));
@@ -551,6 +578,22 @@ int cesx_draw_noise(cesx_handle h, uint64_t step_index, void* xi, void* stream) 
     if (!xi) { e.err = "cesx_draw_noise: null pointer"; return CESX_EINVAL; }
     SET_DEVICE(e);
     return launch_noise(e, step_index, xi, (hipStream_t)stream);
+}
+
+int cesx_prefetch_noise(cesx_handle h, uint64_t step_index, void* stream) {
+    if (!h) return CESX_EINVAL;
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    SET_DEVICE(e);
+    (void)stream;
+    if (std::getenv("CESX_NO_NOISE_PREFETCH")) return CESX_OK;
+    if (!e.d_xi) {
+        CESX_HIP(hipMalloc(&e.d_xi, (size_t)e.p * (size_t)e.J * e.esz));
+    }
+    // The draw itself is enqueued by cesx_chol_async on the side stream, behind chol(C): no extra
+    // cross-stream event (each costs ~6 us of GPU idle time), and it runs while the caller's stream
+    // is in the tail of the second Gram launch and the latency-bound start of K2.
+    e.xi_want = (long long)step_index;
+    return CESX_OK;
 }
 
 int cesx_forward_lineal(cesx_handle h, const void* A, const void* b, const void* U, void* G, void* stream) {

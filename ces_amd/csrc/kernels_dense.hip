@@ -957,11 +957,11 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
     const int unbiased = prm.update == CESX_UPDATE_EKS ? 0 : 1;
     // If cesx_chol_async already ran for these moments, the U-only part of K2 (C, M, ubar, chol(C))
     // is done or in flight on the side stream; otherwise do it here, in line.
+    // The side stream (U-only centring, chol(C), the prefetched noise block) is joined ONCE, as late as the
+    // data flow allows: the G part of the centring needs the moments only; the scalar kernel is the first to
+    // read what the side stream wrote (trace / bias partials, later L).  One event each way per step -- every
+    // record / wait pair costs ~6 us of idle GPU.
     const bool early = e.chol_inflight;
-    if (early) CESX_HIP(hipStreamWaitEvent(s, e.ev_c, 0));
-    // p or n > 256: every Cholesky goes through the one blocked-factorisation workspace, so the rest of K2
-    // (which may factor hk C_gg + Gamma or Sigma + hk C) starts only after the side-stream chol(C)
-    if (early && e.d_Lwork) CESX_HIP(hipStreamWaitEvent(s, e.ev_b, 0));
     hipLaunchKernelGGL(center_kernel, dim3(NPB), dim3(DT), 0, s, mv, e.d_shift64, e.d_y, e.d_ustar,
                        e.diag_gamma ? e.d_gw : (const double*)nullptr,
                        e.diag_sigma ? e.d_sw : (const double*)nullptr, unbiased, early ? 2 : 3, e.d_ubar, e.d_gbar,
@@ -969,6 +969,10 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
     CESX_HIP(hipGetLastError());
     if (!early)
         if ((rc = potrf(e, s, p, e.d_C, e.d_L))) return rc;
+    if (early) {
+        CESX_HIP(hipStreamWaitEvent(s, e.ev_b, 0));
+        e.chol_inflight = false;
+    }
     if (!e.diag_gamma) {
         // Frobenius term <Ginv Srr Ginv, See>, and K = C_ug Ginv
         if ((rc = gemm(e, s, n, n, n, 1.0, e.d_Ginv, n, 1, e.d_Srr, n, 1, e.d_t1))) return rc;
@@ -1029,10 +1033,6 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
         hipLaunchKernelGGL(matvec_kernel, g1(p, 4), dim3(DT), 0, s, p, p, e.d_P, e.d_mv + 5 * mx, e.d_mv + 4 * mx);
         CESX_HIP(hipGetLastError());
     }
-    if (early) {                                     // join the side-stream Cholesky before W needs L
-        CESX_HIP(hipStreamWaitEvent(s, e.ev_b, 0));
-        e.chol_inflight = false;
-    }
     const int ktot = mode == 2 ? e.kp + e.kn : e.ktot;
     return f32 ? assemble<float>(e, s, mode, ktot, prm.switch_mult) : assemble<double>(e, s, mode, ktot, prm.switch_mult);
 }
@@ -1046,16 +1046,22 @@ int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s) {
     const int unbiased = update == CESX_UPDATE_EKS ? 0 : 1;
     // the whole U-only part of K2 (centre, C, M, then chol(C)) goes to the side stream: the main
     // stream continues with the second Gram launch straight after the U x U reduce
-    CESX_HIP(hipEventRecord(e.ev_a, s));
-    CESX_HIP(hipStreamWaitEvent(e.side, e.ev_a, 0));
+    if (s != e.side) {                             // (a caller already on the side stream needs no hand-over)
+        CESX_HIP(hipEventRecord(e.ev_a, s));
+        CESX_HIP(hipStreamWaitEvent(e.side, e.ev_a, 0));
+    }
     hipLaunchKernelGGL(center_kernel, dim3(NPB), dim3(DT), 0, e.side, mv, e.d_shift64, e.d_y, e.d_ustar,
                        e.diag_gamma ? e.d_gw : (const double*)nullptr,
                        e.diag_sigma ? e.d_sw : (const double*)nullptr, unbiased, 1, e.d_ubar, e.d_gbar,
                        e.d_m, e.d_dg, e.d_C, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_M, e.d_part, e.d_scal);
     CESX_HIP(hipGetLastError());
-    CESX_HIP(hipEventRecord(e.ev_c, e.side));      // ubar, C, M are final: the rest of K2 may read them
     int rc;
     if ((rc = potrf(e, e.side, p, e.d_C, e.d_L))) return rc;
+    if (e.xi_want >= 0 && e.d_xi) {                // noise block asked for by cesx_prefetch_noise
+        if ((rc = launch_noise(e, (uint64_t)e.xi_want, e.d_xi, e.side))) return rc;
+        e.xi_step = e.xi_want;
+        e.xi_want = -1;
+    }
     CESX_HIP(hipEventRecord(e.ev_b, e.side));
     e.chol_inflight = true;
     return CESX_OK;

@@ -537,27 +537,33 @@ GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset, 
 }
 
 template <typename T>
-static int launch_gram_t(Engine& e, int part, const void* U, const void* G, double* mom, hipStream_t s) {
+static int launch_gram_t(Engine& e, int part, const void* U, const void* G, hipStream_t s) {
     GramPart& gp = e.gp[part];
     const GramPlan& pl = gp.plan;
+    if (pl.nblocks == 0) return CESX_OK;    // (a tiny problem can have all its blocks in part 0; the reduce still
+                                            //  writes part 1's share of the buffer: row sums it owns and the lagged tail)
+    int rc2 = e.gram_v2 ? launch_gram2(e, part, U, G, s) : -1;      // LDS-DMA kernel when the shapes allow
+    if (rc2 >= 0) return rc2;
     const int lds = 2 * pl.max_rb * pl.tile * ROW_STRIDE + pl.max_rb * pl.tile * 16;
     const bool aligned = (e.J % Mfma<T>::VEC == 0) && ((uintptr_t)U % 16 == 0) && ((uintptr_t)G % 16 == 0);
     dim3 grid(pl.total_wgs), block(GRAM_THREADS);
     auto kern = aligned ? gram_kernel<T, true> : gram_kernel<T, false>;
     CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    if (pl.nblocks > 0) {       // (a tiny problem can have all its blocks in part 0; the reduce below still
-                                //  writes part 1's share of the buffer: row sums it owns and the lagged tail)
-        int rc2 = e.gram_v2 ? launch_gram2(e, part, U, G, s) : -1;      // LDS-DMA kernel when the shapes allow
-        if (rc2 > 0) return rc2;
-        if (rc2 < 0) {
-            ProfScope prof(e, 0, s);
-            hipLaunchKernelGGL(kern, grid, block, lds, s, (const T*)U, (const T*)G, (const T*)e.d_shiftT,
-                               e.p, e.n, (long long)e.J, gp.d_type_hdr, pl.ntypes, gp.d_rows, gp.d_wblk,
-                               (T*)gp.d_slabs, gp.d_rowsum_part);
-        }
+    {
+        ProfScope prof(e, 0, s);
+        hipLaunchKernelGGL(kern, grid, block, lds, s, (const T*)U, (const T*)G, (const T*)e.d_shiftT,
+                           e.p, e.n, (long long)e.J, gp.d_type_hdr, pl.ntypes, gp.d_rows, gp.d_wblk,
+                           (T*)gp.d_slabs, gp.d_rowsum_part);
     }
     CESX_HIP(hipGetLastError());
+    return CESX_OK;
+}
+
+template <typename T>
+static int launch_gram_reduce_t(Engine& e, int part, double* mom, hipStream_t s) {
+    GramPart& gp = e.gp[part];
+    const GramPlan& pl = gp.plan;
     const long long ngroups = (long long)pl.nblocks * pl.tile * pl.tile / Mfma<T>::VEC;
     const int row_lo = std::min(pl.own_lo * pl.tile, e.p + e.n), row_hi = std::min(pl.own_hi * pl.tile, e.p + e.n);
     const long long wgs = (ngroups + RED_G - 1) / RED_G + std::max(1, (row_hi - row_lo + RED_G - 1) / RED_G);
@@ -569,9 +575,14 @@ static int launch_gram_t(Engine& e, int part, const void* U, const void* G, doub
     return CESX_OK;
 }
 
-int launch_gram(Engine& e, int part, const void* U, const void* G, double* mom, hipStream_t s) {
-    return e.cfg.dtype == CESX_F32 ? launch_gram_t<float>(e, part, U, G, mom, s)
-                                   : launch_gram_t<double>(e, part, U, G, mom, s);
+int launch_gram_reduce(Engine& e, int part, double* mom, hipStream_t s) {
+    return e.cfg.dtype == CESX_F32 ? launch_gram_reduce_t<float>(e, part, mom, s) : launch_gram_reduce_t<double>(e, part, mom, s);
+}
+
+int launch_gram(Engine& e, int part, const void* U, const void* G, double* mom, hipStream_t s, bool no_reduce) {
+    int rc = e.cfg.dtype == CESX_F32 ? launch_gram_t<float>(e, part, U, G, s) : launch_gram_t<double>(e, part, U, G, s);
+    if (rc != CESX_OK || no_reduce) return rc;
+    return launch_gram_reduce(e, part, mom, s);
 }
 
 int gram_nbw(int dtype) { return dtype == CESX_F32 ? GramCfg<float>::NBW : GramCfg<double>::NBW; }

@@ -58,6 +58,12 @@ class ShardedUpdate:
             overlap_comm = (isinstance(dev, torch.device) and dev.type == "cuda" and
                             (self.world > 1 or os.environ.get("CESX_FORCE_COMM_OVERLAP") == "1"))
         self.overlap_comm = bool(overlap_comm)
+        # CESX_SIDE_GRAM=1: the U x U Gram launch itself also goes to the side stream.  Measured slower at C2
+        # (0.54 against 0.49 ms/step): stream priority does not keep the second launch's workgroups off the
+        # CUs, the U x U launch finishes later and chol(C), which is on the critical path, starts later.
+        dev = getattr(engine, "device", None)
+        self.side_gram = (isinstance(dev, torch.device) and dev.type == "cuda" and
+                          os.environ.get("CESX_SIDE_GRAM", "0") != "0")
         self._cs = None
         self._moms, self._mom_idx = None, 0
         # one-rank rehearsal of the multi-GPU path: issue the collectives even though world == 1
@@ -88,12 +94,14 @@ class ShardedUpdate:
         self._mom_idx ^= 1
         return self._moms[self._mom_idx]
 
-    def begin(self, prm, U, G, recenter=False):
+    def begin(self, prm, U, G, recenter=False, noise_step=None):
         """First half of a step: everything that does not need the pseudo-time of the previous
         step -- the moments, their all-reduce and chol(C).  Only ``prm.update`` is read, so a
         driver may enqueue ``begin`` of step i+1 BEFORE it reads the result of step i: the
         host's read (ces/calibrate.py:387 tests ``t`` every iteration) then overlaps the Gram
-        of the next step instead of idling the GPU.
+        of the next step instead of idling the GPU.  ``noise_step``: Philox step index of the
+        update this ``begin`` belongs to -- its noise block is then drawn ahead on the engine's
+        background stream (cesx_prefetch_noise) instead of inside the update kernel.
 
         Whether the head all-reduce runs on the side stream is decided ONCE, at construction
         (``overlap_comm``): a collective that may already have been enqueued is never retried,
@@ -102,20 +110,25 @@ class ShardedUpdate:
         eng = self.engine
         if recenter or not self._recentered:
             self.recenter(U, G)
+        if noise_step is not None and hasattr(eng, "prefetch_noise"):
+            eng.prefetch_noise(noise_step)
         nuu = eng.moments_uu_len()
-        mom = eng.moments_uu(U, G, out=self._moment_buffer())
-        if self.overlap_comm:
+        mom = self._moment_buffer()
+        if self.overlap_comm or self.side_gram:
             cur = torch.cuda.current_stream(eng.device)
             if self._cs is None:        # the engine's own side stream: no third stream to share a hardware queue
                 self._cs = eng.side_stream() if hasattr(eng, "side_stream") else torch.cuda.Stream(device=eng.device)
-            self._cs.wait_stream(cur)                # the head of the buffer is complete
-            # the rest of the Gram goes to the main stream FIRST: it does not depend on the collective,
-            # and a Gram launch dispatched behind the one-workgroup Cholesky waits for it
+            self._cs.wait_stream(cur)                # U, G and the centring shift are ready
+            # side stream (high priority): U x U Gram -> all-reduce of the head -> C, L = chol(C);
+            # main stream, at the same time: the rest of the Gram (it does not depend on the collective)
+            with torch.cuda.stream(self._cs):
+                eng.moments_uu(U, G, out=mom)
             eng.moments_rest(U, G, mom)
             with torch.cuda.stream(self._cs):
-                self._all_reduce(mom[:nuu])          # N, sum(u - s), S_aa: all chol(C) needs ...
-                eng.chol_async(prm, mom)             # ... C, L = chol(C): behind the collective on the side stream
+                self._all_reduce(mom[:nuu])          # N, sum(u - s), S_aa: all chol(C) needs
+                eng.chol_async(prm, mom)
         else:
+            eng.moments_uu(U, G, out=mom)
             self._all_reduce(mom[:nuu])
             eng.chol_async(prm, mom)                 # C, then L = chol(C) on the side stream ...
             eng.moments_rest(U, G, mom)              # ... beside the rest of the Gram
@@ -134,7 +147,7 @@ class ShardedUpdate:
 
     def step(self, prm, U, G, xi=None, out=None, recenter=False):
         """moments -> all-reduce -> apply on this rank's shard.  Returns U_next."""
-        self.begin(prm, U, G, recenter=recenter)
+        self.begin(prm, U, G, recenter=recenter, noise_step=int(prm.step_index) if xi is None else None)
         return self.finish(prm, U, G, xi=xi, out=out)
 
     def result(self):
@@ -192,8 +205,9 @@ class ShardedSampler:
         pipelined = hasattr(model, "forward_device")
         prm0 = step_params(update=update, T=self.T)
         G = self._forward(model, U)
+        draw = xis is None                     # on-device noise: drawn ahead of each update
         if pipelined:
-            self.sh.begin(prm0, U, G, recenter=True)
+            self.sh.begin(prm0, U, G, recenter=True, noise_step=self._steps_done if draw else None)
         for i in range(self.T):
             t = m["t"]
             prm = step_params(update=update, time_step=kwargs.get("time_step"), first_step=(i == 0 and not t),
@@ -206,7 +220,7 @@ class ShardedSampler:
                 U = self.sh.finish(prm, U, G, xi=xi)
                 if i + 1 < self.T:
                     G = self._forward(model, U)
-                    self.sh.begin(prm0, U, G)
+                    self.sh.begin(prm0, U, G, noise_step=self._steps_done if draw else None)
             else:
                 U = self.sh.step(prm, U, G, xi=xi, recenter=(i == 0))
             res = self.sh.result()

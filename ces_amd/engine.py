@@ -24,7 +24,8 @@ EXPORTS = ("cesx_abi_version", "cesx_create", "cesx_destroy", "cesx_last_error",
            "cesx_step", "cesx_result", "cesx_moments_len", "cesx_colsum", "cesx_set_shift",
            "cesx_moments", "cesx_apply", "cesx_apply_drift", "cesx_apply_finish", "cesx_draw_noise",
            "cesx_forward_lineal", "cesx_debug_dense", "cesx_profile_enable", "cesx_profile_read",
-           "cesx_moments_uu_len", "cesx_moments_uu", "cesx_chol_async", "cesx_moments_rest", "cesx_side_stream")
+           "cesx_moments_uu_len", "cesx_moments_uu", "cesx_chol_async", "cesx_moments_rest", "cesx_side_stream",
+           "cesx_prefetch_noise")
 
 
 class Config(C.Structure):
@@ -92,6 +93,7 @@ def load_library(path=None):
     lib.cesx_apply_drift.argtypes = [vp, C.POINTER(StepParams), vp, vp, vp, vp, vp, vp]
     lib.cesx_apply_finish.argtypes = [vp, C.POINTER(StepParams), vp, vp, vp, vp, vp]
     lib.cesx_draw_noise.argtypes = [vp, u64, vp, vp]
+    lib.cesx_prefetch_noise.argtypes = [vp, u64, vp]
     lib.cesx_forward_lineal.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.cesx_debug_dense.argtypes = [vp, dp, dp, dp, dp, dp, dp]
     lib.cesx_profile_enable.argtypes = [vp, i32]
@@ -350,6 +352,11 @@ class Engine:
         with torch.cuda.device(self.device):
             self._check(self.lib.cesx_draw_noise(self._h, int(step_index), xi.data_ptr(), self._stream()))
         return xi
+
+    def prefetch_noise(self, step_index):
+        """Draw the noise block of ``step_index`` ahead of its update (cesx_prefetch_noise)."""
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cesx_prefetch_noise(self._h, int(step_index), self._stream()))
 
     def forward_lineal(self, A, U, b=None, out=None):
         A = torch.as_tensor(A).to(device=self.device, dtype=self.torch_dtype).contiguous()

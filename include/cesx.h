@@ -214,6 +214,15 @@ int cesx_apply_finish(cesx_handle h, const cesx_step_params* prm, const double* 
    (p x J_local).  For tests of the generator. */
 int cesx_draw_noise(cesx_handle h, uint64_t step_index, void* xi_dev, void* stream);
 
+/* Optional: draw the noise block of step `step_index` AHEAD of the update, into an engine-owned
+   buffer, on a low-priority background stream (it fills the CUs the Gram launch leaves idle; the
+   f32-input MFMA shares the SIMD's vector lanes, so Philox + Box-Muller inside the update kernel
+   cost it matrix-pipe cycles).  A later cesx_apply / cesx_apply_finish / cesx_step with
+   xi_dev == NULL and the same prm->step_index reads that block (same numbers as the in-kernel
+   generator, np.random.normal's role at ces/calibrate.py:447/:488/:527); any other step index
+   falls back to drawing inside the update kernel.  cesx_step calls it itself. */
+int cesx_prefetch_noise(cesx_handle h, uint64_t step_index, void* stream);
+
 /* ---- forward-map hook --------------------------- */
 
 /* G = A U + b for the linear map utils.lineal (ces/utils.py:25-31) evaluated on
