@@ -232,7 +232,10 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
     if (ldl == 0) ldl = np;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ldt = np + 4;
-    double* PnT = reinterpret_cast<double*>(smem);        // [2][8][ldt]
+    double* PnT = reinterpret_cast<double*>(smem);        // [2][8][ldt]  the panel (k-major), double buffered
+    double* NnT = PnT + 2 * QNB * ldt;                    // [8][ldt]     its negative: the A operand of the trailing update
+    double* ZnT = NnT + QNB * ldt;                        // [8][ldt]     zeros: rows that have no entry in the panel read these
+    for (int i = threadIdx.x; i < QNB * ldt; i += PRT) ZnT[i] = 0.0;
     const int tid = threadIdx.x, lane = tid & 63, i8 = lane & 7;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = np / 16;
@@ -243,11 +246,17 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
     int tR[SLOTS], tC[SLOTS];
 #pragma clang loop unroll(full)
     for (int s = 0; s < SLOTS; ++s) {
-        const int q = wave + 8 * s;                       // tiles dealt round-robin to the 8 waves
-        int R = (int)((sqrt(8.0 * q + 1.0) - 1.0) * 0.5);
-        while ((R + 1) * (R + 2) / 2 <= q) ++R;
-        while (R * (R + 1) / 2 > q) --R;
-        const int Cc = q - R * (R + 1) / 2;
+        // Tiles are dealt round-robin to the 8 waves in COLUMN-descending order (last tile column first,
+        // rows top to bottom inside a column).  The tiles a panel still has to update are the tile columns
+        // at or right of it, i.e. always the first N_act tiles of this order: every wave's share is a prefix
+        // of its slots (balanced to within one tile at every panel) and the trailing update below runs as a
+        // software-pipelined loop over that prefix instead of a branch per slot.
+        const int q = wave + 8 * s;
+        int m_ = (int)((sqrt(8.0 * q + 1.0) - 1.0) * 0.5);            // columns to the right of this tile's column
+        while ((m_ + 1) * (m_ + 2) / 2 <= q) ++m_;
+        while (m_ * (m_ + 1) / 2 > q) --m_;
+        const int Cc = T - 1 - m_;
+        const int R = Cc + (q - m_ * (m_ + 1) / 2);
         const bool on = q < ntile;
         tR[s] = __builtin_amdgcn_readfirstlane(on ? R : -1);      // wave-uniform -> SGPRs
         tC[s] = __builtin_amdgcn_readfirstlane(on ? Cc : 0);
@@ -261,7 +270,8 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
         }
     }
     long long tph[5] = {0, 0, 0, 0, 0}, tl = clock64();
-#define PH(i) if (dbg) { const long long t_ = clock64(); tph[i] += t_ - tl; tl = t_; }
+#define PH(i) if (dbg) { const long long t_ = clock64(); tph[i] += t_ - tl; if (tid == 0 && (i) >= 2) dbg[8 + (kb_dbg / QNB) * 2 + ((i) == 4)] = t_ - tl; tl = t_; }
+    int kb_dbg = 0;
     // columns kbn .. kbn+7 of tile s -> buf[col - kbn][row - kbn] (rows at or below the panel's diagonal block)
     // (no per-lane branches: elements outside the panel are written to the 4 pad rows of column 0)
     auto publish = [&](int s, int kbn, double* buf) {
@@ -284,6 +294,7 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
         double* cur = PnT + ((kb / QNB) & 1) * QNB * ldt;
         double* nxt = PnT + (((kb / QNB) & 1) ^ 1) * QNB * ldt;
         const int m = np - kb;
+        kb_dbg = kb;
         // (b) 8 x 8 diagonal block, redundantly per wave
         double d[QNB];
 #pragma clang loop unroll(full)
@@ -319,6 +330,7 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
 #pragma clang loop unroll(full)
             for (int j = 0; j < QNB; ++j) {
                 cur[j * ldt + r] = x[j];
+                NnT[j * ldt + r] = -x[j];
                 dst[j] = x[j];
             }
         }
@@ -337,22 +349,33 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
         //     tile: A = -L21 rows of the tile, B = L21 rows of the tile's columns); the tile
         //     that holds the next panel's columns is updated too, then published
         const int kn = kb + QNB;                          // first column of the next panel
+        // active tiles = tile columns >= kn / 16: the first N_act tiles of the dealing order
+        const int tact = T - kn / 16;
+        const int n_act = tact > 0 ? tact * (tact + 1) / 2 : 0;
+        const int nact = n_act > wave ? (n_act - wave + 7) / 8 : 0;       // ... of which this wave holds the first nact slots
+        // operands of one tile: A = -L21 rows of the tile (from the negated image), B = L21 rows of the tile's
+        // columns.  Rows / columns left of the panel (finished) have no panel entry: they read the zero image.
+        // The select is on the ADDRESS, so nothing depends on the loaded values until the MFMA: the reads of
+        // tile s+1 stay in flight behind the MFMAs of tile s.
+        struct Ops { double av[2], bv[2]; };
+        auto load_ops = [&](Ops& o, int s_) {
+            const int ra = tR[s_] * 16 - kb + lc, rb = tC[s_] * 16 - kb + lc;
+            const double* pa = (ra >= 0 ? NnT + ra : ZnT) + lr * ldt;
+            const double* pb = (rb >= 0 ? cur + rb : ZnT) + lr * ldt;
+#pragma clang loop unroll(full)
+            for (int h = 0; h < 2; ++h) { o.av[h] = pa[4 * h * ldt]; o.bv[h] = pb[4 * h * ldt]; }
+        };
+        Ops o0, o1;
+        if (nact > 0) load_ops(o0, 0);
 #pragma clang loop unroll(full)
         for (int s = 0; s < SLOTS; ++s) {
-            if (tR[s] >= 0 && tC[s] * 16 + 15 >= kn) {
-                // A operand: row index = lane & 15.  Rows / columns of the tile left of the panel
-                // (finished columns) have no panel entry: load from a clamped address and select 0
-                // afterwards, so that all four loads issue back to back (no exec-mask branches)
-                const int ra = tR[s] * 16 - kb + lc, rb = tC[s] * 16 - kb + lc;
-                const bool aok = ra >= 0, bok = rb >= 0;
-                const double* pa = cur + (aok ? ra : 0);
-                const double* pb = cur + (bok ? rb : 0);
-                double av[2], bv[2];
-#pragma clang loop unroll(full)
-                for (int h = 0; h < 2; ++h) { av[h] = pa[(4 * h + lr) * ldt]; bv[h] = pb[(4 * h + lr) * ldt]; }
+            if (s < nact) {
+                Ops& oc = (s & 1) ? o1 : o0;
+                Ops& on_ = (s & 1) ? o0 : o1;
+                if (s + 1 < SLOTS) { if (s + 1 < nact) load_ops(on_, s + 1); }     // next tile's LDS reads behind these MFMAs
 #pragma clang loop unroll(full)
                 for (int h = 0; h < 2; ++h)
-                    Pt[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(aok ? -av[h] : 0.0, bok ? bv[h] : 0.0, Pt[s], 0, 0, 0);
+                    Pt[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(oc.av[h], oc.bv[h], Pt[s], 0, 0, 0);
                 if (kn < np && tC[s] == kn / 16) publish(s, kn, nxt);
             }
         }
@@ -721,7 +744,7 @@ static int gemm(Engine& e, hipStream_t s, int m, int n, int k, double alpha, con
 
 template <int SLOTS>
 static int potrf_reg_launch(Engine& e, hipStream_t s, int n, int np, const double* A, double* Lp, int lda = 0, int ldl = 0) {
-    const size_t lds = (size_t)2 * QNB * (np + 4) * 8;
+    const size_t lds = (size_t)4 * QNB * (np + 4) * 8;       // panel x 2, its negative, zeros
     CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_reg_kernel<SLOTS>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(potrf_reg_kernel<SLOTS>, dim3(1), dim3(PRT), lds, s, n, np, A, Lp, &e.d_scal->status, (long long*)nullptr,

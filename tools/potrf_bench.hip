@@ -1,6 +1,7 @@
 // dev tool: time potrf_reg_kernel alone.  hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/potrf_bench.hip -o tools/potrf_bench
 #include "../ces_amd/csrc/kernels_dense.hip"
 #include <cstdio>
+namespace cesx { int launch_noise(Engine&, uint64_t, void*, hipStream_t) { return 0; } }
 #ifndef SLOTS
 #define SLOTS 17
 #endif
@@ -16,10 +17,10 @@ int main(int argc, char** argv) {
     double *dA, *dL, *dLp; int* st;
     hipMalloc(&dA, n*n*8); hipMalloc(&dL, n*n*8); hipMalloc(&dLp, np*np*8); hipMalloc(&st, 4);
     hipMemcpy(dA, A.data(), n*n*8, hipMemcpyHostToDevice); hipMemset(st, 0, 4);
-    size_t lds = (size_t)2 * 8 * (np + 4) * 8;
+    size_t lds = (size_t)4 * 8 * (np + 4) * 8;
     auto kern = cesx::potrf_reg_kernel<SLOTS>;
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    long long* dbg; hipMalloc(&dbg, 64);
+    long long* dbg; hipMalloc(&dbg, 8 * 80); hipMemset(dbg, 0, 8 * 80);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(kern, dim3(1), dim3(cesx::PRT), lds, 0, n, np, dA, dLp, st, (long long*)nullptr, 0, 0);
     hipEventRecord(e0);
@@ -31,6 +32,7 @@ int main(int argc, char** argv) {
     int hst; hipMemcpy(&hst, st, 4, hipMemcpyDeviceToHost);
     hipLaunchKernelGGL(kern, dim3(1), dim3(cesx::PRT), lds, 0, n, np, dA, dLp, st, dbg, 0, 0);
     long long hd[5]; hipMemcpy(hd, dbg, 40, hipMemcpyDeviceToHost);
+    { long long pp[72]; hipMemcpy(pp, dbg + 8, 72 * 8, hipMemcpyDeviceToHost); printf("per panel (factor, trailing) cycles:"); for (int k = 0; k < np / 8; k += 1) printf(" %lld/%lld", pp[2 * k], pp[2 * k + 1]); printf("\n"); }
     printf("cycles (wave 0): init %lld | factor %lld barrier %lld | trailing %lld barrier %lld\n", hd[0], hd[1], hd[2], hd[3], hd[4]);
     printf("n=%d potrf %.1f us/call, max |LL^T - A| = %.3e, status %d\n", n, ms * 100.0, err, hst);
     return 0;
