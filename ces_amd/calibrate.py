@@ -14,7 +14,18 @@ Build-only extras (not in the reference):
                                      run reproduces the reference's trajectory (default)
                          'device' -- draw xi on the GPU (Philox4x32-10)
   kwarg ``xi=``          inject the noise block of one update
+  kwarg ``xis=``         (``run``) inject the noise blocks of a whole run, one (p, J) block per iteration
+  ``self.trace_stride``  (``run``, device-resident loop) keep every k-th iterate in ``Uall`` / ``Gall``
+                         (default 1 = every iterate, the reference's behaviour; the first and the final
+                         ensemble are always kept) -- at J = 65 536, p = 256 a full trace is 268 MB of
+                         PCIe traffic and fresh host memory per iteration
   ``run_eks``            alias of ``sampling.run`` (BASELINE.json's name for it)
+
+``sampling.run`` keeps the ensemble ON THE DEVICE for the whole loop when it can: the model offers the
+build-only hook ``forward_device(engine, U_dev)`` (``ces_amd.utils.lineal`` does) and the noise does not
+have to come from numpy's global stream (``self.noise == 'device'`` or ``xis=`` given).  Per iteration
+nothing crosses PCIe but the step's scalars (and the trace, if kept).  Otherwise the reference's data flow
+is kept -- host forward map (``G_ens``), float64 numpy arrays into and out of every update.
 """
 import multiprocessing
 import os
@@ -206,11 +217,21 @@ class sampling(enka):
         xi = kwargs.get("xi", None)
         if xi is None and self.noise == "numpy":
             xi = np.random.normal(0, 1, [self.p, self.J])         # ces/calibrate.py:447/:488/:527
+        # The engine's centring shift follows the ensemble it produced (K2 predicts the next mean): a fresh
+        # pass over (U, G) for the shift is only needed for an ensemble the engine has not seen
+        chained = U0 is getattr(self, "_last_Uk", None) and eng is getattr(self, "_last_engine", None)
         try:
-            U_next = eng.step(prm, U0, Geval, xi=xi, recenter=True)
+            U_next = eng.step(prm, U0, Geval, xi=xi, recenter=not chained)
             res = eng.result()
         finally:
             self._step_counter += 1
+        self._append_result(rule, res, kwargs)
+        out = eng.to_host(U_next) if isinstance(U0, np.ndarray) else U_next
+        self._last_Uk, self._last_engine = out, eng
+        return out
+
+    def _append_result(self, rule, res, kwargs):
+        """Book-keeping of one update on the object (ces/calibrate.py:432-435, :262-265, :250)."""
         m = self.metrics
         m["self-bias"].append(res.self_bias)
         m["bias"].append(res.bias)
@@ -220,9 +241,6 @@ class sampling(enka):
             self.radspec.append(res.radspec)
         m["t"].append(res.t_new)
         self._last_hk = res.hk
-        if isinstance(U0, np.ndarray):
-            return eng.to_host(U_next)
-        return U_next
 
     # -- reference API ---------------------------------------------------
     def timestep_method(self, D, Geval, y_obs, Gamma, Jnoise, **kwargs):
@@ -270,6 +288,66 @@ class sampling(enka):
         self.update_rule = "eks_update_aldi"
         return self._device_update("aldi_constant", y_obs, U0, Geval, Gamma, **kwargs)
 
+    def _device_loop_ok(self, model, save_online, kwargs):
+        return (getattr(model, "type", None) == "map" and hasattr(model, "forward_device") and not save_online
+                and (self.noise == "device" or kwargs.get("xis", None) is not None)
+                and kwargs.get("update", "aldi") in _engine.UPDATES
+                and kwargs.get("time_step", None) in _engine.TIME_STEPS and kwargs.get("time_step", None) != "adaptive"
+                and getattr(self, "device_loop", True))
+
+    def _run_device(self, y_obs, U0, model, Gamma, trace, **kwargs):
+        """``run`` with the ensemble resident in HBM (same iteration structure as ces/calibrate.py:341-408):
+        forward map through ``model.forward_device``, update through the split entry points of the C ABI,
+        software-pipelined like ``ces_amd.dist.ShardedSampler.run`` -- the first half of iteration i+1 (forward
+        map, moments, chol(C)) is enqueued BEFORE the host reads t of iteration i for the ``t_tol`` test (:387);
+        if the run stops there that work is discarded."""
+        from .dist import ShardedUpdate
+        rule = kwargs.get("update", "aldi")
+        eng = self._get_engine()
+        eng.set_problem(y_obs, Gamma, self.mu, self.sigma, self.ustar)
+        sh = ShardedUpdate(eng)
+        stride = max(1, int(getattr(self, "trace_stride", 1)))
+        xis = kwargs.get("xis", None)
+        self.update_rule = {"eks": "eks_update", "aldi": "eks_update_linear", "aldi_constant": "eks_update_aldi"}[rule]
+        prm0 = _engine.step_params(update=rule, T=self.T)
+        U = eng.to_device(U0, self.p, "U")
+        G = model.forward_device(eng, U)
+        sh.begin(prm0, U, G, recenter=True, noise_step=None if xis is not None else self._step_counter)
+        G_next = None
+        for i in range(self.T):
+            if trace and (i % stride == 0):                        # :356-358 (a copy: the device buffers are reused)
+                self.Uall.append(U0 if i == 0 and isinstance(U0, np.ndarray) else eng.to_host(U))
+                self.Gall.append(eng.to_host(G))
+            t = self.metrics["t"]
+            first = len(t) == 0                                    # = len(self.Uall) == 1 of :262 / :520 on a full trace
+            prm = _engine.step_params(update=rule, time_step=kwargs.get("time_step", None), first_step=first,
+                                      t_len=len(t), t_last=t[-1] if t else 0.0, delta_t=kwargs.get("delta_t", None),
+                                      spinup=kwargs.get("spinup", 4.0), switch=kwargs.get("switch", 1.0),
+                                      step_index=self._step_counter, T=self.T)
+            self._step_counter += 1
+            xi = None if xis is None else eng.to_device(xis[i], self.p, "xi")
+            U_new = sh.finish(prm, U, G, xi=xi)
+            G_next = None
+            if i + 1 < self.T:                                     # first half of the next iteration, ahead of the read
+                G_next = model.forward_device(eng, U_new)
+                sh.begin(prm0, U_new, G_next, noise_step=None if xis is not None else self._step_counter)
+            res = sh.result()
+            self._append_result(rule, res, kwargs)
+            U, G = U_new, G_next
+            if self.metrics["t"][-1] > kwargs.get("t_tol", 2.0):   # :387-388
+                break
+        if G is None:                                              # :390-398 one more evaluation of the final ensemble
+            G = model.forward_device(eng, U)
+        self.Ustar = eng.to_host(U)
+        Gfinal = eng.to_host(G)
+        if trace:                                                  # :400-405
+            self.Uall.append(self.Ustar)
+            self.Gall.append(Gfinal)
+            self.Uall = np.asarray(self.Uall)
+            self.Gall = np.array(self.Gall)
+        self.Gstar = Gfinal[:self.n_obs, :]
+        self.Ustar_device, self.Gstar_device = U, G                # build-only: the final ensemble without the D2H copy
+
     def run(self, y_obs, U0, model, Gamma, Jnoise, save_online=False, trace=True, **kwargs):
         """Driver loop, ces/calibrate.py:270-416."""
         getattr(model, "type")                                     # :294-297
@@ -293,6 +371,12 @@ class sampling(enka):
             else:
                 self.W0 = np.tile(wt, self.J).reshape(self.J, model.n_state).T
         self._ensure_metrics()                                     # :329-339
+        if self._device_loop_ok(model, save_online, kwargs):
+            self._get_engine()                                     # (creates self._step_counter)
+            self._run_device(y_obs, U0, model, Gamma, trace, **kwargs)
+            tail = "-" + str(self.nexp).zfill(2) if hasattr(self, "nexp") else ""
+            self.online_path = self.directory + "/ensembles/" + model.model_name + "-" + str(self.J).zfill(4) + tail + "/"
+            return
 
         for i in tqdm(range(self.T), desc="EKS iterations (%s):" % str(self.J), position=1,
                       disable=self.mute_bar):
@@ -313,12 +397,25 @@ class sampling(enka):
                 self.Uall.append(U0)
                 self.Gall.append(Geval)
             Geval = Geval[:self.n_obs, :]
+            if kwargs.get("xis", None) is not None:                # build-only: injected noise blocks
+                kwargs = dict(kwargs, xi=kwargs["xis"][i])
+            U_prev = U0
             if self.__update == "eks":                             # :364-369
                 U0 = self.eks_update(y_obs, U0, Geval, Gamma, i, **kwargs)
             elif self.__update == "aldi":
                 U0 = self.eks_update_aldi(y_obs, U0, Geval, Gamma, i, **kwargs)
             elif self.__update == "aldi_constant":
                 U0 = self.eks_update_aldi_constant(y_obs, U0, Geval, Gamma, i, **kwargs)
+            if not trace and hasattr(self, "_engine"):
+                # nothing else holds the previous iterate or this iteration's forward-map output (no trace; the
+                # caller's own U0 is iteration 0): release their pages on the engine's helper thread, not here
+                # (unmapping 134 MB costs ~8 ms on the calling thread)
+                G_base = Geval.base if isinstance(Geval, np.ndarray) and Geval.base is not None else Geval
+                drop = [G_base] + ([U_prev] if i > 0 and U_prev is not U0 else [])
+                del Geval, G_base
+                self._engine.discard_host(*drop)
+                del drop
+            del U_prev
             if save_online:                                        # :371-385
                 tag = model.model_name + "-eks-" + str(model.l_window).zfill(3) + "-" + str(self.J).zfill(4)
                 if hasattr(self, "nexp"):

@@ -231,14 +231,92 @@ class Engine:
             raise ValueError("expected shape (%d, %d), got %s" % (rows, self.J, tuple(t.shape)))
         return t
 
+    class _HostOutPool:
+        """Fresh float64 result arrays, page-faulted AHEAD of use by a helper thread.
+
+        The reference returns a newly allocated (p, J) float64 array from every update
+        (ces/calibrate.py:443/:484/:525 build ``Uk`` from temporaries) and the trace keeps it alive, so
+        the drop-in must hand out fresh memory too -- and at J = 65 536, p = 256 the first touch of 134 MB
+        of new pages costs 12-20 ms, more than everything else in the call together.  The pool keeps a
+        few arrays of the current shape allocated and touched by a background thread; ``get`` is then a
+        queue pop."""
+
+        def __init__(self, depth=2):
+            import queue
+            import threading
+            self.depth, self.shape = depth, None
+            self.q = queue.Queue()
+            self.req = queue.Queue()
+            self.th = threading.Thread(target=self._work, daemon=True)
+            self.th.start()
+
+        _touch_pool = None
+
+        @classmethod
+        def _fresh(cls, shape, threads=8):
+            a = np.empty(shape, dtype=np.float64)
+            flat = a.reshape(-1)
+            n = flat.size
+            if n < (1 << 22):
+                flat[::512] = 0.0                   # one write per 4 KiB page: the kernel maps (and zeroes) it now
+                return a
+            # the kernel zeroes every new page (~10 GB/s per faulting thread): touch slices from several threads
+            if cls._touch_pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                cls._touch_pool = ThreadPoolExecutor(max_workers=threads, thread_name_prefix="cesx-prefault")
+            step = (n // threads + 511) // 512 * 512
+
+            def touch(k):
+                flat[k * step:min(n, (k + 1) * step):512] = 0.0
+            list(cls._touch_pool.map(touch, range((n + step - 1) // step)))
+            return a
+
+        def _work(self):
+            while True:
+                shape = self.req.get()
+                if shape is None:
+                    return
+                if isinstance(shape, list):          # arrays handed over by discard(): dropped (unmapped) HERE
+                    del shape[:]
+                    continue
+                self.q.put((shape, self._fresh(shape)))
+
+        def discard(self, arrays):
+            """Drop large host arrays on the helper thread: unmapping 134 MB takes ~8 ms on the caller's
+            thread otherwise (the caller must not keep a reference of its own)."""
+            if self.th.is_alive():
+                self.req.put(list(arrays))
+
+        def get(self, shape):
+            shape = tuple(int(x) for x in shape)
+            if shape != self.shape:                 # new shape: what was prepared for the old one is skipped below
+                self.shape = shape
+                for _ in range(self.depth):
+                    self.req.put(shape)
+            if not self.th.is_alive():
+                return self._fresh(shape)
+            while True:
+                got_shape, a = self.q.get()
+                if got_shape == shape:
+                    self.req.put(shape)             # keep the pool at its depth
+                    return a
+
     def to_host(self, t):
-        """Device tensor of the engine dtype -> new float64 numpy array (the reference's dtype)."""
+        """Device tensor of the engine dtype -> NEW float64 numpy array (the reference's dtype)."""
         pin = self._pinned("out", t.shape) if t.numel() >= self._PIN_MIN else None
         if pin is None:
             return t.to("cpu", dtype=torch.float64).numpy()
         pin.copy_(t)                                       # D2H into pinned memory, blocking
+        pool = self.__dict__.setdefault("_out_pool", self._HostOutPool())
+        out = pool.get(tuple(t.shape))
         with self._HostThreads(self.copy_threads):
-            return (pin.to(torch.float64) if pin.dtype != torch.float64 else pin.clone()).numpy()
+            torch.from_numpy(out).copy_(pin)               # widen into pages that are already mapped
+        return out
+
+    def discard_host(self, *arrays):
+        """Hand large host arrays the caller no longer needs to the helper thread for release."""
+        pool = self.__dict__.setdefault("_out_pool", self._HostOutPool())
+        pool.discard([a for a in arrays if isinstance(a, np.ndarray) and a.nbytes >= (1 << 22)])
 
     def empty(self, rows):
         return torch.empty((rows, self.J), dtype=self.torch_dtype, device=self.device)

@@ -120,6 +120,73 @@ def test_trajectory_c1_drop_in(eng_mod, manifest, golden_traj, update):
     assert np.array_equal(eks.Ustar, eks.Uall[-1]) and eks.Gstar.shape == (info["n_obs"], info["J"])
 
 
+@pytest.mark.parametrize("shape,update,dtype,tol", [((2, 10, 100, 30), "aldi", "float64", 1e-9), ((2, 10, 100, 30), "eks", "float64", 1e-9),
+                                                    ((2, 10, 100, 12), "aldi_constant", "float64", 1e-9),
+                                                    ((256, 256, 4096, 5), "aldi", "float64", 1e-8),
+                                                    ((256, 256, 4096, 5), "aldi", "float32", 2e-4)])
+def test_device_resident_run_equals_host_array_run(eng_mod, shape, update, dtype, tol):
+    """``sampling.run`` with the ensemble resident on the device (model.forward_device + injected / device noise)
+    against the SAME class driven the reference's way (host forward map through G_ens, float64 numpy arrays in and
+    out of every update, ces/calibrate.py:341-369), same injected noise blocks: same traces, metrics, final state.
+    C1 (BASELINE.json configs[0]) and a p = n_obs = 256 problem."""
+    from ces_amd.calibrate import sampling
+    from ces_amd.utils import lineal
+    p, n, J, T = shape
+    rng = np.random.default_rng(17)
+    A = rng.standard_normal((n, p)) / np.sqrt(p)
+    ustar = rng.standard_normal((p, 1))
+    y = (A @ ustar).ravel() + 0.1 * rng.standard_normal(n)
+    Gamma = 0.1 * np.eye(n)
+    U0 = rng.standard_normal((p, J))
+    xis = rng.standard_normal((T, p, J))
+    runs = []
+    for device_loop in (False, True):
+        eks = sampling(p=p, n_obs=n, J=J)
+        eks.T, eks.ustar, eks.mu, eks.sigma = T, ustar, np.zeros((p, 1)), 100.0 * np.eye(p)
+        eks.engine_dtype, eks.device_loop = dtype, device_loop
+        model = lineal(A)
+        if not device_loop:
+            # the reference's G_ens calls the model once per particle (65 536 Python calls at J = 65 536): evaluate
+            # the same map for the whole ensemble at once on the host for the larger case
+            eks.G_ens = lambda theta, m: A @ theta
+        eks.run(y, np.copy(U0), model, Gamma, np.linalg.cholesky(Gamma), update=update, t_tol=1e9, xis=xis)
+        runs.append(eks)
+    a, b = runs
+    assert b.Uall.shape == a.Uall.shape == (T + 1, p, J) and b.Gall.shape == a.Gall.shape
+    assert rel_err(b.Uall, a.Uall) < tol and rel_err(b.Gall, a.Gall) < tol
+    assert rel_err(b.Ustar, a.Ustar) < tol and rel_err(b.Gstar, a.Gstar) < tol
+    for k in ("self-bias", "self-bias-data", "bias-data", "bias", "t"):
+        assert len(b.metrics[k]) == T and np.allclose(b.metrics[k], a.metrics[k], rtol=max(tol, 1e-9) * 10), k
+    assert b.update_rule == a.update_rule and b.online_path == a.online_path
+
+
+def test_device_resident_run_trace_stride_and_resume(eng_mod):
+    """Build-only ``trace_stride``: every k-th iterate (plus the first and the final ensemble) is copied to the
+    host; metrics are complete either way; a second ``run`` resumes (ces/calibrate.py:307-310) with fresh noise."""
+    from ces_amd.calibrate import sampling
+    from ces_amd.utils import lineal
+    rng = np.random.default_rng(3)
+    p, n, J, T = 8, 6, 512, 7
+    A = rng.standard_normal((n, p))
+    eks = sampling(p=p, n_obs=n, J=J)
+    eks.T, eks.ustar, eks.mu, eks.sigma = T, np.ones((p, 1)), np.zeros((p, 1)), 10.0 * np.eye(p)
+    eks.noise, eks.trace_stride = "device", 3
+    y = A @ np.ones(p)
+    eks.run(y, rng.standard_normal((p, J)), lineal(A), 0.1 * np.eye(n), None, t_tol=1e9)
+    assert eks.Uall.shape == (3 + 1, p, J)                    # iterates 0, 3, 6 and the final ensemble
+    assert len(eks.metrics["t"]) == T and np.all(np.diff(eks.metrics["t"]) > 0)
+    assert np.array_equal(eks.Ustar, eks.Uall[-1]) and eks.Ustar_device.shape == (p, J)
+    first = eks.Ustar.copy()
+    eks.run(y, eks.Ustar, lineal(A), 0.1 * np.eye(n), None, t_tol=1e9)
+    assert len(eks.metrics["t"]) == 2 * T and eks.metrics["t"][T] > eks.metrics["t"][T - 1]
+    assert eks.Uall.shape[0] == 4 + 4 and not np.allclose(eks.Ustar, first)
+    # trace=False: nothing but the final ensemble comes back
+    eks2 = sampling(p=p, n_obs=n, J=J)
+    eks2.T, eks2.ustar, eks2.mu, eks2.sigma, eks2.noise = T, np.ones((p, 1)), np.zeros((p, 1)), 10.0 * np.eye(p), "device"
+    eks2.run(y, rng.standard_normal((p, J)), lineal(A), 0.1 * np.eye(n), None, trace=False, t_tol=1e9)
+    assert not hasattr(eks2, "Uall") and eks2.Ustar.shape == (p, J) and len(eks2.metrics["t"]) == T
+
+
 def _synthetic(p, n, J, seed, dense=False):
     rng = np.random.default_rng(seed)
     A = rng.standard_normal((n, p)) / np.sqrt(p)
