@@ -2,7 +2,9 @@
 """Condense rocprofv3 output directories (copied back under gpurun_out/) into the small summaries
 that are committed under profiles/.
 
-    python tools/prof_summary.py TAG gpurun_out/prof_k [gpurun_out/prof_FETCH_SIZE ...]
+    python tools/prof_summary.py TAG[:CONFIG] gpurun_out/prof_k [gpurun_out/prof_FETCH_SIZE ...]
+
+CONFIG (default C2) is the key under which the HBM bytes go into profiles/traffic.json (bench.py --config).
 
   * <prof_k>   : rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py ...
                  -> profiles/<TAG>_kernel_stats.csv (the tool's own stats table) and
@@ -30,6 +32,8 @@ def short(name):
 
 def main():
     tag, kdir, pmc_dirs = sys.argv[1], sys.argv[2], sys.argv[3:]
+    tag, _, config = tag.partition(":")
+    config = config or "C2"
     out = os.path.join(ROOT, "profiles")
     stats = sorted(glob.glob(os.path.join(kdir, "*", "*_kernel_stats.csv")))
     if stats:
@@ -40,14 +44,15 @@ def main():
         rows.sort(key=lambda r: int(r["Start_Timestamp"]))
         # a step ends with metric_final_kernel; show the last complete one plus the next step's first launch
         last = [i for i, r in enumerate(rows) if "metric_final_kernel" in r["Kernel_Name"]]
-        i0, i1 = last[-3] + 1, min(last[-2] + 1, len(rows) - 1)
+        i0, i1 = last[-3] + 1, min(last[-2] + 2, len(rows) - 1)
         t0 = int(rows[i0]["Start_Timestamp"])
         with open(os.path.join(out, tag + "_kernel_trace_step.txt"), "w") as f:
             f.write("# one step of `python3 bench.py` under rocprofv3 --kernel-trace (us from the step's first launch;\n"
                     "# the profiler widens the gaps between launches: unprofiled step time is in the bench JSON)\n")
             for r in rows[i0:i1 + 1]:
                 s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-                f.write("%9.1f -> %9.1f  dur %8.1f  %s\n" % ((s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3, short(r["Kernel_Name"])))
+                f.write("%9.1f -> %9.1f  dur %8.1f  %-26s queue %s\n" % ((s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3,
+                                                                          short(r["Kernel_Name"]), r.get("Queue_Id", "?")))
     summary = {}
     for d in pmc_dirs:
         for fn in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
@@ -62,17 +67,35 @@ def main():
                 summary.setdefault(kern, {})[ctr] = dict(mean_per_launch=sum(vals) / len(vals), launches=len(vals),
                                                          median_per_launch=vals[len(vals) // 2])
     if summary:
+        summary = {k: v for k, v in summary.items() if not k.startswith("__amd") and "at::" not in k and "elementwise" not in k}
         json.dump(summary, open(os.path.join(out, tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
-        traffic = {"_note": "HBM bytes per launch at C2 = (2*FETCH_SIZE + WRITE_SIZE) KB from separate rocprofv3 --pmc "
-                            "passes (gfx950 FETCH_SIZE counts 128-B requests as 64 B, MI355X_MICROARCH.md); "
-                            "gram_kernel = sum of a step's two launches; see profiles/%s_pmc_summary.json" % tag}
+        tpath = os.path.join(out, "traffic.json")
+        try:
+            traffic = json.load(open(tpath))
+        except Exception:
+            traffic = {}
+        if "gram_kernel" in traffic:                       # round-1 flat layout -> keyed by config
+            traffic = {"C2_r01": {k: v for k, v in traffic.items() if not k.startswith("_")}}
+        traffic["_note"] = ("HBM bytes per STEP of each kernel = (2*FETCH_SIZE + WRITE_SIZE) KB summed over the kernel's launches "
+                            "of a step, from separate rocprofv3 --pmc passes (gfx950 FETCH_SIZE tallies the 128-B requests of "
+                            "wide streaming reads as 64 B, MI355X_MICROARCH.md section HBM); keyed by bench.py --config; "
+                            "gram_kernel = both Gram launches of a step (gram2_kernel = the LDS-DMA form)")
+        per_step = {}
+        steps = None
+        if "metric_final_kernel" in summary and "FETCH_SIZE" in summary["metric_final_kernel"]:
+            steps = summary["metric_final_kernel"]["FETCH_SIZE"]["launches"]      # one launch per step
         for kern, c in summary.items():
-            if "FETCH_SIZE" in c and "WRITE_SIZE" in c and kern in ("gram_kernel", "update2_kernel", "update_kernel"):
-                per = (2 * c["FETCH_SIZE"]["mean_per_launch"] + c["WRITE_SIZE"]["mean_per_launch"]) * 1024
-                traffic[kern] = int(per * (2 if kern == "gram_kernel" else 1))
-        if "update2_kernel" in traffic:
-            traffic["update_kernel"] = traffic["update2_kernel"]
-        json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1, sort_keys=True)
+            if "FETCH_SIZE" in c and "WRITE_SIZE" in c and steps:
+                tot = (2 * c["FETCH_SIZE"]["mean_per_launch"] * c["FETCH_SIZE"]["launches"]
+                       + c["WRITE_SIZE"]["mean_per_launch"] * c["WRITE_SIZE"]["launches"]) * 1024
+                per_step[kern] = int(tot / steps)
+        if per_step:
+            per_step["gram_kernel"] = per_step.get("gram2_kernel", 0) + per_step.get("gram_kernel", 0)
+            if "update2_kernel" in per_step and "update_kernel" not in per_step:
+                per_step["update_kernel"] = per_step["update2_kernel"]
+            per_step["_source"] = tag + "_pmc_summary.json"
+            traffic[config] = per_step
+        json.dump(traffic, open(tpath, "w"), indent=1, sort_keys=True)
     print("wrote", sorted(os.listdir(out)))
 
 
