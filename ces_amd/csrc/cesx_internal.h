@@ -253,7 +253,7 @@ struct Engine {
     int bk = 16, kp = 0, kn = 0, ktot = 0, rpad = 0;
     double* d_Lwork = nullptr;     // p > 256: work copy of C for the blocked Cholesky [potrf_ld(p)]^2
     void* d_W = nullptr;           // [rpad][ktot]
-    void* d_Wf = nullptr;          // fp32 engines: the same matrix in the fragment-major order of kernels_update2.hip
+    void* d_Wf = nullptr;          // the same matrix in the fragment-major order of kernels_update2.hip (fp32) / kernels_update3.hip (fp64)
     bool update_v2 = true;         // fp32 K3 through the LDS-DMA kernel (CESX_UPDATE_V1=1 switches back)
     bool gram_v2 = true;           // K1 through the LDS-DMA kernel when the shapes allow (CESX_GRAM_V1=1 switches back)
     int num_cus = 256;
@@ -325,6 +325,20 @@ __host__ __device__ inline size_t wf_index(int i, int k, int nkt) {
     const int y = i >> 8, rb = (i >> 5) & 7, li = i & 31;
     const int kt = k >> 4, kk = k & 15, m = kk >> 1, lh = kk & 1, g = m >> 2, v = m & 3;
     return ((((size_t)y * nkt + kt) * 16 + g * 8 + rb) * 64 + lh * 32 + li) * 4 + v;
+}
+// kernels_update3.hip (fp64 LDS-DMA update): CESX_OK, an error, or -1 when the launch does not qualify
+int launch_update3(Engine& e, int out_rows, const void* Wd, int ktot, const void* bias,
+                   const UpdateSrc* src, int nsrc,
+                   const void* add1, const double* c1, double c1_imm,
+                   const void* add2, const double* c2, double c2_imm,
+                   void* out, double* absmax_part, bool metrics, const UpdateOpt& opt, hipStream_t s);
+// index of W[i][k] in the fp64 fragment-major image read by update3_kernel: for every 256-row chunk y, k-tile kt
+// and 16-row block rb two pieces (sp) of 64 lanes x 2 doubles; lane (lr, li) = 16 lr + li of piece sp holds
+// W[256 y + 16 rb + li][16 kt + 4 (2 sp + e) + lr], e = 0, 1
+__host__ __device__ inline size_t wd_index(int i, int k, int nkt) {
+    const int y = i >> 8, rb = (i >> 4) & 15, li = i & 15;
+    const int kt = k >> 4, kk = k & 15, s = kk >> 2, lr = kk & 3, sp = s >> 1, e = s & 1;
+    return ((((size_t)y * nkt + kt) * 16 + rb) * 2 + sp) * 128 + (size_t)(lr * 16 + li) * 2 + e;
 }
 int launch_data_metrics(Engine& e, const void* G, hipStream_t s);   // dense Gamma: separate pass
 int launch_metric_final(Engine& e, const double* mom, bool publish, hipStream_t s);

@@ -254,7 +254,7 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
             DM(t, (size_t)std::max(pl.total_slabs, 1) * pl.tile * pl.tile * e.esz); e.gp[part].d_slabs = t;
         }
         DM(t, (size_t)e.rpad * e.ktot * e.esz); e.d_W = t;
-        if (e.cfg.dtype == CESX_F32) { DM(t, (size_t)e.rpad * e.ktot * e.esz); e.d_Wf = t; }
+        DM(t, (size_t)e.rpad * e.ktot * e.esz); e.d_Wf = t;
         DM(t, (size_t)e.rpad * e.esz); e.d_bias = t;
         DM(t, (size_t)e.rpad * e.kp * e.esz); e.d_Wfwd = t;
     }

@@ -686,7 +686,10 @@ __global__ void assemble_kernel(int mode, int p, int n, int kp, int kn, int rpad
             }
         }
         W[idx] = (T)v;
-        if (Wf) Wf[wf_index(i, k, ktot / 16)] = (float)v;     // fragment-major copy for the fp32 LDS-DMA kernel
+        if (Wf) {                                             // fragment-major copy for the LDS-DMA kernels
+            if (sizeof(T) == 4) Wf[wf_index(i, k, ktot / 16)] = (float)v;
+            else reinterpret_cast<double*>(Wf)[wd_index(i, k, ktot / 16)] = v;
+        }
     }
     if (idx < rpad) {
         const int i = (int)idx;
@@ -960,7 +963,7 @@ static int assemble(Engine& e, hipStream_t s, int mode, int ktot, double sw) {
                        sw, e.d_scal, e.d_M, e.d_K, e.d_L, potrf_ld(e.p), e.d_P, e.d_PK, e.d_mv, mx, e.d_ubar, e.d_gbar,
                        e.d_y, e.diag_gamma ? e.d_gw : (const double*)nullptr, (T*)e.d_W, (T*)e.d_bias,
                        (T*)e.d_shiftT, e.d_shift64, (T*)e.d_rowc, (T*)e.d_gbarT,
-                       sizeof(T) == 4 ? (float*)e.d_Wf : (float*)nullptr);
+                       (float*)e.d_Wf);
     CESX_HIP(hipGetLastError());
     return CESX_OK;
 }

@@ -447,9 +447,12 @@ int launch_update(Engine& e, int out_rows, const void* W, int ktot, const void* 
                   const void* add2, const double* c2, double c2_imm, void* out, double* absmax_part,
                   uint64_t step_index, bool metrics, const UpdateOpt& opt, hipStream_t s) {
     if (opt.wf && e.update_v2) {
-        // fp32 fast path (kernels_update2.hip); -1 = this launch does not qualify
-        const int rc = launch_update2(e, out_rows, opt.wf, ktot, bias, src, nsrc, add1, c1, c1_imm, add2, c2, c2_imm, out,
-                                      absmax_part, step_index, metrics, opt, s);
+        // LDS-DMA fast paths (kernels_update2.hip fp32, kernels_update3.hip fp64); -1 = this launch does not qualify
+        const int rc = e.cfg.dtype == CESX_F32
+            ? launch_update2(e, out_rows, opt.wf, ktot, bias, src, nsrc, add1, c1, c1_imm, add2, c2, c2_imm, out,
+                             absmax_part, step_index, metrics, opt, s)
+            : launch_update3(e, out_rows, opt.wf, ktot, bias, src, nsrc, add1, c1, c1_imm, add2, c2, c2_imm, out,
+                             absmax_part, metrics, opt, s);
         if (rc != -1) return rc;
     }
     return e.cfg.dtype == CESX_F32

@@ -1,0 +1,300 @@
+// K3, fp64 fast path -- the same GEMM  U_next = W . [U ; G ; xi] + b 1^T  as kernels_update.hip
+// (ces/calibrate.py:443-447, :484-488, :515-527) for fp64 engines (BASELINE.json configs[4], and the
+// drop-in class's default dtype), fed the way the fp32 kernel of kernels_update2.hip is fed, adapted
+// to v_mfma_f64_16x16x4_f64 (64 cycles per instruction and SIMD, one double per lane and operand):
+//
+//  * [U; G; xi] tiles (16 rows x 64 particles, 512-B row segments) go global -> LDS by DMA
+//    (global_load_lds_dwordx4), 2 pieces of 2 rows per wave and tile, into a 3-slot ring.  Particle
+//    4 li + c of the tile is column li of MFMA block c, so two ds_read_b128 yield the B operands of
+//    all four blocks of a k value and the epilogue stores 32 contiguous bytes per lane and row.  The
+//    16-byte chunks of ODD tile rows are swapped pairwise at the source (chunk ^ 1): the 16-lane
+//    groups of a ds_read_b128 then hit 16 different bank quads (rows 512 B apart would collide).
+//  * W does NOT pass through LDS (a 256 x 16 fp64 tile is 32 KiB; three slots of it would leave room
+//    for one workgroup per CU): every wave reads the A fragments of its own four row blocks straight
+//    from a fragment-major image of W (written by K2's assemble kernel) with 16-byte loads -- W is
+//    3 MB, L2-resident and shared by all workgroups -- one k-tile ahead, into a second register set.
+//  * the noise segment is read from memory (the block drawn ahead by cesx_prefetch_noise, or the
+//    injected one): fp64 Philox + Box-Muller (log, sincos) inside the loop would cost the matrix pipe
+//    far more than it does in fp32.  A launch that has to draw its noise in-kernel takes the
+//    register-staged kernel.
+//  * one barrier per k-tile; two workgroups per CU cover each other's barrier and epilogue.
+// Bound: MFMA.
+#include "cesx_internal.h"
+
+namespace cesx {
+
+constexpr int U3_THREADS = 256;
+constexpr int U3_BK = 16;            // k-tile
+constexpr int U3_BN = 64;            // particles per workgroup
+constexpr int U3_RC = 256;           // output rows per workgroup
+constexpr int U3_XSLOT = U3_BK * U3_BN * 8;      // 8 KiB
+constexpr int U3_RING = 3;
+
+struct Upd3Args {
+    const double* Wd; int nkt; int out_rows; const double* bias;
+    const double *src0, *src1, *src2; int rows0, rows1, rows2; int kt1, kt2;      // first k-tile of segments 1, 2 (INT_MAX: absent)
+    long long J;
+    double* out;
+    const double* add1; const double* c1p; double c1i;
+    const double* add2; const double* c2p; double c2i;
+    double* absmax_part;
+    const double* rowc; double* metric_part; int metric_seg;
+    int tri_seg;
+};
+
+__global__ __launch_bounds__(U3_THREADS, 2)
+void update3_kernel(const Upd3Args a) {
+    using d4 = double __attribute__((ext_vector_type(4)));
+    using d2 = double __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // [ X ring 3 x 8 KiB | rowc kn x 32 B ]
+    double* const sRowc = reinterpret_cast<double*>(smem + U3_RING * U3_XSLOT);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lr = lane >> 4;
+    const long long jt0 = (long long)blockIdx.x * U3_BN;
+    const int rc0 = blockIdx.y * U3_RC;
+    const int nkt = a.nkt;
+    // row blocks (16 rows) of this wave in mirrored pairs (w, 7-w, 8+w, 15-w): equal work in the triangular segment
+    int rbk[4];
+    rbk[0] = wave; rbk[1] = 7 - wave; rbk[2] = 8 + wave; rbk[3] = 15 - wave;
+    bool rb_on[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rb_on[r] = rc0 + rbk[r] * 16 < a.out_rows;
+    const int tri_t0 = a.tri_seg == 0 ? 0 : a.tri_seg == 1 ? a.kt1 : a.tri_seg == 2 ? a.kt2 : 0x7fffffff;
+    const int tri_t1 = a.tri_seg == 0 ? a.kt1 : a.tri_seg == 1 ? a.kt2 : a.tri_seg == 2 ? nkt : 0x7fffffff;
+    const bool do_metrics = a.metric_part != nullptr && blockIdx.y == 0;
+    const int met_t0 = !do_metrics ? 0x7fffffff : a.metric_seg == 0 ? 0 : a.metric_seg == 1 ? a.kt1 : a.kt2;
+    const int met_t1 = !do_metrics ? 0x7fffffff : a.metric_seg == 0 ? (a.kt1 < nkt ? a.kt1 : nkt)
+                                                : a.metric_seg == 1 ? (a.kt2 < nkt ? a.kt2 : nkt) : nkt;
+
+    // X DMA: piece q (0..7) = tile rows 2q, 2q+1; this wave issues q = wave and wave + 4.  Lane d fills the 16-byte
+    // chunk d % 32 of row 2q + d / 32; the odd row fetches chunk ^ 1 (see the header).  Ragged last workgroup
+    // (J % 4 == 0): columns are clamped, the clamped lanes' results are never stored.
+    const int drow = lane >> 5, dchunk = (lane & 31) ^ drow;
+    long long colc = jt0 + 2 * dchunk;
+    if (colc > a.J - 2) colc = a.J - 2;
+    auto issue_x = [&](int t, int slot) {
+        if (t >= nkt) return;
+        const int b1 = t >= a.kt1 ? 1 : 0, b2 = t >= a.kt2 ? 1 : 0;
+        const int r0 = (t - (b1 * a.kt1 + b2 * (a.kt2 - a.kt1))) * U3_BK;
+        const int rows = a.rows0 + b1 * (a.rows1 - a.rows0) + b2 * (a.rows2 - a.rows1);
+        const long long p0 = (long long)a.src0, p1 = (long long)a.src1, p2 = (long long)a.src2;
+        const double* base = (const double*)(p0 + b1 * (p1 - p0) + b2 * (p2 - p1));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = wave + 4 * i;
+            int row = r0 + 2 * q + drow;
+            row = row < rows ? row : rows - 1;          // padded rows meet zero columns of W
+            glds16(base + (size_t)row * a.J + colc, lds0 + slot * U3_XSLOT + q * 1024);
+        }
+    };
+    // A fragments of k-tile t: for every row block of this wave two 16-byte loads (k-steps 0,1 and 2,3)
+    const double* const wbase = a.Wd + ((size_t)blockIdx.y * nkt * 16) * 256 + lane * 2;     // 256 doubles per (rb, kt)
+    auto load_a = [&](d2 (&af)[4][2], int t) {
+        const int tt = t < nkt ? t : nkt - 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp)
+                af[r][sp] = *reinterpret_cast<const d2*>(wbase + ((size_t)tt * 16 + rbk[r]) * 256 + sp * 128);
+    };
+
+    d4 acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[r][c][e] = 0;
+
+    if (do_metrics) {
+        const int rows4 = (met_t1 - met_t0) * U3_BK * 4;
+        for (int i = tid; i < rows4; i += U3_THREADS) sRowc[i] = a.rowc[i];
+    }
+    double mq_e[4] = {0, 0, 0, 0}, mq_r[4] = {0, 0, 0, 0};
+
+    d2 afA[4][2], afB[4][2];
+    issue_x(0, 0);
+    issue_x(1, 1);
+    load_a(afA, 0);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    // byte offset of this lane's 32 bytes (particles 4 li .. 4 li + 3) in an even / odd tile row
+    const int xoff = li * 32;
+    auto tile_body = [&](int kt, int slot, d2 (&af)[4][2], d2 (&afn)[4][2]) {
+        load_a(afn, kt + 1);
+        const char* X = smem + slot * U3_XSLOT;
+        const bool intri = kt >= tri_t0 && kt < tri_t1;
+        const int k0l = (kt - tri_t0) * U3_BK;
+        bool need[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) need[r] = rb_on[r] && (!intri || rc0 + rbk[r] * 16 + 15 >= k0l);
+        if (kt >= met_t0 && kt < met_t1) {
+            // data metrics of the G tile in this slot: thread = (row tid / 16, 4 particles)
+            const int rr = tid >> 4;
+            const char* rowp = X + rr * 512;
+            const int sw = (rr & 1) * 16;
+            const d2 xa = *reinterpret_cast<const d2*>(rowp + (((tid & 15) * 32 + 0) ^ sw));
+            const d2 xb = *reinterpret_cast<const d2*>(rowp + (((tid & 15) * 32 + 16) ^ sw));
+            const double xv[4] = {xa[0], xa[1], xb[0], xb[1]};
+            const double* rc = sRowc + (size_t)((kt - met_t0) * U3_BK + rr) * 4;
+            const double gb = rc[0], yy = rc[1], w = rc[2];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const double b = xv[c] - gb, r = xv[c] - yy;
+                mq_e[c] += w * b * b;
+                mq_r[c] += w * r * r;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            // The DMAs of tile kt + 2 are issued in the MIDDLE of the tile (its slot was last read during tile
+            // kt - 1): the compiler's own vmcnt wait for the A fragments of the next tile also covers every
+            // older vector-memory operation, so a DMA issued at the top of a tile would be waited for at once.
+            if (s == 2) issue_x(kt + 2, (slot + 2) % U3_RING);
+            // B operands of k value 4 s + lr for the four particle blocks
+            const int krow = 4 * s + lr;
+            const char* rowp = X + krow * 512;
+            const int sw = (krow & 1) * 16;
+            const d2 b01 = *reinterpret_cast<const d2*>(rowp + ((xoff + 0) ^ sw));
+            const d2 b23 = *reinterpret_cast<const d2*>(rowp + ((xoff + 16) ^ sw));
+            const double bv[4] = {b01[0], b01[1], b23[0], b23[1]};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (need[r]) {
+                    const double av = af[r][s >> 1][s & 1];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[c], acc[r][c], 0, 0, 0);
+                }
+            }
+        }
+        // tile kt + 1 has landed for this wave once at most the 2 DMAs of tile kt + 2 and the 8 A loads of
+        // tile kt + 1 (all younger) are outstanding; then every wave has also finished reading this slot
+        if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(10)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else              asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    for (int kt = 0; kt < nkt; kt += 2) {
+        tile_body(kt, kt % U3_RING, afA, afB);
+        if (kt + 1 < nkt) tile_body(kt + 1, (kt + 1) % U3_RING, afB, afA);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // epilogue: lane holds, for row (lane >> 4) + 4 e of each of its blocks, particles 4 li .. 4 li + 3
+    const double c1 = a.add1 ? (a.c1p ? *a.c1p * a.c1i : a.c1i) : 0.0;
+    const double c2 = a.add2 ? (a.c2p ? *a.c2p * a.c2i : a.c2i) : 0.0;
+    const long long j = jt0 + 4 * li;
+    double amax = 0.0;
+    if (j < a.J) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = rc0 + rbk[r] * 16 + lr + 4 * e;
+                if (i < a.out_rows) {
+                    const double bi = a.bias ? a.bias[i] : 0.0;
+                    const size_t o = (size_t)i * a.J + j;
+                    d2 v0 = {acc[r][0][e] + bi, acc[r][1][e] + bi}, v1 = {acc[r][2][e] + bi, acc[r][3][e] + bi};
+                    if (a.add1) { v0 += c1 * *reinterpret_cast<const d2*>(a.add1 + o); v1 += c1 * *reinterpret_cast<const d2*>(a.add1 + o + 2); }
+                    if (a.add2) { v0 += c2 * *reinterpret_cast<const d2*>(a.add2 + o); v1 += c2 * *reinterpret_cast<const d2*>(a.add2 + o + 2); }
+                    *reinterpret_cast<d2*>(a.out + o) = v0;
+                    *reinterpret_cast<d2*>(a.out + o + 2) = v1;
+                    amax = fmax(amax, fmax(fmax(fabs(v0[0]), fabs(v0[1])), fmax(fabs(v1[0]), fabs(v1[1]))));
+                }
+            }
+        }
+    }
+    if (do_metrics) {
+        // combine the 16 row groups of every particle through LDS (the ring is idle now)
+        __syncthreads();
+        double* comb = reinterpret_cast<double*>(smem);           // [2][16][64]
+        const int grp = tid >> 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            comb[grp * U3_BN + 4 * (tid & 15) + c] = mq_e[c];
+            comb[16 * U3_BN + grp * U3_BN + 4 * (tid & 15) + c] = mq_r[c];
+        }
+        __syncthreads();
+        double se = 0.0, sr = 0.0;
+        if (tid < U3_BN && jt0 + tid < a.J) {
+            double qe = 0, qr = 0;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { qe += comb[g * U3_BN + tid]; qr += comb[16 * U3_BN + g * U3_BN + tid]; }
+            se = qe * qe;
+            sr = qr * qr;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { se += __shfl_down(se, o, 64); sr += __shfl_down(sr, o, 64); }
+        __syncthreads();
+        if (tid == 0) {                                            // (tid < 64: only wave 0 holds particles)
+            a.metric_part[blockIdx.x * 2 + 0] = sr;
+            a.metric_part[blockIdx.x * 2 + 1] = se;
+        }
+        __syncthreads();
+    }
+    if (a.absmax_part) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = fmax(amax, __shfl_down(amax, o, 64));
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(smem);
+        if (lane == 0) red[wave] = amax;
+        __syncthreads();
+        if (tid == 0) a.absmax_part[blockIdx.y * gridDim.x + blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    }
+}
+
+// returns CESX_OK, an error, or -1 when the launch does not qualify (caller falls back to update_kernel)
+int launch_update3(Engine& e, int out_rows, const void* Wd, int ktot, const void* bias,
+                   const UpdateSrc* src, int nsrc,
+                   const void* add1, const double* c1, double c1_imm,
+                   const void* add2, const double* c2, double c2_imm,
+                   void* out, double* absmax_part, bool metrics, const UpdateOpt& opt, hipStream_t s) {
+    if (e.cfg.dtype != CESX_F64 || !Wd || opt.ldw != 0 || nsrc < 1 || nsrc > 3) return -1;
+    if (e.J % 4 != 0 || e.J < 4 || ktot % U3_BK != 0) return -1;
+    const int lds = U3_RING * U3_XSLOT + e.kn * 32;      // (the epilogue's 16 KiB metric scratch reuses the ring)
+    if (lds > 78 * 1024) return -1;
+    auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    if (!al16(Wd) || !al16(out) || (add1 && !al16(add1)) || (add2 && !al16(add2))) return -1;
+    Upd3Args a{};
+    a.Wd = (const double*)Wd; a.nkt = ktot / U3_BK; a.out_rows = out_rows; a.bias = (const double*)bias;
+    const double* sp[3] = {nullptr, nullptr, nullptr};
+    int rows[3] = {1, 1, 1}, kt0[3] = {0, 0x7fffffff, 0x7fffffff};
+    int k0 = 0;
+    a.tri_seg = -1;
+    for (int i = 0; i < nsrc; ++i) {
+        if (src[i].kind != 0 || !src[i].ptr || !al16(src[i].ptr)) return -1;      // in-kernel noise: register-staged kernel
+        sp[i] = (const double*)src[i].ptr; rows[i] = src[i].rows; kt0[i] = k0 / U3_BK;
+        if (src[i].tri) a.tri_seg = i;
+        k0 += (src[i].rows + U3_BK - 1) / U3_BK * U3_BK;
+    }
+    if (k0 != ktot) { e.err = "update: K segments do not add up to ktot"; return CESX_EINVAL; }
+    for (int i = nsrc; i < 3; ++i) sp[i] = sp[0];
+    a.src0 = sp[0]; a.src1 = sp[1]; a.src2 = sp[2];
+    a.rows0 = rows[0]; a.rows1 = rows[1]; a.rows2 = rows[2];
+    a.kt1 = kt0[1]; a.kt2 = kt0[2];
+    a.J = e.J;
+    a.out = (double*)out;
+    a.add1 = (const double*)add1; a.c1p = c1; a.c1i = c1_imm;
+    a.add2 = (const double*)add2; a.c2p = c2; a.c2i = c2_imm;
+    a.absmax_part = absmax_part;
+    a.rowc = (const double*)e.d_rowc;
+    a.metric_part = metrics ? e.d_metric_part : nullptr;
+    a.metric_seg = opt.metric_seg;
+    dim3 grid((unsigned)((e.J + U3_BN - 1) / U3_BN), (unsigned)((out_rows + U3_RC - 1) / U3_RC));
+    CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(update3_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    e.last_update_grid_x = (int)grid.x;
+    e.last_update_grid = (int)(grid.x * grid.y);
+    {
+        ProfScope prof(e, opt.prof, s);
+        hipLaunchKernelGGL(update3_kernel, grid, dim3(U3_THREADS), lds, s, a);
+    }
+    CESX_HIP(hipGetLastError());
+    return CESX_OK;
+}
+
+}  // namespace cesx

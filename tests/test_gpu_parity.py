@@ -479,25 +479,26 @@ def test_overlap_variants_match(eng_mod, monkeypatch):
     assert outs[1][1:] == pytest.approx(outs[0][1:], rel=1e-6)
 
 
+@pytest.mark.parametrize("dtype,tol", [("float32", 1e-5), ("float64", 1e-12)])
 @pytest.mark.parametrize("update", ["aldi", "eks", "aldi_constant"])
 @pytest.mark.parametrize("shape", [(96, 80, 5000), (300, 40, 1004), (33, 17, 260)])
-def test_update_kernels_v1_v2_match(eng_mod, monkeypatch, update, shape):
-    """fp32 K3 through the LDS-DMA kernel (kernels_update2.hip, default) and through the
-    register-staged one (CESX_UPDATE_V1=1) give the same step: same Philox noise, same data
+def test_update_kernels_v1_v2_match(eng_mod, monkeypatch, update, shape, dtype, tol):
+    """K3 through the LDS-DMA kernels (kernels_update2.hip fp32 / kernels_update3.hip fp64, default) and through
+    the register-staged one (CESX_UPDATE_V1=1) give the same step: same Philox noise, same data
     metrics, ragged J / p / n included (p > 256 takes two row chunks)."""
     p, n, J = shape
     d = _synthetic(p, n, J, seed=21)
     outs = []
     for v1 in ("0", "1"):
         monkeypatch.setenv("CESX_UPDATE_V1", v1)
-        eng = eng_mod.Engine(p, n, J, dtype="float32", seed=5)
+        eng = eng_mod.Engine(p, n, J, dtype=dtype, seed=5)
         eng.set_problem(d["y"], d["Gamma"], d["mu"], d["sigma"], d["ustar"])
         out = eng.step(eng_mod.step_params(update=update, step_index=4, first_step=False, t_len=1, t_last=0.1),
                        d["U0"], d["G"], xi=None)
         res = eng.result()
         outs.append((out.cpu().numpy(), res.hk, res.bias_data, res.self_bias_data))
-    assert rel_err(outs[1][0], outs[0][0]) < 1e-5
-    assert outs[1][1:] == pytest.approx(outs[0][1:], rel=1e-5)
+    assert rel_err(outs[1][0], outs[0][0]) < tol
+    assert outs[1][1:] == pytest.approx(outs[0][1:], rel=tol)
 
 
 def test_comm_overlap_stream_path_matches(eng_mod):
