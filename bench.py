@@ -430,7 +430,8 @@ def main():
             traffic_tab = tj.get(cfg_name, tj if cfg_name == "C2" and "gram_kernel" in tj else {})
         except Exception:
             traffic_tab = {}
-    tkey = {"gram_kernel(K1)": "gram_kernel", "update_kernel(K3)": "update2_kernel" if dname == "float32" else "update_kernel"}
+    k3name = "update2_kernel" if dname == "float32" else ("update3_kernel" if "update3_kernel" in traffic_tab else "update_kernel")
+    tkey = {"gram_kernel(K1)": "gram_kernel", "update_kernel(K3)": k3name}
     traffic = traffic_tab.get(tkey[dom])
     step_s = elapsed / args.steps
     esz = np.dtype(args.dtype).itemsize

@@ -18,6 +18,7 @@
 #include "cesx_internal.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <set>
 #include <type_traits>
 
@@ -431,7 +432,10 @@ GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset, 
         for (int t = 0; t < pl.ntypes; ++t) {
             std::set<int> rws;
             for (auto& rc : types[t]) { rws.insert(rc.first); rws.insert(rc.second); }
-            w[t] = mfma_cyc * (double)((types[t].size() + 3) / 4) + 300.0 + 1.6 * (double)(rws.size() * tile);
+            // constants fitted to in-kernel cycle stamps of the LDS-DMA kernel (tools/gram2_bench.hip, f32 and
+            // f64 types of 11 ... 121 blocks): 1.055 x the MFMA cycles, 3 cycles per staged row (DMA issue, the
+            // in-place shift pass), 450 per tile (barrier, loop)
+            w[t] = 1.055 * mfma_cyc * (double)((types[t].size() + 3) / 4) + 450.0 + 3.0 * (double)(rws.size() * tile);
             total += w[t];
         }
         const int budget = std::max(wg_budget, pl.ntypes);
@@ -439,6 +443,11 @@ GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset, 
         // are that many: slice k of every such type then covers the same J range on the same XCD
         // (workgroup id mod 8), and the rows the types share are fetched from HBM once (at C2 the two
         // types of the second launch read 131 MB instead of 238 MB).
+        // ... unless there are many types with few slices each: rounding 17.5 down to 16 then costs more (the
+        // busiest workgroup sets the launch time) than the shared fetches save
+        int align_from = 16;
+        if (const char* av = std::getenv("CESX_GRAM_ALIGN_FROM")) align_from = std::max(8, std::atoi(av));
+        else if (pl.ntypes > 4) align_from = 64;
         std::vector<double> want(pl.ntypes);
         for (int t = 0; t < pl.ntypes; ++t) want[t] = total > 0 ? (double)budget * w[t] / total : 1.0;
         std::vector<int> order(pl.ntypes);
@@ -451,7 +460,7 @@ GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset, 
             double sum = 0.0;
             while (j < order.size() && want[order[j]] >= 0.96 * want[order[i]]) sum += want[order[j++]];
             int each = std::max(1, (int)std::floor(sum / (double)(j - i)));
-            if (each >= 16) each -= each % 8;
+            if (each >= align_from) each -= each % 8;
             for (size_t q = i; q < j; ++q) { nsl[order[q]] = each; used += each; }
             groups.push_back({i, j});
             i = j;
@@ -464,13 +473,13 @@ GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset, 
             double load = 0.0;
             for (size_t g = 0; g < groups.size(); ++g) {
                 const int t0 = order[groups[g].first];
-                const int inc = nsl[t0] >= 16 ? 8 : 1;
+                const int inc = nsl[t0] >= align_from ? 8 : 1;
                 if ((int)(groups[g].second - groups[g].first) * inc > budget - used) continue;
                 const double l = want[t0] / (double)nsl[t0];
                 if (l > load) { load = l; best = g; }
             }
             if (best < groups.size()) {
-                const int inc = nsl[order[groups[best].first]] >= 16 ? 8 : 1;
+                const int inc = nsl[order[groups[best].first]] >= align_from ? 8 : 1;
                 for (size_t q = groups[best].first; q < groups[best].second; ++q) { nsl[order[q]] += inc; used += inc; }
                 any = true;
             }

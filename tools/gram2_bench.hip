@@ -73,6 +73,11 @@ int run(int subset, int budget, int p, int n, long long J) {
         printf("  barrier cycles per wave (avg over WGs):");
         for (int w2 = 0; w2 < 16; ++w2) { double sb = 0; for (unsigned i = 0; i < grid.x; ++i) sb += bw[i * 16 + w2]; printf(" %.0f", sb / grid.x); }
         printf("\n");
+        for (int t = 0; t < pl.ntypes; ++t) {
+            const int w0 = pl.type_hdr[t * 8 + 4], ns = pl.type_hdr[t * 8 + 5];
+            double ww = 0, lp = 0; for (int i = w0; i < w0 + ns; ++i) { ww += c[4 * i + 3]; lp += c[4 * i + 1]; }
+            printf("    type %2d: %3d blocks, %2d row blocks, %3d slices: WG wall %.1f us, loop %.0f cycles\n", t, pl.type_hdr[t * 8 + 3], pl.type_hdr[t * 8 + 0], ns, ww / ns / 100, lp / ns);
+        }
         printf("  wave 0 per WG: prologue %.0f, loop %.0f, epilogue %.0f cycles; WG wall %.1f us (max %.1f) -> %.0f MHz\n", a0 / grid.x, a1 / grid.x, a2 / grid.x,
                w / grid.x / 100, wmax / 100, (a0 + a1 + a2) / w * 100);
     }

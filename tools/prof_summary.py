@@ -91,8 +91,8 @@ def main():
                 per_step[kern] = int(tot / steps)
         if per_step:
             per_step["gram_kernel"] = per_step.get("gram2_kernel", 0) + per_step.get("gram_kernel", 0)
-            if "update2_kernel" in per_step and "update_kernel" not in per_step:
-                per_step["update_kernel"] = per_step["update2_kernel"]
+            # (update_kernel also counts the forward-map launches of the bench set-up: the step's K3 is
+            #  update2_kernel (fp32) / update3_kernel (fp64) when the LDS-DMA kernels ran)
             per_step["_source"] = tag + "_pmc_summary.json"
             traffic[config] = per_step
         json.dump(traffic, open(tpath, "w"), indent=1, sort_keys=True)
