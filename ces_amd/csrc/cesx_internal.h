@@ -255,6 +255,10 @@ struct Engine {
     void* d_W = nullptr;           // [rpad][ktot]
     void* d_Wf = nullptr;          // the same matrix in the fragment-major order of kernels_update2.hip (fp32) / kernels_update3.hip (fp64)
     bool update_v2 = true;         // fp32 K3 through the LDS-DMA kernel (CESX_UPDATE_V1=1 switches back)
+    bool side_poll = true;         // side -> caller hand-over by a polled sequence number instead of an event (CESX_SIDE_EVENT=1: event)
+    unsigned long long* d_sideflag = nullptr;
+    unsigned long long side_seq = 0;
+    int  center_u_wgs = 256;       // workgroups of the U-only centring on the side stream (see cesx_create)
     bool gram_v2 = true;           // K1 through the LDS-DMA kernel when the shapes allow (CESX_GRAM_V1=1 switches back)
     int num_cus = 256;
     void* d_bias = nullptr;        // [rpad]

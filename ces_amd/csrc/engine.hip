@@ -221,7 +221,16 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
             int min_types = 1;
             if (part == 0) if (const char* gv = std::getenv("CESX_GRAM_UU_TYPES")) min_types = std::atoi(gv);
             // part 1: 7 workgroups per shader engine (8 CUs), so that the Cholesky always finds a free CU
-            int budget = part == 0 ? e.num_cus : e.num_cus - e.num_cus / 8;      // 256 / 224 on MI355X
+            // Part 1 runs beside what the side stream carries, and a kernel on another stream is only placed
+            // while it needs no more whole CUs than are free (tools/place_probe.hip: beside 248 one-per-CU
+            // workgroups a kernel of <= 8 workgroups starts at once, one of 16 waits for the whole launch).
+            //   * one device, p <= 256: the side stream runs the U-only centring (8 workgroups), the one-workgroup
+            //     chol(C) and then the noise block -> 1 CU in 32 stays free (248 workgroups on MI355X);
+            //   * sharded ensembles (RCCL's all-reduce kernels run there too) and p > 256 (blocked Cholesky: TRSM /
+            //     GEMM launches of tens of workgroups) -> 1 CU in 8 stays free (224).
+            const bool slim_side = e.J == e.Jg && potrf_ld(p) <= 256;
+            e.center_u_wgs = slim_side ? 8 : 256;       // (16 x 1024 threads do NOT get placed on the 8 free CUs: measured)
+            int budget = part == 0 ? e.num_cus : e.num_cus - (slim_side ? e.num_cus / 32 : e.num_cus / 8);
             if (part == 1) if (const char* bv = std::getenv("CESX_GRAM_B_WGS")) budget = std::max(8, std::atoi(bv));
             gp.plan = make_gram_plan(P, tile, gram_nbw(cfg->dtype), gram_max_stage_rows(), part + 1, pbU, min_types,
                                      budget, ntiles);
@@ -286,7 +295,8 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
         DM(e.d_lanczos, ((ms + 1) * n + 4 * ms) * 8);
     }
     DM(e.d_mv, (size_t)6 * mx * 8); DM(e.d_part, 256 * 4 * 8);
-    DM(e.d_scal, sizeof(Scalars)); DM(e.d_absmax, 8); DM(e.d_c0, 8);
+    DM(e.d_scal, sizeof(Scalars)); DM(e.d_absmax, 8); DM(e.d_c0, 8); DM(e.d_sideflag, 8);
+    if (const char* sv = std::getenv("CESX_SIDE_EVENT")) e.side_poll = sv[0] == '0';
     DM(e.d_absmax_part, (size_t)update_grid_blocks(e, p) * 8);
 #undef DM
     if (hipHostMalloc(reinterpret_cast<void**>(&e.h_scal), sizeof(Scalars), hipHostMallocMapped) != hipSuccess ||
@@ -334,7 +344,7 @@ void cesx_destroy(cesx_handle h) {
                     e.gp[1].d_type_hdr, e.gp[1].d_rows, e.gp[1].d_wblk, e.gp[1].d_blk_rc, e.gp[1].d_row_own, e.gp[1].d_slabs, e.gp[1].d_rowsum_part, e.d_sums, e.d_ubar, e.d_gbar, e.d_m, e.d_dg,
                     e.d_wdel, e.d_C, e.d_L, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_Kp, e.d_M, e.d_P, e.d_PK,
                     e.d_t1, e.d_t2, e.d_t3, e.d_t4, e.d_Lp, e.d_lanczos, e.d_mv, e.d_part, e.d_scal, e.d_absmax,
-                    e.d_c0, e.d_absmax_part};
+                    e.d_c0, e.d_absmax_part, e.d_sideflag};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     for (int w = 0; w < 2; ++w)

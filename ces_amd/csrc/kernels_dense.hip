@@ -41,7 +41,7 @@ struct MomView {
 };
 
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(DT)
+__global__ __launch_bounds__(1024)
 void center_kernel(MomView mv, const double* __restrict__ shift, const double* __restrict__ y,
                    const double* __restrict__ ustar, const double* __restrict__ gw,
                    const double* __restrict__ sw, int unbiased, int what,
@@ -49,7 +49,7 @@ void center_kernel(MomView mv, const double* __restrict__ shift, const double* _
                    double* __restrict__ dg, double* __restrict__ C, double* __restrict__ Cug,
                    double* __restrict__ See, double* __restrict__ Srr, double* __restrict__ K,
                    double* __restrict__ M, double* __restrict__ part, Scalars* __restrict__ sc) {
-    __shared__ double red[DT / 64];
+    __shared__ double red[1024 / 64];      // (launched with 256 or, for the U-only part beside a Gram launch, 1024 threads)
     // what & 1: the part that depends on U alone (C, M = C Sigma^{-1}, ubar, tr S_uu, |ubar - u*|^2):
     //           everything chol(C) needs, available before the rest of the Gram is finished
     // what & 2: the part that involves G
@@ -66,7 +66,7 @@ void center_kernel(MomView mv, const double* __restrict__ shift, const double* _
     const double* sb = mv.sb();
     // 32-bit index arithmetic (p, n < 32768): a 64-bit divide per element used to dominate this kernel
     const unsigned pp = (unsigned)p * p, pn = (unsigned)p * n, nn = (unsigned)n * n;
-    const unsigned gid = blockIdx.x * DT + threadIdx.x, gsz = gridDim.x * DT;
+    const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
     double tr = 0.0, b2 = 0.0, fr = 0.0;
     if (what & 1) {
         const double* Saa = mv.Saa();
@@ -119,6 +119,13 @@ void center_kernel(MomView mv, const double* __restrict__ shift, const double* _
         if (what & 1) { part[blockIdx.x * 4 + 0] = tr; part[blockIdx.x * 4 + 1] = b2; }
         if (what & 2) part[blockIdx.x * 4 + 2] = fr;
     }
+    // launched with fewer than NPB workgroups (the U-only part beside a Gram launch): the scalar kernel
+    // sums all NPB slots, the ones no workgroup owns must read zero
+    if (blockIdx.x == 0)
+        for (int b = gridDim.x + threadIdx.x; b < NPB; b += blockDim.x) {
+            if (what & 1) { part[b * 4 + 0] = 0.0; part[b * 4 + 1] = 0.0; }
+            if (what & 2) part[b * 4 + 2] = 0.0;
+        }
 }
 
 // part[blk*4 + 2] = sum A .* B   (dense-Gamma Frobenius term)
@@ -725,6 +732,24 @@ __global__ void assemble_kernel(int mode, int p, int n, int kp, int kn, int rpad
     }
 }
 
+// Hand-over from the side stream to the caller's stream WITHOUT an event: the last kernel of the side chain
+// publishes a sequence number, a one-wave kernel on the caller's stream polls it.  A hipEventRecord /
+// hipStreamWaitEvent pair costs ~12 us between the end of the producer and the start of the consumer
+// (rocprofv3 traces); this hand-over costs the poll interval.  The poller is launched behind the caller's
+// own kernels of the step (nothing else wants its CU exclusively at that point), the side chain never waits
+// for the caller's stream after its start, and the poll gives up after 2 s (status CESX_EHIP).
+__global__ void side_done_kernel(unsigned long long* flag, unsigned long long seq) {
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void side_join_kernel(const unsigned long long* flag, unsigned long long seq, Scalars* sc) {
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > 200000000LL) { sc->status = CESX_EHIP; break; }     // 2 s at 100 MHz
+    }
+}
+
 // v = hk * (a + b)
 __global__ void hk_sum_kernel(int len, const Scalars* __restrict__ sc, const double* __restrict__ a,
                               const double* __restrict__ b, double* __restrict__ out) {
@@ -996,7 +1021,12 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
     if (!early)
         if ((rc = potrf(e, s, p, e.d_C, e.d_L))) return rc;
     if (early) {
-        CESX_HIP(hipStreamWaitEvent(s, e.ev_b, 0));
+        if (e.side_poll) {
+            hipLaunchKernelGGL(side_join_kernel, dim3(1), dim3(64), 0, s, e.d_sideflag, e.side_seq, e.d_scal);
+            CESX_HIP(hipGetLastError());
+        } else {
+            CESX_HIP(hipStreamWaitEvent(s, e.ev_b, 0));
+        }
         e.chol_inflight = false;
     }
     if (!e.diag_gamma) {
@@ -1076,7 +1106,8 @@ int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s) {
         CESX_HIP(hipEventRecord(e.ev_a, s));
         CESX_HIP(hipStreamWaitEvent(e.side, e.ev_a, 0));
     }
-    hipLaunchKernelGGL(center_kernel, dim3(NPB), dim3(DT), 0, e.side, mv, e.d_shift64, e.d_y, e.d_ustar,
+    // (few workgroups -> 1024 threads each: 8 x 256 threads took 25 us for the 65 k elements of C, latency bound)
+    hipLaunchKernelGGL(center_kernel, dim3(std::min(NPB, e.center_u_wgs)), dim3(e.center_u_wgs < NPB ? 1024 : DT), 0, e.side, mv, e.d_shift64, e.d_y, e.d_ustar,
                        e.diag_gamma ? e.d_gw : (const double*)nullptr,
                        e.diag_sigma ? e.d_sw : (const double*)nullptr, unbiased, 1, e.d_ubar, e.d_gbar,
                        e.d_m, e.d_dg, e.d_C, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_M, e.d_part, e.d_scal);
@@ -1088,7 +1119,12 @@ int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s) {
         e.xi_step = e.xi_want;
         e.xi_want = -1;
     }
-    CESX_HIP(hipEventRecord(e.ev_b, e.side));
+    if (e.side_poll) {
+        hipLaunchKernelGGL(side_done_kernel, dim3(1), dim3(64), 0, e.side, e.d_sideflag, ++e.side_seq);
+        CESX_HIP(hipGetLastError());
+    } else {
+        CESX_HIP(hipEventRecord(e.ev_b, e.side));
+    }
     e.chol_inflight = true;
     return CESX_OK;
 }
