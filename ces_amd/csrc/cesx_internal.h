@@ -255,9 +255,6 @@ struct Engine {
     void* d_W = nullptr;           // [rpad][ktot]
     void* d_Wf = nullptr;          // the same matrix in the fragment-major order of kernels_update2.hip (fp32) / kernels_update3.hip (fp64)
     bool update_v2 = true;         // fp32 K3 through the LDS-DMA kernel (CESX_UPDATE_V1=1 switches back)
-    bool side_poll = true;         // side -> caller hand-over by a polled sequence number instead of an event (CESX_SIDE_EVENT=1: event)
-    unsigned long long* d_sideflag = nullptr;
-    unsigned long long side_seq = 0;
     int  center_u_wgs = 256;       // workgroups of the U-only centring on the side stream (see cesx_create)
     bool gram_v2 = true;           // K1 through the LDS-DMA kernel when the shapes allow (CESX_GRAM_V1=1 switches back)
     int num_cus = 256;
@@ -275,7 +272,8 @@ struct Engine {
     hipEvent_t ev = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;   // ev_c: side-stream centring done
     hipStream_t side = nullptr;      // side stream (high priority): U x U Gram, chol(C), the step's last small kernel
     hipStream_t bg = nullptr;        // background stream (low priority): noise blocks drawn ahead into idle CUs
-    hipEvent_t ev_in = nullptr, ev_k3 = nullptr, ev_m = nullptr, ev_x = nullptr;   // (spare)
+    hipEvent_t ev_x = nullptr;       // the prefetched noise block is complete (side stream)
+    hipEvent_t ev_in = nullptr, ev_k3 = nullptr, ev_m = nullptr;   // (spare)
     void* d_xi = nullptr;            // [p][J] engine dtype: noise block drawn ahead by cesx_prefetch_noise
     long long xi_step = -1;          // step index d_xi holds (-1: none)
     long long xi_want = -1;          // step index asked for by cesx_prefetch_noise, drawn behind the next second Gram launch

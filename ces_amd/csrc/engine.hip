@@ -122,8 +122,10 @@ int finish_step(Engine& e, const cesx_step_params& prm, hipStream_t s) {
 
 // the noise block of this step drawn ahead by cesx_prefetch_noise (nullptr: draw inside the update kernel)
 const void* prefetched_noise(Engine& e, const cesx_step_params& prm, hipStream_t s) {
-    (void)s;      // drawn on the side stream behind chol(C); launch_dense has joined that stream already
+    // drawn on the side stream behind chol(C); its own event, waited for HERE (right before the update kernel):
+    // K2's scalar and assemble kernels do not need the block and run beside the draw
     if (!e.d_xi || e.xi_step != (long long)prm.step_index) return nullptr;
+    if (hipStreamWaitEvent(s, e.ev_x, 0) != hipSuccess) return nullptr;
     return e.d_xi;
 }
 
@@ -295,8 +297,7 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
         DM(e.d_lanczos, ((ms + 1) * n + 4 * ms) * 8);
     }
     DM(e.d_mv, (size_t)6 * mx * 8); DM(e.d_part, 256 * 4 * 8);
-    DM(e.d_scal, sizeof(Scalars)); DM(e.d_absmax, 8); DM(e.d_c0, 8); DM(e.d_sideflag, 8);
-    if (const char* sv = std::getenv("CESX_SIDE_EVENT")) e.side_poll = sv[0] == '0';
+    DM(e.d_scal, sizeof(Scalars)); DM(e.d_absmax, 8); DM(e.d_c0, 8);
     DM(e.d_absmax_part, (size_t)update_grid_blocks(e, p) * 8);
 #undef DM
     if (hipHostMalloc(reinterpret_cast<void**>(&e.h_scal), sizeof(Scalars), hipHostMallocMapped) != hipSuccess ||
@@ -344,7 +345,7 @@ void cesx_destroy(cesx_handle h) {
                     e.gp[1].d_type_hdr, e.gp[1].d_rows, e.gp[1].d_wblk, e.gp[1].d_blk_rc, e.gp[1].d_row_own, e.gp[1].d_slabs, e.gp[1].d_rowsum_part, e.d_sums, e.d_ubar, e.d_gbar, e.d_m, e.d_dg,
                     e.d_wdel, e.d_C, e.d_L, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_Kp, e.d_M, e.d_P, e.d_PK,
                     e.d_t1, e.d_t2, e.d_t3, e.d_t4, e.d_Lp, e.d_lanczos, e.d_mv, e.d_part, e.d_scal, e.d_absmax,
-                    e.d_c0, e.d_absmax_part, e.d_sideflag};
+                    e.d_c0, e.d_absmax_part};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     for (int w = 0; w < 2; ++w)

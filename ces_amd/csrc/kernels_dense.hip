@@ -732,24 +732,6 @@ __global__ void assemble_kernel(int mode, int p, int n, int kp, int kn, int rpad
     }
 }
 
-// Hand-over from the side stream to the caller's stream WITHOUT an event: the last kernel of the side chain
-// publishes a sequence number, a one-wave kernel on the caller's stream polls it.  A hipEventRecord /
-// hipStreamWaitEvent pair costs ~12 us between the end of the producer and the start of the consumer
-// (rocprofv3 traces); this hand-over costs the poll interval.  The poller is launched behind the caller's
-// own kernels of the step (nothing else wants its CU exclusively at that point), the side chain never waits
-// for the caller's stream after its start, and the poll gives up after 2 s (status CESX_EHIP).
-__global__ void side_done_kernel(unsigned long long* flag, unsigned long long seq) {
-    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-__global__ void side_join_kernel(const unsigned long long* flag, unsigned long long seq, Scalars* sc) {
-    if (threadIdx.x != 0) return;
-    const long long t0 = wall_clock64();
-    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
-        __builtin_amdgcn_s_sleep(8);
-        if (wall_clock64() - t0 > 200000000LL) { sc->status = CESX_EHIP; break; }     // 2 s at 100 MHz
-    }
-}
-
 // v = hk * (a + b)
 __global__ void hk_sum_kernel(int len, const Scalars* __restrict__ sc, const double* __restrict__ a,
                               const double* __restrict__ b, double* __restrict__ out) {
@@ -1021,12 +1003,7 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
     if (!early)
         if ((rc = potrf(e, s, p, e.d_C, e.d_L))) return rc;
     if (early) {
-        if (e.side_poll) {
-            hipLaunchKernelGGL(side_join_kernel, dim3(1), dim3(64), 0, s, e.d_sideflag, e.side_seq, e.d_scal);
-            CESX_HIP(hipGetLastError());
-        } else {
-            CESX_HIP(hipStreamWaitEvent(s, e.ev_b, 0));
-        }
+        CESX_HIP(hipStreamWaitEvent(s, e.ev_b, 0));
         e.chol_inflight = false;
     }
     if (!e.diag_gamma) {
@@ -1114,16 +1091,12 @@ int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s) {
     CESX_HIP(hipGetLastError());
     int rc;
     if ((rc = potrf(e, e.side, p, e.d_C, e.d_L))) return rc;
-    if (e.xi_want >= 0 && e.d_xi) {                // noise block asked for by cesx_prefetch_noise
+    CESX_HIP(hipEventRecord(e.ev_b, e.side));      // C, M, ubar, L: what K2's scalar and assemble kernels read
+    if (e.xi_want >= 0 && e.d_xi) {                // noise block asked for by cesx_prefetch_noise: waited for only by K3
         if ((rc = launch_noise(e, (uint64_t)e.xi_want, e.d_xi, e.side))) return rc;
+        CESX_HIP(hipEventRecord(e.ev_x, e.side));
         e.xi_step = e.xi_want;
         e.xi_want = -1;
-    }
-    if (e.side_poll) {
-        hipLaunchKernelGGL(side_done_kernel, dim3(1), dim3(64), 0, e.side, e.d_sideflag, ++e.side_seq);
-        CESX_HIP(hipGetLastError());
-    } else {
-        CESX_HIP(hipEventRecord(e.ev_b, e.side));
     }
     e.chol_inflight = true;
     return CESX_OK;
