@@ -351,6 +351,50 @@ def test_in_kernel_noise_equals_injected_noise(eng_mod):
     assert rel_err(a, b) < 1e-6
 
 
+@pytest.mark.parametrize("dtype,tol", [("float32", 2e-6), ("float64", 1e-13)])
+@pytest.mark.parametrize("update", ["aldi", "aldi_constant"])
+def test_prefetched_noise_block(eng_mod, dtype, tol, update):
+    """cesx_prefetch_noise (include/cesx.h): the block drawn AHEAD of the update on the side stream is what the
+    update uses when xi_dev == NULL and the step index matches -- the same numbers as the in-kernel generator
+    (CESX_NO_NOISE_PREFETCH=1) and as the injected cesx_draw_noise block; a different step index falls back to
+    drawing inside the update kernel.  Split entry points (what ces_amd.dist drives) and cesx_step."""
+    import os
+    from ces_amd.dist import ShardedUpdate
+    p, n, J = 48, 40, 2048
+    d = _synthetic(p, n, J, seed=13)
+
+    def run(prefetch_step, use_step, env=None):
+        if env:
+            os.environ["CESX_NO_NOISE_PREFETCH"] = "1"
+        try:
+            eng = eng_mod.Engine(p, n, J, dtype=dtype, seed=21)
+            eng.set_problem(d["y"], d["Gamma"], d["mu"], d["sigma"], d["ustar"])
+            sh = ShardedUpdate(eng)
+            U, G = eng.to_device(d["U0"]), eng.to_device(d["G"])
+            prm = eng_mod.step_params(update=update, step_index=use_step)
+            sh.begin(prm, U, G, recenter=True, noise_step=prefetch_step)
+            out = sh.finish(prm, U, G, xi=None)
+            res = sh.result()
+            return out.cpu().numpy(), res.hk, eng
+        finally:
+            os.environ.pop("CESX_NO_NOISE_PREFETCH", None)
+    a, hk_a, eng = run(7, 7)                     # prefetched block used
+    b, hk_b, _ = run(None, 7)                    # no prefetch: drawn inside the update kernel
+    c, hk_c, _ = run(7, 7, env=True)             # prefetch disabled by the environment
+    e, hk_e, _ = run(3, 7)                       # block of another step prefetched: ignored, step 7 drawn in-kernel
+    assert rel_err(a, b) < tol and rel_err(a, c) < tol and rel_err(a, e) < tol
+    assert hk_a == pytest.approx(hk_b, rel=1e-12) and hk_a == pytest.approx(hk_e, rel=1e-12)
+    # and the injected block of the same step gives the same update
+    xi = eng.draw_noise(7)
+    prm = eng_mod.step_params(update=update, step_index=7)
+    f = eng.step(prm, d["U0"], d["G"], xi=xi).cpu().numpy()
+    eng.result()
+    assert rel_err(a, f) < tol
+    # a different step index draws a different block
+    g, _, _ = run(8, 8)
+    assert rel_err(a, g) > 1e-3
+
+
 @pytest.mark.parametrize("dtype,tol", [("float64", 1e-9), ("float32", 1e-4)])
 def test_logical_shards_add_up(eng_mod, dtype, tol):
     """moments of N column shards sum to the moments of the whole
