@@ -260,6 +260,9 @@ struct Engine {
     int num_cus = 256;
     void* d_bias = nullptr;        // [rpad]
     void* d_Wfwd = nullptr;        // forward-map staging [npad][kp]
+    void* d_Wfwd_f = nullptr;      // the same map in the fragment-major order of the LDS-DMA update kernels (cesx_forward_set_lineal)
+    void* d_bfwd = nullptr;        // [rpad] its offset b
+    bool  fwd_set = false, fwd_has_b = false;
     // per-kernel profiling (cesx_profile_*)
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[2];
@@ -352,6 +355,7 @@ int gram_tile(int dtype);
 int gram_kt(int dtype);
 int gram_max_stage_rows();
 int launch_noise(Engine& e, uint64_t step_index, void* xi, hipStream_t s);
+int launch_stage_forward(Engine& e, const void* A, const void* b, hipStream_t s);   // A, b -> d_Wfwd, d_Wfwd_f, d_bfwd
 
 // RAII-less helper: records an event pair around a launch when profiling is on
 struct ProfScope {

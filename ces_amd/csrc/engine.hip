@@ -268,6 +268,8 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
         DM(t, (size_t)e.rpad * e.ktot * e.esz); e.d_Wf = t;
         DM(t, (size_t)e.rpad * e.esz); e.d_bias = t;
         DM(t, (size_t)e.rpad * e.kp * e.esz); e.d_Wfwd = t;
+        DM(t, (size_t)e.rpad * e.kp * e.esz); e.d_Wfwd_f = t;
+        DM(t, (size_t)e.rpad * e.esz); e.d_bfwd = t;
     }
     for (int part = 0; part < 2; ++part) {
         GramPart& gp = e.gp[part];
@@ -338,7 +340,7 @@ void cesx_destroy(cesx_handle h) {
     DeviceGuard dg(e.cfg.device);
     void* ptrs[] = {e.d_y, e.d_mu, e.d_ustar, e.d_Gamma, e.d_Ginv, e.d_gw, e.d_Wh, e.d_Sigma, e.d_Sinv, e.d_sw,
                     e.d_shift64, e.d_shiftT, e.d_yT, e.d_gwT, e.d_GinvT, e.d_wdT, e.d_W, e.d_Wf, e.d_Lwork,
-                    e.d_bias, e.d_Wfwd, e.d_metric_part, e.d_metric_sums,
+                    e.d_bias, e.d_Wfwd, e.d_Wfwd_f, e.d_bfwd, e.d_metric_part, e.d_metric_sums,
                     e.d_gbarT, e.d_rowc,
                     e.d_colsum_part, e.d_mom,
                     e.gp[0].d_type_hdr, e.gp[0].d_rows, e.gp[0].d_wblk, e.gp[0].d_blk_rc, e.gp[0].d_row_own, e.gp[0].d_slabs, e.gp[0].d_rowsum_part,
@@ -621,6 +623,30 @@ int cesx_forward_lineal(cesx_handle h, const void* A, const void* b, const void*
     UpdateOpt opt;
     return launch_update(e, e.n, e.d_Wfwd, e.kp, b, src, 1, nullptr, nullptr, 0.0, nullptr, nullptr, 0.0, G,
                          nullptr, 0, false, opt, s);
+}
+
+int cesx_forward_set_lineal(cesx_handle h, const void* A, const void* b, void* stream) {
+    if (!h) return CESX_EINVAL;
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    if (!A) { e.err = "cesx_forward_set_lineal: null pointer"; return CESX_EINVAL; }
+    SET_DEVICE(e);
+    TRY(launch_stage_forward(e, A, b, (hipStream_t)stream));
+    e.fwd_set = true;
+    e.fwd_has_b = b != nullptr;
+    return CESX_OK;
+}
+
+int cesx_forward_apply(cesx_handle h, const void* U, void* G, void* stream) {
+    if (!h) return CESX_EINVAL;
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    if (!U || !G) { e.err = "cesx_forward_apply: null pointer"; return CESX_EINVAL; }
+    if (!e.fwd_set) { e.err = "cesx_forward_apply: cesx_forward_set_lineal has not been called"; return CESX_ESTATE; }
+    SET_DEVICE(e);
+    UpdateSrc src[1] = {{U, e.p, 0, 0}};
+    UpdateOpt opt;
+    opt.wf = e.d_Wfwd_f;
+    return launch_update(e, e.n, e.d_Wfwd, e.kp, e.fwd_has_b ? e.d_bfwd : nullptr, src, 1, nullptr, nullptr, 0.0, nullptr,
+                         nullptr, 0.0, G, nullptr, 0, false, opt, (hipStream_t)stream);
 }
 
 int cesx_profile_enable(cesx_handle h, int on) {

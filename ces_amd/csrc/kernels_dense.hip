@@ -732,6 +732,34 @@ __global__ void assemble_kernel(int mode, int p, int n, int kp, int kn, int rpad
     }
 }
 
+// forward map A (n x p) -> zero-padded rpad x kp row-major image + the fragment-major image the LDS-DMA update
+// kernels read (wf_index / wd_index), b -> padded offset vector
+template <typename T>
+__global__ void stage_forward_kernel(int n, int p, int rpad, int kp, const T* __restrict__ A, const T* __restrict__ b,
+                                     T* __restrict__ W, T* __restrict__ Wf, T* __restrict__ bias) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long long)rpad * kp) {
+        const int i = (int)(idx / kp), k = (int)(idx % kp);
+        const T v = (i < n && k < p) ? A[(size_t)i * p + k] : (T)0;
+        W[idx] = v;
+        if (sizeof(T) == 4) Wf[wf_index(i, k, kp / 16)] = v;
+        else Wf[wd_index(i, k, kp / 16)] = v;
+    }
+    if (idx < rpad) bias[idx] = (b != nullptr && idx < n) ? b[idx] : (T)0;
+}
+
+int launch_stage_forward(Engine& e, const void* A, const void* b, hipStream_t s) {
+    const long long len = (long long)e.rpad * e.kp;
+    if (e.cfg.dtype == CESX_F32)
+        hipLaunchKernelGGL(stage_forward_kernel<float>, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s, e.n, e.p, e.rpad, e.kp,
+                           (const float*)A, (const float*)b, (float*)e.d_Wfwd, (float*)e.d_Wfwd_f, (float*)e.d_bfwd);
+    else
+        hipLaunchKernelGGL(stage_forward_kernel<double>, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s, e.n, e.p, e.rpad, e.kp,
+                           (const double*)A, (const double*)b, (double*)e.d_Wfwd, (double*)e.d_Wfwd_f, (double*)e.d_bfwd);
+    CESX_HIP(hipGetLastError());
+    return CESX_OK;
+}
+
 // v = hk * (a + b)
 __global__ void hk_sum_kernel(int len, const Scalars* __restrict__ sc, const double* __restrict__ a,
                               const double* __restrict__ b, double* __restrict__ out) {

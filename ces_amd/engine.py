@@ -25,7 +25,7 @@ EXPORTS = ("cesx_abi_version", "cesx_create", "cesx_destroy", "cesx_last_error",
            "cesx_moments", "cesx_apply", "cesx_apply_drift", "cesx_apply_finish", "cesx_draw_noise",
            "cesx_forward_lineal", "cesx_debug_dense", "cesx_profile_enable", "cesx_profile_read",
            "cesx_moments_uu_len", "cesx_moments_uu", "cesx_chol_async", "cesx_moments_rest", "cesx_side_stream",
-           "cesx_prefetch_noise")
+           "cesx_prefetch_noise", "cesx_forward_set_lineal", "cesx_forward_apply")
 
 
 class Config(C.Structure):
@@ -95,6 +95,8 @@ def load_library(path=None):
     lib.cesx_draw_noise.argtypes = [vp, u64, vp, vp]
     lib.cesx_prefetch_noise.argtypes = [vp, u64, vp]
     lib.cesx_forward_lineal.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.cesx_forward_set_lineal.argtypes = [vp, vp, vp, vp]
+    lib.cesx_forward_apply.argtypes = [vp, vp, vp, vp]
     lib.cesx_debug_dense.argtypes = [vp, dp, dp, dp, dp, dp, dp]
     lib.cesx_profile_enable.argtypes = [vp, i32]
     lib.cesx_profile_read.argtypes = [vp, i32, dp, C.POINTER(C.c_int)]
@@ -446,6 +448,27 @@ class Engine:
             self._check(self.lib.cesx_forward_lineal(self._h, A.data_ptr(), None if bt is None else bt.data_ptr(),
                                                      U.data_ptr(), out.data_ptr(), self._stream()))
         self._keep = (A, bt, U, out)
+        return out
+
+    def forward_set_lineal(self, A, b=None):
+        """Install the linear map G = A U + b in the engine (cesx_forward_set_lineal); the engine keeps its own copy."""
+        A = torch.as_tensor(A).to(device=self.device, dtype=self.torch_dtype).contiguous()
+        if tuple(A.shape) != (self.n_obs, self.p):
+            raise ValueError("A must be (n_obs, p)")
+        bt = None if b is None else torch.as_tensor(np.ascontiguousarray(b)).to(device=self.device, dtype=self.torch_dtype).reshape(-1).contiguous()
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cesx_forward_set_lineal(self._h, A.data_ptr(), None if bt is None else bt.data_ptr(),
+                                                         self._stream()))
+            torch.cuda.current_stream(self.device).synchronize()       # A, bt may be released now
+        self._fwd_token = object()          # identifies the installed map (ces_amd.utils.lineal checks it)
+        return self._fwd_token
+
+    def forward_apply(self, U, out=None):
+        """G = A U + b with the installed map (cesx_forward_apply)."""
+        out = self.empty(self.n_obs) if out is None else out
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cesx_forward_apply(self._h, U.data_ptr(), out.data_ptr(), self._stream()))
+        self._keep_fwd = (U, out)
         return out
 
     def profile_enable(self, on=True):

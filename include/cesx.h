@@ -232,6 +232,15 @@ int cesx_prefetch_noise(cesx_handle h, uint64_t step_index, void* stream);
 int cesx_forward_lineal(cesx_handle h, const void* A_dev, const void* b_dev,
                         const void* U_dev, void* G_dev, void* stream);
 
+/* The same map in two steps for a driver loop that applies ONE map every iteration
+   (sampling.run calls model once per particle per iteration, ces/calibrate.py:351-352):
+   cesx_forward_set_lineal copies A (and b) into engine-owned buffers laid out for the LDS-DMA
+   update kernels, cesx_forward_apply evaluates G = A U + b with them -- no staging copies per
+   iteration, and the GEMM runs in the fast kernel.  The engine keeps its own copy: A_dev / b_dev
+   may be freed or changed afterwards (call set again to change the map). */
+int cesx_forward_set_lineal(cesx_handle h, const void* A_dev, const void* b_dev, void* stream);
+int cesx_forward_apply(cesx_handle h, const void* U_dev, void* G_dev, void* stream);
+
 /* ---- introspection ---------------------------------------------------- */
 
 /* Per-kernel timing with HIP events recorded on the launch stream around the

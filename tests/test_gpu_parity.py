@@ -425,15 +425,22 @@ def test_logical_shards_add_up(eng_mod, dtype, tol):
 
 
 def test_forward_lineal_hook(eng_mod):
-    """ces/utils.py:25-31 on the whole shard."""
+    """ces/utils.py:25-31 on the whole shard: the one-call form (cesx_forward_lineal) and the
+    installed-map form (cesx_forward_set_lineal + cesx_forward_apply, what lineal.forward_device uses), through the
+    LDS-DMA kernels (J % 4 == 0) and the register-staged fallback (ragged J), two models sharing one engine."""
     from ces_amd.utils import lineal
     rng = np.random.default_rng(2)
-    p, n, J = 37, 21, 1234
-    A, b, U = rng.standard_normal((n, p)), rng.standard_normal(n), rng.standard_normal((p, J))
-    for dtype, tol in (("float64", 1e-12), ("float32", 1e-5)):
-        eng = eng_mod.Engine(p, n, J, dtype=dtype)
-        G = lineal(A, b=b).forward_device(eng, eng.to_device(U)).cpu().numpy()
-        assert rel_err(G, A @ U + b[:, None]) < tol
+    for p, n, J in ((37, 21, 1234), (64, 50, 2048), (300, 260, 1024)):
+        A, b, U = rng.standard_normal((n, p)), rng.standard_normal(n), rng.standard_normal((p, J))
+        A2 = rng.standard_normal((n, p))
+        for dtype, tol in (("float64", 1e-12), ("float32", 1e-5)):
+            eng = eng_mod.Engine(p, n, J, dtype=dtype)
+            Ud = eng.to_device(U)
+            m1, m2 = lineal(A, b=b), lineal(A2)
+            assert rel_err(m1.forward_device(eng, Ud).cpu().numpy(), A @ U + b[:, None]) < tol
+            assert rel_err(m2.forward_device(eng, Ud).cpu().numpy(), A2 @ U) < tol
+            assert rel_err(m1.forward_device(eng, Ud).cpu().numpy(), A @ U + b[:, None]) < tol       # re-installed
+            assert rel_err(eng.forward_lineal(A2, Ud, b=b).cpu().numpy(), A2 @ U + b[:, None]) < tol
 
 
 def test_c4_darcy_drop_in(eng_mod):
