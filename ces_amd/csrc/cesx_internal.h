@@ -62,6 +62,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+// The same piece from a wave-uniform 64-bit base (an SGPR pair) plus a 32-bit per-lane byte offset: the address
+// arithmetic of a piece is scalar, no vector ALU instruction is spent on it (on gfx950 every VALU instruction in an
+// f32 MFMA loop costs the matrix pipe ~4 cycles, a 64-bit v_mul four times that).
+__device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" :: "s"(sbase), "v"(voff), "s"(lds_dst) : "memory");
+}
+
 // Slab layout of one partial Gram block ("accumulator-major"): element ((q * 64 + lane) * VEC + e)
 // is accumulator register VEC * q + e of lane `lane`, so a wave stores a block with 16-byte stores
 // of consecutive lanes (1 KiB per instruction).  (row, col) of the first element of group `grp`
@@ -256,6 +263,7 @@ struct Engine {
     void* d_Wf = nullptr;          // the same matrix in the fragment-major order of kernels_update2.hip (fp32) / kernels_update3.hip (fp64)
     bool update_v2 = true;         // fp32 K3 through the LDS-DMA kernel (CESX_UPDATE_V1=1 switches back)
     int  center_u_wgs = 256;       // workgroups of the U-only centring on the side stream (see cesx_create)
+    bool k2_fused = true;          // ALDI, default / spectral time step: scalar + assemble kernels as one launch (CESX_K2_SPLIT=1 switches back)
     bool gram_v2 = true;           // K1 through the LDS-DMA kernel when the shapes allow (CESX_GRAM_V1=1 switches back)
     int num_cus = 256;
     void* d_bias = nullptr;        // [rpad]
@@ -275,11 +283,21 @@ struct Engine {
     hipEvent_t ev = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;   // ev_c: side-stream centring done
     hipStream_t side = nullptr;      // side stream (high priority): U x U Gram, chol(C), the step's last small kernel
     hipStream_t bg = nullptr;        // background stream (low priority): noise blocks drawn ahead into idle CUs
-    hipEvent_t ev_x = nullptr;       // the prefetched noise block is complete (side stream)
+    hipEvent_t ev_x[2] = {nullptr, nullptr};   // prefetched noise block b is complete (side stream)
     hipEvent_t ev_in = nullptr, ev_k3 = nullptr, ev_m = nullptr;   // (spare)
-    void* d_xi = nullptr;            // [p][J] engine dtype: noise block drawn ahead by cesx_prefetch_noise
-    long long xi_step = -1;          // step index d_xi holds (-1: none)
-    long long xi_want = -1;          // step index asked for by cesx_prefetch_noise, drawn behind the next second Gram launch
+    // Noise blocks drawn ahead by cesx_prefetch_noise, [p][J] engine dtype each.  Two of them: behind chol(C) of the
+    // step that asked for block s the side stream draws block s (unless an earlier step already did) AND block s + 1
+    // (the lookahead), so that from the second step on the update kernel finds its block complete -- ordered before
+    // this step's chol(C) on the side stream, whose event the caller's stream waits for anyway -- and the draw of the
+    // next one runs beside K2's latency-bound kernels with nothing waiting for it.
+    void* d_xi[2] = {nullptr, nullptr};
+    long long xi_step[2] = {-1, -1};                 // step index block b holds (-1: none)
+    unsigned long long xi_seq[2] = {0, 0};           // chol_seq of the cesx_chol_async call that drew block b
+    long long xi_want = -1;          // step index asked for by cesx_prefetch_noise, drawn behind the next chol(C)
+    bool xi_lookahead = true;        // CESX_NOISE_LOOKAHEAD=0 switches the second draw off
+    unsigned long long chol_seq = 0;              // cesx_chol_async calls so far
+    unsigned long long evb_waited_seq = 0;        // ... the last one whose ev_b a stream has waited for,
+    hipStream_t evb_waited_stream = nullptr;      // and that stream
     int last_update_grid_x = 0, last_update_grid = 0, last_metric_parts = 0;
     bool pending = false;
     cesx_step_params last_prm{};

@@ -124,9 +124,15 @@ int finish_step(Engine& e, const cesx_step_params& prm, hipStream_t s) {
 const void* prefetched_noise(Engine& e, const cesx_step_params& prm, hipStream_t s) {
     // drawn on the side stream behind chol(C); its own event, waited for HERE (right before the update kernel):
     // K2's scalar and assemble kernels do not need the block and run beside the draw
-    if (!e.d_xi || e.xi_step != (long long)prm.step_index) return nullptr;
-    if (hipStreamWaitEvent(s, e.ev_x, 0) != hipSuccess) return nullptr;
-    return e.d_xi;
+    for (int b = 0; b < 2; ++b) {
+        if (!e.d_xi[b] || e.xi_step[b] != (long long)prm.step_index) continue;
+        // a block drawn behind an EARLIER chol(C) precedes this step's chol(C) on the side stream: a stream that has
+        // waited for this step's ev_b is already ordered behind the draw
+        const bool ordered = e.xi_seq[b] < e.evb_waited_seq && s == e.evb_waited_stream;
+        if (!ordered && hipStreamWaitEvent(s, e.ev_x[b], 0) != hipSuccess) return nullptr;
+        return e.d_xi[b];
+    }
+    return nullptr;
 }
 
 int run_update_main(Engine& e, const cesx_step_params& prm, const void* U, const void* G, const void* xi,
@@ -198,6 +204,7 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
     if (const char* ov = std::getenv("CESX_OVERLAP")) e.overlap_chol = ov[0] != '0';
     if (const char* uv = std::getenv("CESX_UPDATE_V1")) e.update_v2 = uv[0] == '0';
     if (const char* gv = std::getenv("CESX_GRAM_V1")) e.gram_v2 = gv[0] == '0';
+    if (const char* kv = std::getenv("CESX_K2_SPLIT")) e.k2_fused = kv[0] == '0';
     auto fail = [&](int rc) { g_create_err = e.err; cesx_destroy(reinterpret_cast<cesx_handle>(ep)); return rc; };
     int rc;
     DeviceGuard dg(cfg->device);
@@ -311,7 +318,8 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
         hipEventCreateWithFlags(&e.ev_in, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e.ev_k3, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e.ev_m, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e.ev_x, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e.ev_x[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e.ev_x[1], hipEventDisableTiming) != hipSuccess ||
         create_side_stream(e) != hipSuccess) {
         e.err = "pinned host buffer / event creation failed";
         return fail(CESX_EHIP);
@@ -358,11 +366,12 @@ void cesx_destroy(cesx_handle h) {
     if (e.ev_a) (void)hipEventDestroy(e.ev_a);
     if (e.ev_b) (void)hipEventDestroy(e.ev_b);
     if (e.ev_c) (void)hipEventDestroy(e.ev_c);
-    for (hipEvent_t ev : {e.ev_in, e.ev_k3, e.ev_m, e.ev_x})
+    for (hipEvent_t ev : {e.ev_in, e.ev_k3, e.ev_m, e.ev_x[0], e.ev_x[1]})
         if (ev) (void)hipEventDestroy(ev);
     if (e.side) (void)hipStreamDestroy(e.side);
     if (e.bg) (void)hipStreamDestroy(e.bg);
-    if (e.d_xi) (void)hipFree(e.d_xi);
+    for (void* q : e.d_xi)
+        if (q) (void)hipFree(q);
     delete &e;
 }
 
@@ -599,9 +608,9 @@ int cesx_prefetch_noise(cesx_handle h, uint64_t step_index, void* stream) {
     SET_DEVICE(e);
     (void)stream;
     if (std::getenv("CESX_NO_NOISE_PREFETCH")) return CESX_OK;
-    if (!e.d_xi) {
-        CESX_HIP(hipMalloc(&e.d_xi, (size_t)e.p * (size_t)e.J * e.esz));
-    }
+    e.xi_lookahead = !(std::getenv("CESX_NOISE_LOOKAHEAD") && std::atoi(std::getenv("CESX_NOISE_LOOKAHEAD")) == 0);
+    for (int b = 0; b < (e.xi_lookahead ? 2 : 1); ++b)
+        if (!e.d_xi[b]) CESX_HIP(hipMalloc(&e.d_xi[b], (size_t)e.p * (size_t)e.J * e.esz));
     // The draw itself is enqueued by cesx_chol_async on the side stream, behind chol(C): no extra
     // cross-stream event (each costs ~6 us of GPU idle time), and it runs while the caller's stream
     // is in the tail of the second Gram launch and the latency-bound start of K2.

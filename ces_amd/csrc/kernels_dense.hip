@@ -577,6 +577,35 @@ __global__ void whiten_diag_kernel(int n, const double* __restrict__ See, const 
 // ---------------------------------------------------------------------------
 // scalars: metrics, time step, pseudo-time
 // ---------------------------------------------------------------------------
+// the step's scalars from the three summed partials (trace of S_uu, |ubar - u*|^2, Frobenius term); returns hk
+__device__ __forceinline__ double step_hk(const cesx_step_params& prm, double N, double fr, double radspec) {
+    const double frob = sqrt(fr > 0.0 ? fr : 0.0) / N;
+    switch (prm.time_step) {
+        case CESX_TS_DEFAULT: return 1.0 / (frob + 1e-8);
+        case CESX_TS_SPECTRAL: return 1.0 / radspec;
+        case CESX_TS_CONSTANT: return prm.delta_t;
+        case CESX_TS_MIX: return (prm.t_len == 0 || prm.t_last < prm.spinup) ? 1.0 / (frob + 1e-8) : prm.delta_t;
+        default: return 0.0;
+    }
+}
+__device__ __forceinline__ void write_scalars(const cesx_step_params& prm, int p, double N, double tr, double b2,
+                                              double fr, Scalars* __restrict__ sc) {
+    sc->tr_suu = tr;
+    sc->self_bias = tr / N;
+    sc->bias = tr / N + b2;
+    sc->frob2 = fr;
+    sc->alpha = (p + 1.0) / N;
+    if (prm.update != CESX_UPDATE_ALDI_CONSTANT) {
+        const double hk = step_hk(prm, N, fr, sc->radspec);
+        sc->hk = hk;
+        sc->sqrt2hk = sqrt(2.0 * hk);
+        sc->t_new = prm.first_step ? hk : hk + prm.t_last;
+        bool kp = prm.time_step == CESX_TS_CONSTANT;
+        if (prm.update == CESX_UPDATE_ALDI && prm.time_step == CESX_TS_MIX && sc->t_new > 1.0) kp = true;
+        sc->spare[0] = kp ? 1.0 : 0.0;
+    }
+}
+
 // block 0: scalars; blocks 1..: the four matvecs K y, K gbar, M mu, M ubar (one wave per row)
 __global__ __launch_bounds__(DT)
 void scalar_kernel(MomView mv, cesx_step_params prm, const double* __restrict__ part,
@@ -607,30 +636,7 @@ void scalar_kernel(MomView mv, cesx_step_params prm, const double* __restrict__ 
     b2 = dblock_sum(b2, red);
     fr = dblock_sum(fr, red);
     if (tid != 0) return;
-    sc->tr_suu = tr;
-    sc->self_bias = tr / N;
-    sc->bias = tr / N + b2;
-    sc->frob2 = fr;
-    sc->alpha = (p + 1.0) / N;
-    const double frob = sqrt(fr > 0.0 ? fr : 0.0) / N;
-    double hk = 0.0;
-    if (prm.update != CESX_UPDATE_ALDI_CONSTANT) {
-        switch (prm.time_step) {
-            case CESX_TS_DEFAULT: hk = 1.0 / (frob + 1e-8); break;
-            case CESX_TS_SPECTRAL: hk = 1.0 / sc->radspec; break;
-            case CESX_TS_CONSTANT: hk = prm.delta_t; break;
-            case CESX_TS_MIX:
-                hk = (prm.t_len == 0 || prm.t_last < prm.spinup) ? 1.0 / (frob + 1e-8) : prm.delta_t;
-                break;
-            default: hk = 0.0;
-        }
-        sc->hk = hk;
-        sc->sqrt2hk = sqrt(2.0 * hk);
-        sc->t_new = prm.first_step ? hk : hk + prm.t_last;
-        bool kp = prm.time_step == CESX_TS_CONSTANT;
-        if (prm.update == CESX_UPDATE_ALDI && prm.time_step == CESX_TS_MIX && sc->t_new > 1.0) kp = true;
-        sc->spare[0] = kp ? 1.0 : 0.0;
-    }
+    write_scalars(prm, p, N, tr, b2, fr, sc);
 }
 
 // hk = 0.1 / max|drift| (ces/calibrate.py:519-523)
@@ -729,6 +735,91 @@ __global__ void assemble_kernel(int mode, int p, int n, int kp, int kn, int rpad
         const T st = (T)s;
         shiftT[i] = st;
         shift64[i] = (double)st;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// ALDI with the default / spectral time step: nothing sits between the scalar kernel and the assembly, so both run
+// as ONE launch (a kernel boundary costs 5-7 us here, more beside the noise draw).  Every workgroup sums the same
+// NPB partials in the same order -- the same hk everywhere, no grid-wide dependency; workgroups [0, nwb) write W
+// (and the vectors that need no matvec), the rest take one row i < p per wave: K_i . y, K_i . gbar, M_i . mu,
+// M_i . ubar -> bias_i and the next centring shift.  Same arithmetic, in the same order, as scalar_kernel +
+// assemble_kernel<T>(mode 0).
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(DT)
+void finish_aldi_kernel(MomView mv, cesx_step_params prm, const double* __restrict__ part, Scalars* __restrict__ sc,
+                        int nwb, int kp, int kn, int rpad, int ktot, const double* __restrict__ M,
+                        const double* __restrict__ K, const double* __restrict__ L, int ldl,
+                        const double* __restrict__ y, const double* __restrict__ gbar, const double* __restrict__ mu,
+                        const double* __restrict__ ubar, const double* __restrict__ gw, int mx, double* __restrict__ mvs,
+                        T* __restrict__ W, T* __restrict__ bias, T* __restrict__ shiftT, double* __restrict__ shift64,
+                        T* __restrict__ rowc, T* __restrict__ gbarT, float* __restrict__ Wf) {
+    static_assert(DT == NPB, "one partial per thread");
+    __shared__ double red[DT / 64];
+    const int p = mv.p, n = mv.n, tid = threadIdx.x;
+    const double N = mv.N();
+    const double tr = dblock_sum(part[tid * 4], red);
+    const double b2 = dblock_sum(part[tid * 4 + 1], red);
+    const double fr = dblock_sum(part[tid * 4 + 2], red);
+    const double hk = step_hk(prm, N, fr, sc->radspec), s2 = sqrt(2.0 * hk), al = (p + 1.0) / N;
+    if (blockIdx.x == 0 && tid == 0) write_scalars(prm, p, N, tr, b2, fr, sc);
+    if ((int)blockIdx.x >= nwb) {
+        const int i = ((int)blockIdx.x - nwb) * (DT / 64) + (tid >> 6), lane = tid & 63;
+        if (i >= p) return;
+        double ky = 0.0, kg = 0.0, mm = 0.0, mu_ = 0.0;
+        const double* Ki = K + (size_t)i * n;
+        const double* Mi = M + (size_t)i * p;
+        for (int c = lane; c < n; c += 64) { ky += Ki[c] * y[c]; kg += Ki[c] * gbar[c]; }
+        for (int c = lane; c < p; c += 64) { mm += Mi[c] * mu[c]; mu_ += Mi[c] * ubar[c]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            ky += __shfl_down(ky, o, 64); kg += __shfl_down(kg, o, 64);
+            mm += __shfl_down(mm, o, 64); mu_ += __shfl_down(mu_, o, 64);
+        }
+        if (lane == 0) {
+            mvs[i] = ky; mvs[(size_t)mx + i] = kg; mvs[(size_t)2 * mx + i] = mm; mvs[(size_t)3 * mx + i] = mu_;
+            bias[i] = (T)(hk * (ky + mm - al * ubar[i]));
+            const T st = (T)(ubar[i] + (-hk * (mu_ - mm) - hk * (kg - ky)));
+            shiftT[i] = st;
+            shift64[i] = (double)st;
+        }
+        return;
+    }
+    const long long idx = (long long)blockIdx.x * blockDim.x + tid;
+    if (idx < (long long)rpad * ktot) {
+        const int i = (int)(idx / ktot), k = (int)(idx % ktot);
+        double v = 0.0;
+        if (i < p) {
+            if (k < kp) {
+                if (k < p) v = (i == k ? 1.0 + hk * al : 0.0) - hk * M[(size_t)i * p + k];
+            } else if (k < kp + kn) {
+                const int c = k - kp;
+                if (c < n) v = -hk * K[(size_t)i * n + c];
+            } else {
+                const int c = k - kp - kn;
+                if (c < p && c <= i) v = s2 * L[(size_t)i * ldl + c];
+            }
+        }
+        W[idx] = (T)v;
+        if (Wf) {
+            if (sizeof(T) == 4) Wf[wf_index(i, k, ktot / 16)] = (float)v;
+            else reinterpret_cast<double*>(Wf)[wd_index(i, k, ktot / 16)] = v;
+        }
+    }
+    if (idx >= p && idx < rpad) bias[idx] = (T)0;
+    if (idx < kn) {
+        const int i = (int)idx;
+        rowc[i * 4 + 0] = (T)(i < n ? gbar[i] : 0.0);
+        rowc[i * 4 + 1] = (T)(i < n ? y[i] : 0.0);
+        rowc[i * 4 + 2] = (T)((i < n && gw != nullptr) ? gw[i] : 0.0);
+        rowc[i * 4 + 3] = (T)0;
+        if (i < n) gbarT[i] = (T)gbar[i];
+    }
+    if (idx >= p && idx < p + n) {
+        const T st = (T)gbar[idx - p];
+        shiftT[idx] = st;
+        shift64[idx] = (double)st;
     }
 }
 
@@ -1032,6 +1123,8 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
         if ((rc = potrf(e, s, p, e.d_C, e.d_L))) return rc;
     if (early) {
         CESX_HIP(hipStreamWaitEvent(s, e.ev_b, 0));
+        e.evb_waited_seq = e.chol_seq;
+        e.evb_waited_stream = s;
         e.chol_inflight = false;
     }
     if (!e.diag_gamma) {
@@ -1058,6 +1151,20 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
         hipLaunchKernelGGL(lanczos_kernel, dim3(1), dim3(DT), 0, s, n, e.d_t3, mom, msteps, e.d_lanczos,
                            lz, lz + msteps, lz + 2 * msteps, e.d_scal);
         CESX_HIP(hipGetLastError());
+    }
+    if (phase == 0 && prm.update == CESX_UPDATE_ALDI && e.k2_fused &&
+        (prm.time_step == CESX_TS_DEFAULT || prm.time_step == CESX_TS_SPECTRAL)) {
+        const int nwb = (int)(((long long)e.rpad * e.ktot + DT - 1) / DT), nvb = (p + DT / 64 - 1) / (DT / 64);
+        auto go = [&](auto tag) {
+            using T = decltype(tag);
+            hipLaunchKernelGGL(finish_aldi_kernel<T>, dim3(nwb + nvb), dim3(DT), 0, s, mv, prm, e.d_part, e.d_scal, nwb,
+                               e.kp, e.kn, e.rpad, e.ktot, e.d_M, e.d_K, e.d_L, potrf_ld(p), e.d_y, e.d_gbar, e.d_mu,
+                               e.d_ubar, e.diag_gamma ? e.d_gw : (const double*)nullptr, mx, e.d_mv, (T*)e.d_W,
+                               (T*)e.d_bias, (T*)e.d_shiftT, e.d_shift64, (T*)e.d_rowc, (T*)e.d_gbarT, (float*)e.d_Wf);
+        };
+        if (f32) go(float{}); else go(double{});
+        CESX_HIP(hipGetLastError());
+        return CESX_OK;
     }
     auto scalars_and_matvecs = [&]() {
         hipLaunchKernelGGL(scalar_kernel, dim3(1 + (4 * p + DT / 64 - 1) / (DT / 64)), dim3(DT), 0, s, mv, prm,
@@ -1120,10 +1227,24 @@ int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s) {
     int rc;
     if ((rc = potrf(e, e.side, p, e.d_C, e.d_L))) return rc;
     CESX_HIP(hipEventRecord(e.ev_b, e.side));      // C, M, ubar, L: what K2's scalar and assemble kernels read
-    if (e.xi_want >= 0 && e.d_xi) {                // noise block asked for by cesx_prefetch_noise: waited for only by K3
-        if ((rc = launch_noise(e, (uint64_t)e.xi_want, e.d_xi, e.side))) return rc;
-        CESX_HIP(hipEventRecord(e.ev_x, e.side));
-        e.xi_step = e.xi_want;
+    ++e.chol_seq;
+    if (e.xi_want >= 0 && e.d_xi[0]) {
+        // noise blocks asked for by cesx_prefetch_noise (cesx_internal.h): this step's, unless the lookahead of an
+        // earlier step drew it, then the next step's.  Nothing but the update kernel that reads a block waits for it.
+        auto draw = [&](long long step, int b) -> int {
+            if ((rc = launch_noise(e, (uint64_t)step, e.d_xi[b], e.side))) return rc;
+            CESX_HIP(hipEventRecord(e.ev_x[b], e.side));
+            e.xi_step[b] = step;
+            e.xi_seq[b] = e.chol_seq;
+            return CESX_OK;
+        };
+        int have = e.xi_step[0] == e.xi_want ? 0 : (e.d_xi[1] && e.xi_step[1] == e.xi_want) ? 1 : -1;
+        if (have < 0) {
+            have = 0;
+            if ((rc = draw(e.xi_want, 0))) return rc;
+        }
+        if (e.xi_lookahead && e.d_xi[1] && e.xi_step[have ^ 1] != e.xi_want + 1)
+            if ((rc = draw(e.xi_want + 1, have ^ 1))) return rc;
         e.xi_want = -1;
     }
     e.chol_inflight = true;

@@ -68,12 +68,13 @@ struct TileD {
     int ndma;            // DMAs one wave issues for it
 };
 
+template <bool NOISE>
 __device__ __forceinline__ TileD make_tile(int t, const Upd2Args& a) {
     // branch-free selects (a ternary chain over loaded values becomes a lookup table in scratch)
     const int b1 = t >= a.kt1 ? 1 : 0, b2 = t >= a.kt2 ? 1 : 0;
     TileD d;
     d.valid = t < a.nkt ? 1 : 0;
-    d.noise = (a.kind0 + b1 * (a.kind1 - a.kind0) + b2 * (a.kind2 - a.kind1)) != 0 ? 1 : 0;
+    d.noise = NOISE && (a.kind0 + b1 * (a.kind1 - a.kind0) + b2 * (a.kind2 - a.kind1)) != 0 ? 1 : 0;
     d.r0 = (t - (b1 * a.kt1 + b2 * (a.kt2 - a.kt1))) * U2_BK;
     d.rows = a.rows0 + b1 * (a.rows1 - a.rows0) + b2 * (a.rows2 - a.rows1);
     const long long p0 = (long long)a.src0, p1 = (long long)a.src1, p2 = (long long)a.src2;
@@ -105,6 +106,9 @@ __device__ __forceinline__ void noise_pair(uint32_t a, uint32_t b, float& z0, fl
     z1 = ra * __builtin_amdgcn_sinf(u1);
 }
 
+// NOISE = false: every K segment is read from memory (xi injected or drawn ahead); the Philox stages and their
+// branches are compiled out of the K loop
+template <bool NOISE>
 __global__ __launch_bounds__(U2_THREADS, 2)
 void update2_kernel(const Upd2Args a) {
     using acc_t = Mfma<float>::acc_t;
@@ -139,8 +143,12 @@ void update2_kernel(const Upd2Args a) {
     // this lane's column inside the tile, clamped for the ragged last workgroup (J % 4 == 0)
     long long colc = jt0 + 4 * li;
     if (colc > a.J - 4) colc = a.J - 4;
-    // fragment-major W: this lane's 16 bytes of piece 0 of tile 0; + t * 16 KiB + piece * 1 KiB
-    const char* const wlane = reinterpret_cast<const char*>(a.Wf) + ((size_t)blockIdx.y * nkt * 16) * 1024 + lane * 16;
+    // fragment-major W: piece 0 of tile 0 (wave-uniform); + t * 16 KiB + piece * 1 KiB + lane * 16
+    const char* const wlane = reinterpret_cast<const char*>(a.Wf) + ((size_t)blockIdx.y * nkt * 16) * 1024;
+    // per-lane byte offsets of the two [U; G; xi] pieces this wave issues per tile, from the tile's first row
+    const bool wide = a.J >= (1ll << 26);
+    const unsigned xoff0 = wide ? 0u : (unsigned)(((long long)(2 * wave + lh) * a.J + colc) * 4);
+    const unsigned xoff1 = wide ? 0u : (unsigned)(((long long)(2 * (wave + 4) + lh) * a.J + colc) * 4);
     const unsigned long long gj0 = (unsigned long long)(a.j_offset + jt0);
 
     // LDS byte addresses of the ring slots (wave-uniform), rotated with the tiles
@@ -151,19 +159,26 @@ void update2_kernel(const Upd2Args a) {
 
     // piece i of a tile (descriptor d, W image at wt) into ring slots (wsl, xsl):
     // i = 0, 1: rows 2q, 2q+1 of the [U; G] tile for q = wave + 4 i; i = 2..5: the W pieces
-    // (g, rb) = (0, rb0), (0, rb1), (1, rb0), (1, rb1) that this wave alone consumes
+    // (g, rb) = (0, rb0), (0, rb1), (1, rb0), (1, rb1) that this wave alone consumes.
+    // Addresses are scalar: a wave-uniform base (SGPR pair) + a per-lane byte offset fixed for the whole kernel
+    // (xoff0 / xoff1 / lane * 16); only a ragged last tile of a segment (rows clamped per lane) and ensembles
+    // of 2^26 particles or more take the per-lane 64-bit form.
 #define U2_PIECE(i, d, wt, wsl, xsl) do {                                                                   \
         if ((d).valid) {                                                                                    \
             if ((i) < 2) {                                                                                  \
                 if (!(d).noise && !(U2_ABL & 1)) {                                                          \
                     const int q_ = wave + 4 * (i);                                                          \
-                    int row_ = (d).r0 + 2 * q_ + lh;                                                        \
-                    row_ = row_ < (d).rows ? row_ : (d).rows - 1;   /* padded rows meet zero columns of W */ \
-                    glds16((d).base + (size_t)row_ * a.J + colc, (xsl) + q_ * 1024);                        \
+                    if ((d).r0 + U2_BK <= (d).rows && !wide) {                                              \
+                        glds16s((d).base + (size_t)(d).r0 * a.J, (i) == 0 ? xoff0 : xoff1, (xsl) + q_ * 1024); \
+                    } else {                                                                                \
+                        int row_ = (d).r0 + 2 * q_ + lh;                                                    \
+                        row_ = row_ < (d).rows ? row_ : (d).rows - 1;   /* padded rows meet zero columns of W */ \
+                        glds16((d).base + (size_t)row_ * a.J + colc, (xsl) + q_ * 1024);                    \
+                    }                                                                                       \
                 }                                                                                           \
             } else if (!(U2_ABL & 2)) {                                                                     \
                 const int piece_ = (((i) - 2) >> 1) * 8 + ((((i) - 2) & 1) ? rb1 : rb0);                    \
-                glds16((wt) + piece_ * 1024, (wsl) + piece_ * 1024);                                        \
+                glds16s((wt) + piece_ * 1024, lane * 16, (wsl) + piece_ * 1024);                            \
             }                                                                                               \
         }                                                                                                   \
     } while (0)
@@ -181,7 +196,7 @@ void update2_kernel(const Upd2Args a) {
     } while (0)
 
     // stage k (0..6) of the item of half `half` of the xi tile d (ring slot xsl), when `on`
-#define U2_NSTAGE(k, on, half, d, xsl, it) do { if (on) {                                                   \
+#define U2_NSTAGE(k, on, half, d, xsl, it) do { if (NOISE && (on)) {                                                   \
         const int item_ = tid + U2_THREADS * (half);                                                        \
         const int jl_ = item_ % U2_BN, ql_ = item_ / U2_BN;                                                 \
         if ((k) == 0) {                                                                                     \
@@ -231,11 +246,11 @@ void update2_kernel(const Upd2Args a) {
         __builtin_amdgcn_s_sleep(100);
         __builtin_amdgcn_s_sleep(100);
     }
-    TileD d0 = make_tile(0, a), d1 = make_tile(1, a);
+    TileD d0 = make_tile<NOISE>(0, a), d1 = make_tile<NOISE>(1, a);
     const char* wt = wlane;                       // W image of the tile being issued
 #pragma unroll
     for (int i = 0; i < 6; ++i) U2_PIECE(i, d0, wt, wsl0, xsl0);
-    if (d0.valid && d0.noise) { U2_NOISE(0, d0, xsl0); U2_NOISE(1, d0, xsl0); }
+    if (NOISE && d0.valid && d0.noise) { U2_NOISE(0, d0, xsl0); U2_NOISE(1, d0, xsl0); }
     wt += 16 * 1024;
 #pragma unroll
     for (int i = 0; i < 6; ++i) U2_PIECE(i, d1, wt, wsl1, xsl1);
@@ -248,7 +263,7 @@ void update2_kernel(const Upd2Args a) {
         f0a0 = *reinterpret_cast<const f4*>(U2_LDSP(wsl0) + rb0 * 1024 + lane * 16);
         f0a1 = *reinterpret_cast<const f4*>(U2_LDSP(wsl0) + rb1 * 1024 + lane * 16);
     }
-    if (d1.valid && d1.noise) U2_NOISE(0, d1, xsl1);
+    if (NOISE && d1.valid && d1.noise) U2_NOISE(0, d1, xsl1);
 
 #ifdef U2_CLOCKS
     clk_loop0 = clock64();
@@ -261,7 +276,7 @@ void update2_kernel(const Upd2Args a) {
         if (kt == a.kt2) clk_s2 = clock64();
 #endif
         wt += 16 * 1024;
-        const TileD d2 = make_tile(kt + 2, a);
+        const TileD d2 = make_tile<NOISE>(kt + 2, a);
         const bool intri = kt >= tri_t0 && kt < tri_t1;
         const bool need0 = on0 && (!intri || last0 >= d0.r0);
         const bool need1 = on1 && (!intri || last1 >= d0.r0);
@@ -279,19 +294,17 @@ void update2_kernel(const Upd2Args a) {
             f1a0 = *reinterpret_cast<const f4*>(Wt + (8 + rb0) * 1024 + lane * 16);
             f1a1 = *reinterpret_cast<const f4*>(Wt + (8 + rb1) * 1024 + lane * 16);
         }
-        if (kt >= met_t0 && kt < met_t1) {
-            // data metrics of the G tile in this slot: thread = (row t/32 + 8h, 4 particles)
+        // data metrics of the G tile in this slot: thread = (row t/32 + 8h, 4 particles).  The operands are read
+        // here, with the fragments; the arithmetic sits behind the first 16 MFMAs (their 1k cycles cover the LDS
+        // latency, so the wave does not stall on it with an idle matrix pipe)
+        const bool met = kt >= met_t0 && kt < met_t1;
+        f4 mx[2], mrc[2];
+        if (met) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int rr = (tid >> 5) + 8 * h;
-                const f4 x = *reinterpret_cast<const f4*>(Xt + rr * U2_BN + 4 * (tid & 31));
-                const f4 rc = *reinterpret_cast<const f4*>(sRowc + (size_t)(d0.r0 + rr) * 4);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float b = x[c] - rc[0], r = x[c] - rc[1];
-                    mq_e[c] += rc[2] * b * b;
-                    mq_r[c] += rc[2] * r * r;
-                }
+                mx[h] = *reinterpret_cast<const f4*>(Xt + rr * U2_BN + 4 * (tid & 31));
+                mrc[h] = *reinterpret_cast<const f4*>(sRowc + (size_t)(d0.r0 + rr) * 4);
             }
         }
         // first half: MFMAs of k-steps 0..3; in their shadow the DMAs of tile kt+2 and, stage by
@@ -308,6 +321,16 @@ void update2_kernel(const Upd2Args a) {
             U2_PIECE(2, d2, wt, wsl2, xsl2); U2_PIECE(3, d2, wt, wsl2, xsl2);
             U2_NSTAGE(0, g1, 1, d1, xsl1, it); U2_NSTAGE(1, g1, 1, d1, xsl1, it);
             U2_NSTAGE(2, g1, 1, d1, xsl1, it); U2_NSTAGE(3, g1, 1, d1, xsl1, it);
+        }
+        if (met) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float b = mx[h][c] - mrc[h][0], r = mx[h][c] - mrc[h][1];
+                    mq_e[c] += mrc[h][2] * b * b;
+                    mq_r[c] += mrc[h][2] * r * r;
+                }
         }
         if (need1) {
             U2_MFMA4(1, f0a1[0], f0b[0]); U2_PIECE(4, d2, wt, wsl2, xsl2); U2_NSTAGE(4, g1, 1, d1, xsl1, it);
@@ -494,13 +517,15 @@ int launch_update2(Engine& e, int out_rows, const void* Wf, int ktot, const void
     dim3 grid((unsigned)((e.J + U2_BN - 1) / U2_BN), (unsigned)((out_rows + U2_RC - 1) / U2_RC));
     // the dispatcher gives every CU one workgroup before any CU gets its second: from there on start late
     a.stagger_from = (long long)grid.x * grid.y > e.num_cus ? e.num_cus : 0x7fffffff;
-    CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(update2_kernel),
+    const bool noise = kind[0] != 0 || kind[1] != 0 || kind[2] != 0;
+    auto kern = noise ? update2_kernel<true> : update2_kernel<false>;
+    CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     e.last_update_grid_x = (int)grid.x;
     e.last_update_grid = (int)(grid.x * grid.y);
     {
         ProfScope prof(e, opt.prof, s);
-        hipLaunchKernelGGL(update2_kernel, grid, dim3(U2_THREADS), lds, s, a);
+        hipLaunchKernelGGL(kern, grid, dim3(U2_THREADS), lds, s, a);
     }
     CESX_HIP(hipGetLastError());
     return CESX_OK;

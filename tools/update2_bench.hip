@@ -68,11 +68,11 @@ int main(int argc, char** argv) {
     auto kern = (J % 4 == 0) ? update_kernel<float, true, UpdCfg<float>::WC> : update_kernel<float, false, UpdCfg<float>::WC>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     const int lds2 = U2_RING * (U2_WSLOT + U2_XSLOT) + kn * 16;
-    CK(hipFuncSetAttribute((const void*)update2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+    CK(hipFuncSetAttribute((const void*)update2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
     CK(hipMemset(out, 0, (size_t)p * J * 4)); CK(hipMemset(out2, 0xff, (size_t)p * J * 4));
     hipLaunchKernelGGL(kern, grid, dim3(UPD_THREADS), lds, 0, a);
     CK(hipDeviceSynchronize());
-    hipLaunchKernelGGL(update2_kernel, grid, dim3(U2_THREADS), lds2, 0, b);
+    hipLaunchKernelGGL(update2_kernel<true>, grid, dim3(U2_THREADS), lds2, 0, b);
     CK(hipDeviceSynchronize());
     {
         std::vector<float> h1((size_t)p * J), h2((size_t)p * J);
@@ -96,9 +96,9 @@ int main(int argc, char** argv) {
         }
     }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(update2_kernel, grid, dim3(U2_THREADS), lds2, 0, b);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(update2_kernel<true>, grid, dim3(U2_THREADS), lds2, 0, b);
     hipEventRecord(e0);
-    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(update2_kernel, grid, dim3(U2_THREADS), lds2, 0, b);
+    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(update2_kernel<true>, grid, dim3(U2_THREADS), lds2, 0, b);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
 #ifdef U2_CLOCKS
