@@ -371,6 +371,49 @@ void gram_reduce_kernel(const T* __restrict__ slabs, const int* __restrict__ blk
 // ---------------------------------------------------------------------------
 // host: work partition
 // ---------------------------------------------------------------------------
+// Cycles one J tile costs a workgroup of a type with `blocks` blocks over `row_blocks` staged block rows: the MFMAs of
+// its busiest SIMD (blocks / 4 SIMDs, 64 cycles per MFMA, tile-width / k MFMAs per block) plus the part that does
+// not shrink with the block count -- staging the type's rows and the barrier.  Constants fitted to in-kernel cycle
+// stamps of the LDS-DMA kernel (tools/gram2_bench.hip, f32 and f64 types of 11 ... 121 blocks): 1.055 x the MFMA
+// cycles, 3 cycles per staged row (DMA issue, the in-place shift pass), 450 per tile (barrier, loop).
+static double gram_tile_cost(int tile, int blocks, int row_blocks) {
+    const double mfma_cyc = tile == 32 ? 16 * 64.0 : 4 * 64.0;      // f32: 32 j / k=2; f64: 16 j / k=4
+    return 1.055 * mfma_cyc * (double)((blocks + 3) / 4) + 450.0 + 3.0 * (double)(row_blocks * tile);
+}
+
+// Slices per type that level the launch: whole tiles per slice, the busiest workgroup (tiles x cost per tile) as
+// light as the workgroup budget allows.  Returns that workgroup's cycles.
+static double gram_level_slices(const std::vector<double>& w, int budget, long long ntiles, std::vector<int>& nsl) {
+    const int nt = (int)w.size();
+    nsl.assign(nt, 1);
+    if (ntiles <= 0) return 0.0;
+    auto need = [&](double T, std::vector<int>* out) {
+        long long total = 0;
+        for (int t = 0; t < nt; ++t) {
+            const long long tps = (long long)std::floor(T / w[t] + 1e-9);
+            if (tps < 1) return (long long)1 << 40;
+            const long long n_ = (ntiles + tps - 1) / tps;
+            if (out) (*out)[t] = (int)n_;
+            total += n_;
+        }
+        return total;
+    };
+    // candidates: k tiles of some type
+    double lo = 0.0, hi = 0.0;
+    for (int t = 0; t < nt; ++t) hi = std::max(hi, w[t] * (double)ntiles);
+    if (need(hi, nullptr) > budget) {          // fewer workgroups than types cannot happen (budget >= nt): one slice each
+        return hi;
+    }
+    for (int it = 0; it < 60; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        if (need(mid, nullptr) <= budget) hi = mid; else lo = mid;
+    }
+    need(hi, &nsl);
+    double worst = 0.0;
+    for (int t = 0; t < nt; ++t) worst = std::max(worst, w[t] * (double)((ntiles + nsl[t] - 1) / nsl[t]));
+    return worst;
+}
+
 GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset, int pbU, int min_types,
                         int wg_budget, long long ntiles) {
     GramPlan pl;
@@ -397,9 +440,49 @@ GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset, 
         // takes what is left
         int per = std::max(1, ((int)all.size() + nt - 1) / nt);
         if (per > 4) per = std::min(cap / 4 * 4, (per + 3) / 4 * 4);
-        for (size_t lo = 0; lo < all.size(); lo += per) {
-            std::vector<std::pair<int, int>> v(all.begin() + lo, all.begin() + std::min(all.size(), lo + (size_t)per));
+        std::vector<int> sizes;
+        for (size_t lo = 0; lo < all.size(); lo += per) sizes.push_back((int)std::min(all.size() - lo, (size_t)per));
+        // ... unless another split of the same number of runs packs the launch better: tiles per slice are whole
+        // numbers (at C2 two runs of 52 + 48 blocks over 248 workgroups end at 16 and 18 tiles per slice, the
+        // second 7 % above the mean; 44 + 56 end at 19 and 15, level).  Two- and three-run plans are searched in
+        // steps of 4 blocks with the cost model below.
+        if (sizes.size() >= 2 && sizes.size() <= 3 && !std::getenv("CESX_GRAM_EQUAL_RUNS")) {
+            const int nb_all = (int)all.size();
+            auto eval = [&](const std::vector<int>& sz) {
+                std::vector<double> w;
+                int lo = 0;
+                for (int n_ : sz) {
+                    std::set<int> rws;
+                    for (int q = lo; q < lo + n_; ++q) { rws.insert(all[q].first); rws.insert(all[q].second); }
+                    w.push_back(gram_tile_cost(tile, n_, (int)rws.size()));
+                    lo += n_;
+                }
+                std::vector<int> ns;
+                return gram_level_slices(w, std::max(wg_budget, (int)sz.size()), ntiles, ns);
+            };
+            double best = eval(sizes);
+            std::vector<int> cand(sizes.size());
+            for (int a = 4; a <= std::min(cap, nb_all - 4); a += 4) {
+                if (sizes.size() == 2) {
+                    cand = {a, nb_all - a};
+                    if (cand[1] > cap) continue;
+                    const double c = eval(cand);
+                    if (c < best * 0.995) { best = c; sizes = cand; }
+                } else {
+                    for (int b = 4; b <= std::min(cap, nb_all - a - 4); b += 4) {
+                        cand = {a, b, nb_all - a - b};
+                        if (cand[2] > cap) continue;
+                        const double c = eval(cand);
+                        if (c < best * 0.995) { best = c; sizes = cand; }
+                    }
+                }
+            }
+        }
+        size_t lo = 0;
+        for (int n_ : sizes) {
+            std::vector<std::pair<int, int>> v(all.begin() + lo, all.begin() + lo + n_);
             types.push_back(v);
+            lo += n_;
         }
     } else {
         // rectangles a x b of blocks with (a + b) * tile rows staged
@@ -425,19 +508,18 @@ GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset, 
     // (16 B per lane-store, ~80 B/clk/CU) and the barrier.  Largest-remainder rounding within the
     // workgroup budget; never more slices than J tiles.
     std::vector<int> nsl(pl.ntypes, 1);
-    {
-        const double mfma_cyc = tile == 32 ? 16 * 64.0 : 4 * 64.0;      // f32: 32 j / k=2; f64: 16 j / k=4
-        std::vector<double> w(pl.ntypes);
-        double total = 0.0;
-        for (int t = 0; t < pl.ntypes; ++t) {
-            std::set<int> rws;
-            for (auto& rc : types[t]) { rws.insert(rc.first); rws.insert(rc.second); }
-            // constants fitted to in-kernel cycle stamps of the LDS-DMA kernel (tools/gram2_bench.hip, f32 and
-            // f64 types of 11 ... 121 blocks): 1.055 x the MFMA cycles, 3 cycles per staged row (DMA issue, the
-            // in-place shift pass), 450 per tile (barrier, loop)
-            w[t] = 1.055 * mfma_cyc * (double)((types[t].size() + 3) / 4) + 450.0 + 3.0 * (double)(rws.size() * tile);
-            total += w[t];
-        }
+    std::vector<double> w(pl.ntypes);
+    double total = 0.0;
+    for (int t = 0; t < pl.ntypes; ++t) {
+        std::set<int> rws;
+        for (auto& rc : types[t]) { rws.insert(rc.first); rws.insert(rc.second); }
+        w[t] = gram_tile_cost(tile, (int)types[t].size(), (int)rws.size());
+        total += w[t];
+    }
+    if (pl.ntypes <= 4 && !std::getenv("CESX_GRAM_PROPORTIONAL")) {
+        // few types, many slices each: whole tiles per slice, levelled (gram_level_slices)
+        gram_level_slices(w, std::max(wg_budget, pl.ntypes), ntiles, nsl);
+    } else {
         const int budget = std::max(wg_budget, pl.ntypes);
         // Types of (nearly) the same cost get the SAME number of slices, a multiple of 8 when there
         // are that many: slice k of every such type then covers the same J range on the same XCD

@@ -3,14 +3,20 @@
 // :429/:461/:503 and np.cov(Geval) :440/:472 all factor through Z Z^T), fed the way
 // K3 (kernels_update2.hip) is fed:
 //
-//  * raw rows of U / G go global -> LDS by DMA (global_load_lds_dwordx4), one piece = 8 rows x 128 B
-//    (a whole 128-B line per row and instruction: fully coalesced).  No staging registers, no
+//  * raw rows of U / G go global -> LDS by DMA (global_load_lds_dwordx4).  No staging registers, no
 //    ds_write pass, no subtract-and-store pass.
-//  * a DMA writes its 64 x 16 B contiguously (lds_base + 16 lane), so rows sit 128 B apart in LDS --
-//    a 4-way bank conflict for 16-byte fragment reads of 16 different rows.  The conflict is removed
-//    at the SOURCE: the lane that fills chunk c' of row r fetches global chunk c' ^ ((r >> 1) & 7),
-//    a permutation inside the row's 128-B line (coalescing unchanged); readers apply the same XOR.
-//    Every 16-lane group of a ds_read_b128 then covers all 64 banks exactly once (f32 and f64 maps).
+//  * LDS layout of a tile: one PANEL per k-group g (the 8 / 16 particles one fragment read covers), a panel row
+//    = the CP 16-byte chunks of that group (f32: 2 chunks = 32 B, f64: 4 = 64 B), rows TILE-block by TILE-block:
+//    byte (g, row, chunk c) = g * PANEL + row * CP * 16 + c * 16.  One DMA piece (64 lanes x 16 B, written
+//    contiguously at lds_base + 16 lane) is exactly one block row of one panel; its lanes fetch 32- / 64-byte
+//    segments of TILE different rows (the 4 / 2 pieces of a block row together read whole 128-B lines).
+//    PANEL is a compile-time stride, so the k-group enters a fragment read as the IMMEDIATE offset of the
+//    ds_read and the address registers depend on the block only: 2 address adds per block and tile instead of
+//    2 per block and k-group (every VALU instruction in this loop is taken from the f32 MFMA rate).
+//  * bank conflicts are removed at the SOURCE: the lane that fills physical chunk c' of row r fetches logical
+//    chunk c' ^ swz(r), swz(r) = (r / RPB) % CP with RPB = rows per 256 B; readers apply the same XOR (it
+//    depends on the lane only, not on g).  Every 16-lane group of a ds_read_b128 then covers all 64 banks
+//    exactly once (f32 and f64 maps).
 //  * the f32-input MFMA runs on the SIMD's f32 vector lanes: every VALU instruction in the K loop takes
 //    its issue cycles away from the matrix pipe (tools/mfma_rate.hip: 64.0 cycles per MFMA with LDS-fed
 //    operands, 72 with two v_sub per MFMA at 4 waves per SIMD, 89 at one).  So the centring shift is NOT
@@ -34,8 +40,12 @@ constexpr int G2_WAVES = G2_THREADS / 64;
 constexpr int G2_ROWB = 128;               // bytes of one row in a tile: 32 f32 / 16 f64
 constexpr int G2_MAX_ROWS = 512;           // = MAX_STAGE_ROWS of kernels_gram.hip (the plans are shared)
 constexpr int G2_MAXP = G2_MAX_ROWS / 8 / G2_WAVES;      // DMA pieces per wave and tile (4)
+constexpr int G2_SLOT = G2_MAX_ROWS * G2_ROWB;           // one tile in LDS: 64 KiB, a compile-time stride
 #ifndef G2_ABL      // timing ablations (tools/gram2_bench.hip); results are wrong when set
 #define G2_ABL 0
+#endif
+#ifndef G2_SHIFT_AT
+#define G2_SHIFT_AT 1
 #endif
 #ifdef G2_CLOCKS
 __device__ long long g_gram2_clk[4096 * 4];
@@ -54,7 +64,12 @@ void gram2_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __r
     constexpr int TILE = M::TILE, VEC = M::VEC, NBW = GramCfg<T>::NBW;
     constexpr int KT = G2_ROWB / (int)sizeof(T);         // particles per tile
     constexpr int KL = 64 / TILE;                        // lane groups of a fragment read (k sub-blocks)
-    constexpr int NGROUP = 8 / KL;                       // fragment reads per row and tile
+    constexpr int NGROUP = 8 / KL;                       // fragment reads per row and tile (k-groups)
+    constexpr int CP = KL;                               // 16-byte chunks of one k-group per row
+    constexpr int PROW = CP * 16;                        // bytes of a panel row
+    constexpr int PANEL = G2_MAX_ROWS * PROW;            // f32 16 KiB, f64 32 KiB
+    constexpr int RPB = 256 / PROW;                      // rows per 256 B of a panel
+    static_assert(NGROUP * PANEL == G2_SLOT && TILE * PROW == 1024, "one DMA piece = one block row of one panel");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef G2_CLOCKS
@@ -71,7 +86,6 @@ void gram2_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __r
     const int slab0 = hdr[6], rs0 = hdr[7];
     const int nrows = nrb * TILE;
     const int P = p + n;
-    const int slot_bytes = nrows * G2_ROWB;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(
         (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
 
@@ -102,8 +116,8 @@ void gram2_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __r
 
     // per staged row: source pointer and shift.  Rows past P (padding of the last block row) read row 0
     // of U: their products land in rows / columns the reduce never reads.
-    const T** rowptr = reinterpret_cast<const T**>(smem + 2 * slot_bytes);
-    T* rowshift = reinterpret_cast<T*>(smem + 2 * slot_bytes + nrows * 8);
+    const T** rowptr = reinterpret_cast<const T**>(smem + 2 * G2_SLOT);
+    T* rowshift = reinterpret_cast<T*>(smem + 2 * G2_SLOT + G2_MAX_ROWS * 8);
     for (int row = tid; row < nrows; row += G2_THREADS) {
         const int gr = (rows_tab[rows_off + row / TILE] & 0xffff) * TILE + row % TILE;
         const T* ptr = U;
@@ -117,25 +131,27 @@ void gram2_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __r
     }
     __syncthreads();
 
-    // DMA pieces of this wave: piece q = wave + 16 i covers rows 8q .. 8q+7; lane = (row in piece, chunk).
-    // Per-lane source pointers live in registers and advance by one tile per issue (one 64-bit add per
-    // piece and tile: every VALU instruction in this loop is taken from the MFMA rate).
-    const int npieces = nrows >> 3;
-    const int prow = lane >> 3;
+    // DMA pieces of this wave: piece q = wave + 16 i = (block row q / NGROUP, k-group q % NGROUP);
+    // lane = (row of the block row, physical chunk).  Per-lane source pointers live in registers and advance by
+    // one tile per issue (one 64-bit add per piece and tile).
+    const int npieces = nrb * NGROUP;
+    const int prow = lane / CP, pch = lane % CP;
     const T* gsrc[G2_MAXP];
+    int poff[G2_MAXP];                                     // LDS byte offset of the piece inside a slot (wave-uniform)
 #pragma unroll
     for (int i = 0; i < G2_MAXP; ++i) {
         const int q = wave + G2_WAVES * i;
-        const int row = q < npieces ? 8 * q + prow : 0;
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);            // the swizzle (see the header)
-        gsrc[i] = rowptr[row] + t0 * KT + chunk * VEC;
+        const int rb = q < npieces ? q / NGROUP : 0, g = q % NGROUP;
+        const int chunk = g * CP + (pch ^ ((prow / RPB) % CP));      // the swizzle (see the header)
+        gsrc[i] = rowptr[rb * TILE + prow] + t0 * KT + chunk * VEC;
+        poff[i] = g * PANEL + rb * 1024;
     }
     auto issue_tile = [&](int slot) {
 #pragma unroll
         for (int i = 0; i < G2_MAXP; ++i) {
             const int q = wave + G2_WAVES * i;
             if (q < npieces) {
-                if (!(G2_ABL & 1)) glds16(gsrc[i], lds0 + slot * slot_bytes + q * 1024);
+                if (!(G2_ABL & 1)) glds16(gsrc[i], lds0 + slot * G2_SLOT + poff[i]);
                 gsrc[i] += KT;
             }
         }
@@ -146,16 +162,16 @@ void gram2_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __r
 #pragma unroll
     for (int i = 0; i < G2_MAXP; ++i) {
         const int q = wave + G2_WAVES * i;
-        psh[i] = q < npieces ? rowshift[8 * q + prow] : (T)0;
+        psh[i] = q < npieces ? rowshift[(q / NGROUP) * TILE + prow] : (T)0;
         rs[i] = 0;
     }
     auto shift_tile = [&](int slot) {
-        char* sb = smem + slot * slot_bytes + lane * 16;
+        char* sb = smem + slot * G2_SLOT + lane * 16;
         vec_t v[G2_MAXP];
 #pragma unroll
         for (int i = 0; i < G2_MAXP; ++i) {
             const int q = wave + G2_WAVES * i;
-            if (q < npieces) v[i] = *reinterpret_cast<const vec_t*>(sb + q * 1024);
+            if (q < npieces) v[i] = *reinterpret_cast<const vec_t*>(sb + poff[i]);
         }
 #pragma unroll
         for (int i = 0; i < G2_MAXP; ++i) {
@@ -163,18 +179,15 @@ void gram2_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __r
             if (q < npieces) {
 #pragma unroll
                 for (int c = 0; c < VEC; ++c) { v[i][c] -= psh[i]; rs[i] += v[i][c]; }
-                *reinterpret_cast<vec_t*>(sb + q * 1024) = v[i];
+                *reinterpret_cast<vec_t*>(sb + poff[i]) = v[i];
             }
         }
     };
 
-    // fragment reads: lane = (k sub-block lk, row li of the block); group g reads chunk KL g + lk of the
-    // row, XOR-swizzled: byte offset foff0 ^ (g * KL * 16)  (KL g has no bit in common with lk)
+    // fragment reads: lane = (k sub-block lk, row li of the block) reads physical chunk lk ^ swz(li) of its panel
+    // row; the k-group is the immediate offset g * PANEL
     const int li = lane % TILE, lk = lane / TILE;
-    const int foff0 = li * G2_ROWB + ((lk ^ ((li >> 1) & 7)) << 4);
-    int foff[NGROUP];
-#pragma unroll
-    for (int g = 0; g < NGROUP; ++g) foff[g] = foff0 ^ (g * KL * 16);
+    const int foff0 = li * PROW + ((lk ^ ((li / RPB) % CP)) << 4);
 
     // One (block, group) step: VEC MFMAs on fragments that were loaded one step earlier.  The loads of
     // the NEXT step are issued first (sched_barrier keeps them there), so every LDS read has VEC MFMAs
@@ -186,10 +199,15 @@ void gram2_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __r
             for (int v = 0; v < VEC; ++v) { f.a[v] = (T)(lane + v + b); f.c[v] = (T)(lane - v + g); }
             return;
         }
-        f.a = *reinterpret_cast<const vec_t*>(base + (iab[b] & 0xff) * (TILE * G2_ROWB) + foff[g]);
-        f.c = *reinterpret_cast<const vec_t*>(base + (iab[b] >> 8) * (TILE * G2_ROWB) + foff[g]);
+        f.a = *reinterpret_cast<const vec_t*>(base + (iab[b] & 0xff) * 1024 + foff0 + g * PANEL);
+        f.c = *reinterpret_cast<const vec_t*>(base + (iab[b] >> 8) * 1024 + foff0 + g * PANEL);
     };
 
+    // After which of its blocks a wave shifts its pieces of the next tile.  The SIMD issues the oldest wave first:
+    // waves 0-3 run ahead and wait at the tile's barrier while 12-15 still multiply, so a shift pass placed
+    // early in EVERY wave's own instruction stream lies in the middle of the tile in wall time for all but the
+    // oldest (whose wait for the DMA is covered by the others' MFMAs); placed last it is exposed for the youngest.
+    const int shift_at = __builtin_amdgcn_readfirstlane(G2_SHIFT_AT < 0 ? ((wave >> 2) + 1) * NBW / 4 : G2_SHIFT_AT);
     if (t0 < t1) {
         issue_tile(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -203,11 +221,20 @@ void gram2_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __r
     for (long long t = t0; t < t1; ++t) {
         const int cur = (int)((t - t0) & 1);
         if (t + 1 < t1) issue_tile(cur ^ 1);
-        const char* base = smem + cur * slot_bytes;
+        const char* base = smem + cur * G2_SLOT;
         Frag f0, f1;
         if (nb > 0) load_frag(f0, base, 0, 0);
 #pragma unroll
         for (int b = 0; b < NBW; ++b) {
+            // This wave's pieces of tile t+1 (issued at the top of the tile, landed long since) are shifted in
+            // place BETWEEN two of its blocks, at a different point for each of the 4 waves of a SIMD: the
+            // LDS round trip of one wave's shift pass is covered by the MFMAs of the other three, instead of
+            // all 16 waves running it together behind their last MFMA with the matrix pipes idle.
+            if (b == shift_at && t + 1 < t1) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (!(G2_ABL & 8)) shift_tile(cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (b < nb) {
 #pragma unroll
                 for (int g = 0; g < NGROUP; ++g) {
@@ -226,16 +253,15 @@ void gram2_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __r
                 }
             }
         }
+        if (shift_at == NBW && t + 1 < t1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(G2_ABL & 8)) shift_tile(cur ^ 1);
+        }
         static_assert(NGROUP % 2 == 0, "the fragment double buffer returns to f0 at every block boundary");
 #ifdef G2_CLOCKS
         const long long tb0 = clock64();
 #endif
-        // this wave's pieces of tile t+1 have landed: shift them in place; then the tile's one barrier
-        // (every wave has read slot `cur`, every piece of tile t+1 is shifted)
-        if (t + 1 < t1) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (!(G2_ABL & 8)) shift_tile(cur ^ 1);
-        }
+        // the tile's one barrier (every wave has read slot `cur`, every piece of tile t+1 is shifted)
         if (!(G2_ABL & 2)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #ifdef G2_CLOCKS
         gbar += clock64() - tb0;
@@ -245,19 +271,25 @@ void gram2_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __r
     const long long gclk2 = clock64();
 #endif
 
-    // first moments of this slice: the 8 lanes that share a row are adjacent; chunk 0's lane reports.
-    // Only the type that owns a block row reports it.
+    // first moments of this slice: a row's 8 chunks sit in CP adjacent lanes of NGROUP different waves; combined
+    // through LDS (the tile slots are idle now) in a fixed order.  Only the type that owns a block row reports it.
+    {
+        double* rsum = reinterpret_cast<double*>(smem);            // [nrows][NGROUP]
 #pragma unroll
-    for (int i = 0; i < G2_MAXP; ++i) {
-        const int q = wave + G2_WAVES * i;
-        double v = (double)rs[i];
-        v += __shfl_xor(v, 1, 64);
-        v += __shfl_xor(v, 2, 64);
-        v += __shfl_xor(v, 4, 64);
-        if (q < npieces && (lane & 7) == 0) {
-            const int row = 8 * q + prow;
+        for (int i = 0; i < G2_MAXP; ++i) {
+            const int q = wave + G2_WAVES * i;
+            double v = (double)rs[i];
+#pragma unroll
+            for (int o = 1; o < CP; o <<= 1) v += __shfl_xor(v, o, 64);
+            if (q < npieces && pch == 0) rsum[((q / NGROUP) * TILE + prow) * NGROUP + q % NGROUP] = v;
+        }
+        __syncthreads();
+        for (int row = tid; row < nrows; row += G2_THREADS) {
             const int ent = rows_tab[rows_off + row / TILE];
             const int gr = (ent & 0xffff) * TILE + row % TILE;
+            double v = 0.0;
+#pragma unroll
+            for (int g = 0; g < NGROUP; ++g) v += rsum[row * NGROUP + g];
             if ((ent >> 16) != 0 && gr < P) rowsum_part[(size_t)(rs0 + slice) * P + gr] = v;
         }
     }
@@ -293,8 +325,8 @@ static int launch_gram2_t(Engine& e, int part, const void* U, const void* G, hip
     constexpr int KT = G2_ROWB / (int)sizeof(T);
     if (e.J % KT != 0 || e.J < KT || ((uintptr_t)U & 15) || ((uintptr_t)G & 15)) return -1;
     const int nrows = pl.max_rb * pl.tile;
-    if (nrows > G2_MAX_ROWS || (nrows & 7)) return -1;
-    const int lds = 2 * nrows * G2_ROWB + nrows * 8 + nrows * (int)sizeof(T);
+    if (nrows > G2_MAX_ROWS) return -1;
+    const int lds = 2 * G2_SLOT + G2_MAX_ROWS * 8 + G2_MAX_ROWS * (int)sizeof(T);
     auto kern = gram2_kernel<T>;
     CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     {

@@ -30,7 +30,7 @@ int run(int subset, int budget, int p, int n, long long J) {
     hipMemcpy(wblk, pl.wblk.data(), pl.wblk.size() * 4, hipMemcpyHostToDevice);
     const int nrows = pl.max_rb * tile;
     const int lds1 = 2 * nrows * ROW_STRIDE + nrows * 16;
-    const int lds2 = 2 * nrows * G2_ROWB + nrows * 8 + nrows * (int)sizeof(T);
+    const int lds2 = 2 * G2_SLOT + G2_MAX_ROWS * 8 + G2_MAX_ROWS * (int)sizeof(T);
     auto k1 = gram_kernel<T, true>;
     auto k2 = gram2_kernel<T>;
     hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
