@@ -263,6 +263,7 @@ struct Engine {
     void* d_Wf = nullptr;          // the same matrix in the fragment-major order of kernels_update2.hip (fp32) / kernels_update3.hip (fp64)
     bool update_v2 = true;         // fp32 K3 through the LDS-DMA kernel (CESX_UPDATE_V1=1 switches back)
     int  center_u_wgs = 256;       // workgroups of the U-only centring on the side stream (see cesx_create)
+    bool ext_events = true;        // hand-over events bound to kernels' own completion signals (CESX_EXT_EVENTS=0: separate markers)
     bool k2_fused = true;          // ALDI, default / spectral time step: scalar + assemble kernels as one launch (CESX_K2_SPLIT=1 switches back)
     bool gram_v2 = true;           // K1 through the LDS-DMA kernel when the shapes allow (CESX_GRAM_V1=1 switches back)
     int num_cus = 256;
@@ -316,11 +317,11 @@ struct UpdateSrc {            // one K-segment of the update GEMM
 int launch_colsum(Engine& e, const void* U, const void* G, double* sums, hipStream_t s);
 int launch_set_shift(Engine& e, const double* sums, hipStream_t s);
 int launch_gram(Engine& e, int part, const void* U, const void* G, double* mom, hipStream_t s, bool no_reduce = false);   // part 0 / 1
-int launch_gram_reduce(Engine& e, int part, double* mom, hipStream_t s);   // the fp64 slab reduce of that launch
+int launch_gram_reduce(Engine& e, int part, double* mom, hipStream_t s, hipEvent_t stop = nullptr);   // the fp64 slab reduce of that launch (stop: bound to its completion)
 // kernels_gram2.hip (LDS-DMA Gram): CESX_OK, an error, or -1 when the launch does not qualify (caller falls back)
 int launch_gram2(Engine& e, int part, const void* U, const void* G, hipStream_t s);
 int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int phase, hipStream_t s);
-int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s);
+int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s, bool ev_a_bound = false);
 struct UpdateOpt {
     int ldw = 0;          // row stride of W (0: = ktot)
     int metric_seg = 1;   // K-segment that holds G (data metrics)

@@ -205,6 +205,7 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
     if (const char* uv = std::getenv("CESX_UPDATE_V1")) e.update_v2 = uv[0] == '0';
     if (const char* gv = std::getenv("CESX_GRAM_V1")) e.gram_v2 = gv[0] == '0';
     if (const char* kv = std::getenv("CESX_K2_SPLIT")) e.k2_fused = kv[0] == '0';
+    if (const char* xv = std::getenv("CESX_EXT_EVENTS")) e.ext_events = xv[0] != '0';
     auto fail = [&](int rc) { g_create_err = e.err; cesx_destroy(reinterpret_cast<cesx_handle>(ep)); return rc; };
     int rc;
     DeviceGuard dg(cfg->device);
@@ -453,6 +454,24 @@ int cesx_chol_async(cesx_handle h, int update, const double* mom, void* stream) 
     return launch_chol_async(e, update, mom, (hipStream_t)stream);
 }
 
+int cesx_moments_uu_chol(cesx_handle h, int update, const void* U, const void* G, double* mom, void* stream) {
+    if (!h) return CESX_EINVAL;
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    TRY(moments_check(e, U, G, mom));
+    if (update < 0 || update > 2) { e.err = "cesx_moments_uu_chol: bad argument"; return CESX_EINVAL; }
+    SET_DEVICE(e);
+    hipStream_t s = (hipStream_t)stream;
+    if (s == e.side || !e.ext_events) {
+        TRY(launch_gram(e, 0, U, G, mom, s));
+        return launch_chol_async(e, update, mom, s);
+    }
+    // nothing can sit between the reduce of the U x U launch and the hand-over to the side stream: the hand-over
+    // event is the reduce kernel's own completion signal, no marker packet in front of the second Gram launch
+    TRY(launch_gram(e, 0, U, G, mom, s, true));
+    TRY(launch_gram_reduce(e, 0, mom, s, e.ev_a));
+    return launch_chol_async(e, update, mom, s, true);
+}
+
 int cesx_moments_rest(cesx_handle h, const void* U, const void* G, double* mom, void* stream) {
     if (!h) return CESX_EINVAL;
     Engine& e = *reinterpret_cast<Engine*>(h);
@@ -546,8 +565,8 @@ int cesx_step(cesx_handle h, const cesx_step_params* prm, const void* U, const v
     if (!xi && e.overlap_chol) TRY(cesx_prefetch_noise(h, prm->step_index, stream));
     // U x U moments -> chol(C) on the side stream, beside the rest of the Gram -> apply.  (Putting the
     // U x U launch itself on the side stream too was measured slower: see ces_amd/dist.py.)
-    TRY(cesx_moments_uu(h, U, G, e.d_mom, stream));
-    if (e.overlap_chol) TRY(cesx_chol_async(h, prm->update, e.d_mom, stream));
+    if (e.overlap_chol) TRY(cesx_moments_uu_chol(h, prm->update, U, G, e.d_mom, stream));
+    else TRY(cesx_moments_uu(h, U, G, e.d_mom, stream));
     TRY(cesx_moments_rest(h, U, G, e.d_mom, stream));
     return cesx_apply(h, prm, e.d_mom, U, G, xi, Unext, stream);
 }

@@ -9,6 +9,7 @@
 //   assembly of W, b for the K3 update GEMM     :443-447, :484-488, :515-527
 // p, n are a few hundred: these kernels are latency bound, not roofline bound.
 #include "cesx_internal.h"
+#include <hip/hip_ext.h>
 
 namespace cesx {
 
@@ -872,10 +873,15 @@ static int gemm(Engine& e, hipStream_t s, int m, int n, int k, double alpha, con
 }
 
 template <int SLOTS>
-static int potrf_reg_launch(Engine& e, hipStream_t s, int n, int np, const double* A, double* Lp, int lda = 0, int ldl = 0) {
+static int potrf_reg_launch(Engine& e, hipStream_t s, int n, int np, const double* A, double* Lp, int lda = 0, int ldl = 0,
+                            hipEvent_t stop = nullptr) {      // stop: event bound to this kernel's own completion signal
     const size_t lds = (size_t)4 * QNB * (np + 4) * 8;       // panel x 2, its negative, zeros
     CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_reg_kernel<SLOTS>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (stop)
+        hipExtLaunchKernelGGL(potrf_reg_kernel<SLOTS>, dim3(1), dim3(PRT), (unsigned)lds, s, nullptr, stop, 0, n, np, A, Lp,
+                              &e.d_scal->status, (long long*)nullptr, lda, ldl);
+    else
     hipLaunchKernelGGL(potrf_reg_kernel<SLOTS>, dim3(1), dim3(PRT), lds, s, n, np, A, Lp, &e.d_scal->status, (long long*)nullptr,
                        lda, ldl);
     CESX_HIP(hipGetLastError());
@@ -986,12 +992,13 @@ __global__ void pad_copy_kernel(int n, int np, const double* __restrict__ A, dou
 // potrf_ld(n) = n rounded up to 32; entries above the diagonal are undefined).
 int potrf_ld(int n) { return (n + PNB - 1) / PNB * PNB; }
 
-static int potrf_reg_any(Engine& e, hipStream_t s, int n, int np, const double* A, double* Lp, int lda, int ldl) {
+static int potrf_reg_any(Engine& e, hipStream_t s, int n, int np, const double* A, double* Lp, int lda, int ldl,
+                         hipEvent_t stop = nullptr) {
     const int T = np / 16, ntile = T * (T + 1) / 2, slots = (ntile + 7) / 8;
-    if (slots <= 2) return potrf_reg_launch<2>(e, s, n, np, A, Lp, lda, ldl);       // np <= 64
-    if (slots <= 5) return potrf_reg_launch<5>(e, s, n, np, A, Lp, lda, ldl);       // np <= 128
-    if (slots <= 10) return potrf_reg_launch<10>(e, s, n, np, A, Lp, lda, ldl);     // np <= 192
-    if (slots <= 17) return potrf_reg_launch<17>(e, s, n, np, A, Lp, lda, ldl);     // np <= 256
+    if (slots <= 2) return potrf_reg_launch<2>(e, s, n, np, A, Lp, lda, ldl, stop);       // np <= 64
+    if (slots <= 5) return potrf_reg_launch<5>(e, s, n, np, A, Lp, lda, ldl, stop);       // np <= 128
+    if (slots <= 10) return potrf_reg_launch<10>(e, s, n, np, A, Lp, lda, ldl, stop);     // np <= 192
+    if (slots <= 17) return potrf_reg_launch<17>(e, s, n, np, A, Lp, lda, ldl, stop);     // np <= 256
     e.err = "potrf: diagonal block too large for the register kernel";
     return CESX_EINVAL;
 }
@@ -1008,9 +1015,20 @@ static int trsm_reg(Engine& e, hipStream_t s, int nr, int nc, const double* A, i
     return CESX_OK;
 }
 
-static int potrf(Engine& e, hipStream_t s, int n, const double* A, double* Lp) {
+// stop (optional): an event to complete with the factorisation.  One-kernel factorisations bind it to the kernel's own
+// completion signal (hipExtLaunchKernel: no separate marker packet on the stream -- a marker costs ~6 us before the
+// next kernel of the stream starts); the blocked path records it behind its last kernel.
+static int potrf(Engine& e, hipStream_t s, int n, const double* A, double* Lp, hipEvent_t stop = nullptr) {
     const int np = potrf_ld(n);
-    if (np <= 256) return potrf_reg_any(e, s, n, np, A, Lp, 0, 0);
+    if (np <= 256) {
+        if (stop && !e.ext_events) {
+            int rc0 = potrf_reg_any(e, s, n, np, A, Lp, 0, 0);
+            if (rc0) return rc0;
+            CESX_HIP(hipEventRecord(stop, s));
+            return CESX_OK;
+        }
+        return potrf_reg_any(e, s, n, np, A, Lp, 0, 0, stop);
+    }
     // Blocked right-looking factorisation with 256-wide diagonal blocks (p > 256): register
     // Cholesky of the diagonal block, register TRSM of the rows below it (64 rows per
     // workgroup), fp64 GEMM for the trailing update -- on a work copy bordered by the identity.
@@ -1032,6 +1050,7 @@ static int potrf(Engine& e, hipStream_t s, int n, const double* A, double* Lp) {
             CESX_HIP(hipGetLastError());
         }
     }
+    if (stop) CESX_HIP(hipEventRecord(stop, s));
     return CESX_OK;
 }
 
@@ -1208,14 +1227,14 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
 // U-only part of K2, started as soon as the U x U part of the moments is complete (and, on
 // several devices, all-reduced): C = S_uu / div + 1e-8 I, M, ubar, then chol(C) on the engine's
 // side stream.  cesx_apply joins it right before W is assembled.
-int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s) {
+int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s, bool ev_a_bound) {
     const int p = e.p, n = e.n;
     MomView mv{p, n, mom};
     const int unbiased = update == CESX_UPDATE_EKS ? 0 : 1;
     // the whole U-only part of K2 (centre, C, M, then chol(C)) goes to the side stream: the main
     // stream continues with the second Gram launch straight after the U x U reduce
     if (s != e.side) {                             // (a caller already on the side stream needs no hand-over)
-        CESX_HIP(hipEventRecord(e.ev_a, s));
+        if (!ev_a_bound) CESX_HIP(hipEventRecord(e.ev_a, s));      // (bound: ev_a is the U x U reduce kernel's own signal)
         CESX_HIP(hipStreamWaitEvent(e.side, e.ev_a, 0));
     }
     // (few workgroups -> 1024 threads each: 8 x 256 threads took 25 us for the 65 k elements of C, latency bound)
@@ -1225,8 +1244,7 @@ int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s) {
                        e.d_m, e.d_dg, e.d_C, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_M, e.d_part, e.d_scal);
     CESX_HIP(hipGetLastError());
     int rc;
-    if ((rc = potrf(e, e.side, p, e.d_C, e.d_L))) return rc;
-    CESX_HIP(hipEventRecord(e.ev_b, e.side));      // C, M, ubar, L: what K2's scalar and assemble kernels read
+    if ((rc = potrf(e, e.side, p, e.d_C, e.d_L, e.ev_b))) return rc;      // ev_b: C, M, ubar, L -- what K2's scalar and assemble kernels read
     ++e.chol_seq;
     if (e.xi_want >= 0 && e.d_xi[0]) {
         // noise blocks asked for by cesx_prefetch_noise (cesx_internal.h): this step's, unless the lookahead of an

@@ -16,6 +16,7 @@
 //     fp64 in a fixed order (deterministic, no float atomics).
 // Bound: MFMA (f32 MFMA issues at the f32 vector rate on gfx950).
 #include "cesx_internal.h"
+#include <hip/hip_ext.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -652,12 +653,18 @@ static int launch_gram_t(Engine& e, int part, const void* U, const void* G, hipS
 }
 
 template <typename T>
-static int launch_gram_reduce_t(Engine& e, int part, double* mom, hipStream_t s) {
+static int launch_gram_reduce_t(Engine& e, int part, double* mom, hipStream_t s, hipEvent_t stop) {
     GramPart& gp = e.gp[part];
     const GramPlan& pl = gp.plan;
     const long long ngroups = (long long)pl.nblocks * pl.tile * pl.tile / Mfma<T>::VEC;
     const int row_lo = std::min(pl.own_lo * pl.tile, e.p + e.n), row_hi = std::min(pl.own_hi * pl.tile, e.p + e.n);
     const long long wgs = (ngroups + RED_G - 1) / RED_G + std::max(1, (row_hi - row_lo + RED_G - 1) / RED_G);
+    if (stop)
+        hipExtLaunchKernelGGL(gram_reduce_kernel<T>, dim3((unsigned)wgs), dim3(256), 0, s, nullptr, stop, 0,
+                              (const T*)gp.d_slabs, (const int*)gp.d_blk_rc, (const int*)gp.d_row_own, pl.nblocks, pl.tile, e.ml,
+                              (long long)e.J, row_lo, row_hi, part == 0 ? 1 : 0, (const double*)gp.d_rowsum_part,
+                              part == 1 ? (const double*)e.d_metric_sums : (const double*)nullptr, mom);
+    else
     hipLaunchKernelGGL(gram_reduce_kernel<T>, dim3((unsigned)wgs), dim3(256), 0, s,
                        (const T*)gp.d_slabs, gp.d_blk_rc, gp.d_row_own, pl.nblocks, pl.tile, e.ml,
                        (long long)e.J, row_lo, row_hi, part == 0 ? 1 : 0, gp.d_rowsum_part,
@@ -666,8 +673,8 @@ static int launch_gram_reduce_t(Engine& e, int part, double* mom, hipStream_t s)
     return CESX_OK;
 }
 
-int launch_gram_reduce(Engine& e, int part, double* mom, hipStream_t s) {
-    return e.cfg.dtype == CESX_F32 ? launch_gram_reduce_t<float>(e, part, mom, s) : launch_gram_reduce_t<double>(e, part, mom, s);
+int launch_gram_reduce(Engine& e, int part, double* mom, hipStream_t s, hipEvent_t stop) {
+    return e.cfg.dtype == CESX_F32 ? launch_gram_reduce_t<float>(e, part, mom, s, stop) : launch_gram_reduce_t<double>(e, part, mom, s, stop);
 }
 
 int launch_gram(Engine& e, int part, const void* U, const void* G, double* mom, hipStream_t s, bool no_reduce) {

@@ -47,6 +47,7 @@ struct Upd2Args {
     const float* rowc; double* metric_part; int metric_seg;
     int tri_seg;
     int stagger_from;     // workgroups with a linear index >= this start late (see the kernel)
+    int stagger_n;        // ... by this many s_sleep(100) = 6.4k cycles each
 };
 
 // wait until at most `n` of this wave's DMAs are outstanding, retire its LDS traffic, barrier
@@ -242,10 +243,8 @@ void update2_kernel(const Upd2Args a) {
     // amount of work, so without this they all reach the 128-KiB store epilogue together and the
     // matrix pipes idle while HBM drains; staggered, one workgroup's stores (and barrier / staging
     // stalls) are covered by the other's MFMAs (-3 % at C2).
-    if ((int)(blockIdx.y * gridDim.x + blockIdx.x) >= a.stagger_from) {
-        __builtin_amdgcn_s_sleep(100);
-        __builtin_amdgcn_s_sleep(100);
-    }
+    if ((int)(blockIdx.y * gridDim.x + blockIdx.x) >= a.stagger_from)
+        for (int i = 0; i < a.stagger_n; ++i) __builtin_amdgcn_s_sleep(100);
     TileD d0 = make_tile<NOISE>(0, a), d1 = make_tile<NOISE>(1, a);
     const char* wt = wlane;                       // W image of the tile being issued
 #pragma unroll
@@ -517,6 +516,8 @@ int launch_update2(Engine& e, int out_rows, const void* Wf, int ktot, const void
     dim3 grid((unsigned)((e.J + U2_BN - 1) / U2_BN), (unsigned)((out_rows + U2_RC - 1) / U2_RC));
     // the dispatcher gives every CU one workgroup before any CU gets its second: from there on start late
     a.stagger_from = (long long)grid.x * grid.y > e.num_cus ? e.num_cus : 0x7fffffff;
+    a.stagger_n = 2;
+    if (const char* sv = std::getenv("CESX_U2_STAGGER")) a.stagger_n = std::atoi(sv);
     const bool noise = kind[0] != 0 || kind[1] != 0 || kind[2] != 0;
     auto kern = noise ? update2_kernel<true> : update2_kernel<false>;
     CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

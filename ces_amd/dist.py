@@ -127,6 +127,9 @@ class ShardedUpdate:
             with torch.cuda.stream(self._cs):
                 self._all_reduce(mom[:nuu])          # N, sum(u - s), S_aa: all chol(C) needs
                 eng.chol_async(prm, mom)
+        elif self.world == 1 and not self._force_collectives and hasattr(eng, "moments_uu_chol"):
+            eng.moments_uu_chol(prm, U, G, out=mom)  # no collective between the two: one call, no marker packet
+            eng.moments_rest(U, G, mom)
         else:
             eng.moments_uu(U, G, out=mom)
             self._all_reduce(mom[:nuu])

@@ -185,6 +185,10 @@ int cesx_moments(cesx_handle h, const void* U_dev, const void* G_dev, double* mo
 int cesx_moments_uu(cesx_handle h, const void* U_dev, const void* G_dev, double* mom_dev, void* stream);
 int cesx_chol_async(cesx_handle h, int update, const double* mom_dev, void* stream);
 int cesx_moments_rest(cesx_handle h, const void* U_dev, const void* G_dev, double* mom_dev, void* stream);
+/* cesx_moments_uu + cesx_chol_async in one call, for an ensemble on ONE device (no all-reduce between the two):
+   the hand-over to the side stream is then the U x U reduce kernel's own completion signal instead of a marker
+   packet in front of the second Gram launch (~6 us per step at C2).  Same results as the two calls. */
+int cesx_moments_uu_chol(cesx_handle h, int update, const void* U_dev, const void* G_dev, double* mom_dev, void* stream);
 
 /* The engine's side stream (a hipStream_t).  A sharded driver issues the all-reduce of the
    leading part of the moment buffer on it (and then calls cesx_chol_async with it as
