@@ -1,6 +1,7 @@
 // Internal declarations shared by the HIP translation units of libcesx.so.
 // gfx950 (MI355X / CDNA4) only.
 #pragma once
+#include <cstddef>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
@@ -199,6 +200,49 @@ struct Scalars {              // device-resident fp64 scalars written by K2
     unsigned long long seq;   // host copy only: step counter written last by publish_kernel
 };
 
+// Finalisation of a step's data metrics and publication of its scalars to the host: the fixed-order fp64 sum of the
+// update kernel's per-workgroup partials (sums[0..1] = sum over workgroups of {q_r^2, q_e^2}), this shard's
+// contribution to the two data metrics (divided by the GLOBAL ensemble size), from the tail of the all-reduced moment
+// buffer the previous step's global values (multi-device runs), then -- host != nullptr -- the copy of the scalars
+// into the host-mapped result block, its sequence number last.  Run by ONE workgroup of 256 threads: the
+// metric_final kernel, or (single-device fast path) an extra workgroup of the NEXT step's U x U reduce launch, so
+// that no one-workgroup kernel sits between the update kernel and the next Gram launch.
+struct MetricFin {
+    const double* part; int nparts; const double* mom; size_t tail_off; double* sums; Scalars* sc;
+    Scalars* host; unsigned long long seq;
+    double N;            // > 0: the global ensemble size (else read from mom[0])
+};
+__device__ __forceinline__ void metric_final_body(const MetricFin& f) {
+    __shared__ double mf_red[2][4];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < f.nparts; i += blockDim.x) { a += f.part[(size_t)i * 2]; b += f.part[(size_t)i * 2 + 1]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b += __shfl_down(b, o, 64); }
+    if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 4) { mf_red[0][threadIdx.x >> 6] = a; mf_red[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = 0.0; b = 0.0;
+        for (int i = 0; i < (int)(blockDim.x >> 6) && i < 4; ++i) { a += mf_red[0][i]; b += mf_red[1][i]; }
+        const double N = f.N > 0.0 ? f.N : f.mom[0];
+        f.sums[0] = a; f.sums[1] = b;
+        f.sc->bias_data = a / N;
+        f.sc->self_bias_data = b / N;
+        f.sc->spare[1] = f.mom[f.tail_off] / N;          // lagged global bias-data
+        f.sc->spare[2] = f.mom[f.tail_off + 1] / N;      // lagged global self-bias-data
+    }
+    if (f.host == nullptr) return;
+    // last kernel of an eks / aldi step: publish the results (see publish_kernel)
+    __threadfence();
+    __syncthreads();
+    const double* src = reinterpret_cast<const double*>(f.sc);
+    double* dst = reinterpret_cast<double*>(f.host);
+    constexpr int ND = offsetof(Scalars, seq) / 8;
+    if (threadIdx.x < ND) dst[threadIdx.x] = __hip_atomic_load(&src[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&f.host->seq, f.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 struct Engine {
     cesx_config cfg{};
     std::string err;
@@ -301,6 +345,11 @@ struct Engine {
     hipStream_t evb_waited_stream = nullptr;      // and that stream
     int last_update_grid_x = 0, last_update_grid = 0, last_metric_parts = 0;
     bool pending = false;
+    // single-device fast path: the metric finalisation + publication of the last update rides on the next
+    // U x U reduce launch (cesx_moments_uu_chol); every other entry point flushes it as a kernel of its own first
+    bool met_deferred = false, met_defer_ok = true;      // CESX_DEFER_PUBLISH=0 switches the deferral off
+    hipStream_t met_stream = nullptr;
+    const double* met_mom = nullptr;
     cesx_step_params last_prm{};
 };
 
@@ -317,7 +366,7 @@ struct UpdateSrc {            // one K-segment of the update GEMM
 int launch_colsum(Engine& e, const void* U, const void* G, double* sums, hipStream_t s);
 int launch_set_shift(Engine& e, const double* sums, hipStream_t s);
 int launch_gram(Engine& e, int part, const void* U, const void* G, double* mom, hipStream_t s, bool no_reduce = false);   // part 0 / 1
-int launch_gram_reduce(Engine& e, int part, double* mom, hipStream_t s, hipEvent_t stop = nullptr);   // the fp64 slab reduce of that launch (stop: bound to its completion)
+int launch_gram_reduce(Engine& e, int part, double* mom, hipStream_t s, hipEvent_t stop = nullptr, const MetricFin* fin = nullptr);   // the fp64 slab reduce of that launch (stop: bound to its completion)
 // kernels_gram2.hip (LDS-DMA Gram): CESX_OK, an error, or -1 when the launch does not qualify (caller falls back)
 int launch_gram2(Engine& e, int part, const void* U, const void* G, hipStream_t s);
 int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int phase, hipStream_t s);
@@ -366,6 +415,7 @@ __host__ __device__ inline size_t wd_index(int i, int k, int nkt) {
 }
 int launch_data_metrics(Engine& e, const void* G, hipStream_t s);   // dense Gamma: separate pass
 int launch_metric_final(Engine& e, const double* mom, bool publish, hipStream_t s);
+MetricFin metric_fin_args(Engine& e, const double* mom, bool publish);     // (publish: takes the next sequence number)
 int launch_publish(Engine& e, hipStream_t s);
 int launch_absmax_final(Engine& e, int nparts, double* absmax_out, hipStream_t s);
 int potrf_ld(int n);

@@ -154,6 +154,14 @@ int finish_metrics(Engine& e, const double* mom, const void* G, bool publish, hi
     return launch_metric_final(e, mom, publish, s);
 }
 
+// the deferred metric finalisation + publication of the last update (Engine::met_deferred), as a kernel of its own
+int flush_metrics(Engine& e) {
+    if (!e.met_deferred) return CESX_OK;
+    e.met_deferred = false;
+    return launch_metric_final(e, e.met_mom, true, e.met_stream);
+}
+#define FLUSH(e) TRY(flush_metrics(e))
+
 }  // namespace
 
 extern "C" {
@@ -206,6 +214,7 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
     if (const char* gv = std::getenv("CESX_GRAM_V1")) e.gram_v2 = gv[0] == '0';
     if (const char* kv = std::getenv("CESX_K2_SPLIT")) e.k2_fused = kv[0] == '0';
     if (const char* xv = std::getenv("CESX_EXT_EVENTS")) e.ext_events = xv[0] != '0';
+    if (const char* dv = std::getenv("CESX_DEFER_PUBLISH")) e.met_defer_ok = dv[0] != '0';
     auto fail = [&](int rc) { g_create_err = e.err; cesx_destroy(reinterpret_cast<cesx_handle>(ep)); return rc; };
     int rc;
     DeviceGuard dg(cfg->device);
@@ -382,6 +391,7 @@ int cesx_set_problem(cesx_handle h, const double* y, const double* Gamma, const 
     Engine& e = *reinterpret_cast<Engine*>(h);
     if (!y || !Gamma || !mu || !Sigma || !ustar) { e.err = "cesx_set_problem: null pointer"; return CESX_EINVAL; }
     SET_DEVICE(e);
+    FLUSH(e);
     const int p = e.p, n = e.n;
     std::vector<double> L, Li, inv;
     if (!host_chol(n, Gamma, L)) { e.err = "Gamma is not symmetric positive definite"; return CESX_ENOTPD; }
@@ -419,6 +429,7 @@ int cesx_colsum(cesx_handle h, const void* U, const void* G, double* sums, void*
     Engine& e = *reinterpret_cast<Engine*>(h);
     if (!U || !G || !sums) { e.err = "cesx_colsum: null pointer"; return CESX_EINVAL; }
     SET_DEVICE(e);
+    FLUSH(e);
     return launch_colsum(e, U, G, sums, (hipStream_t)stream);
 }
 
@@ -427,6 +438,7 @@ int cesx_set_shift(cesx_handle h, const double* sums, void* stream) {
     Engine& e = *reinterpret_cast<Engine*>(h);
     if (!sums) { e.err = "cesx_set_shift: null pointer"; return CESX_EINVAL; }
     SET_DEVICE(e);
+    FLUSH(e);
     return launch_set_shift(e, sums, (hipStream_t)stream);
 }
 
@@ -442,6 +454,7 @@ int cesx_moments_uu(cesx_handle h, const void* U, const void* G, double* mom, vo
     Engine& e = *reinterpret_cast<Engine*>(h);
     TRY(moments_check(e, U, G, mom));
     SET_DEVICE(e);
+    FLUSH(e);
     return launch_gram(e, 0, U, G, mom, (hipStream_t)stream);
 }
 
@@ -451,6 +464,7 @@ int cesx_chol_async(cesx_handle h, int update, const double* mom, void* stream) 
     if (!mom || update < 0 || update > 2) { e.err = "cesx_chol_async: bad argument"; return CESX_EINVAL; }
     if (!e.problem_set) { e.err = "cesx_set_problem has not been called"; return CESX_ESTATE; }
     SET_DEVICE(e);
+    FLUSH(e);
     return launch_chol_async(e, update, mom, (hipStream_t)stream);
 }
 
@@ -462,13 +476,22 @@ int cesx_moments_uu_chol(cesx_handle h, int update, const void* U, const void* G
     SET_DEVICE(e);
     hipStream_t s = (hipStream_t)stream;
     if (s == e.side || !e.ext_events) {
+        FLUSH(e);
         TRY(launch_gram(e, 0, U, G, mom, s));
         return launch_chol_async(e, update, mom, s);
     }
+    if (e.met_deferred && e.met_stream != s) FLUSH(e);
     // nothing can sit between the reduce of the U x U launch and the hand-over to the side stream: the hand-over
     // event is the reduce kernel's own completion signal, no marker packet in front of the second Gram launch
     TRY(launch_gram(e, 0, U, G, mom, s, true));
-    TRY(launch_gram_reduce(e, 0, mom, s, e.ev_a));
+    if (e.met_deferred) {
+        MetricFin f = metric_fin_args(e, e.met_mom, true);
+        f.N = (double)e.Jg;
+        e.met_deferred = false;
+        TRY(launch_gram_reduce(e, 0, mom, s, e.ev_a, &f));
+    } else {
+        TRY(launch_gram_reduce(e, 0, mom, s, e.ev_a));
+    }
     return launch_chol_async(e, update, mom, s, true);
 }
 
@@ -477,6 +500,7 @@ int cesx_moments_rest(cesx_handle h, const void* U, const void* G, double* mom, 
     Engine& e = *reinterpret_cast<Engine*>(h);
     TRY(moments_check(e, U, G, mom));
     SET_DEVICE(e);
+    FLUSH(e);
     // (the reduce kernel of this launch also copies this shard's data-metric sums of the PREVIOUS
     //  apply to the tail of the buffer: they ride on this step's all-reduce)
     return launch_gram(e, 1, U, G, mom, (hipStream_t)stream);
@@ -494,6 +518,7 @@ int cesx_apply_drift(cesx_handle h, const cesx_step_params* prm, const double* m
     TRY(check_prm(e, prm));
     if (!mom || !U || !G || !Unext || !absmax) { e.err = "cesx_apply_drift: null pointer"; return CESX_EINVAL; }
     SET_DEVICE(e);
+    FLUSH(e);
     hipStream_t s = (hipStream_t)stream;
     TRY(launch_dense(e, *prm, mom, 1, s));
     UpdateSrc src[2] = {{U, e.p, 0, 0}, {G, e.n, 0, 0}};
@@ -514,6 +539,7 @@ int cesx_apply_finish(cesx_handle h, const cesx_step_params* prm, const double* 
     TRY(check_prm(e, prm));
     if (!absmax || !U || !Unext) { e.err = "cesx_apply_finish: null pointer"; return CESX_EINVAL; }
     SET_DEVICE(e);
+    FLUSH(e);
     hipStream_t s = (hipStream_t)stream;
     if (absmax != e.d_absmax) CESX_HIP(hipMemcpyAsync(e.d_absmax, absmax, 8, hipMemcpyDeviceToDevice, s));
     TRY(launch_dense(e, *prm, nullptr, 2, s));
@@ -539,12 +565,19 @@ int cesx_apply(cesx_handle h, const cesx_step_params* prm, const double* mom, co
         return cesx_apply_finish(h, prm, e.d_absmax, U, xi, Unext, stream);
     }
     SET_DEVICE(e);
+    FLUSH(e);
     hipStream_t s = (hipStream_t)stream;
     TRY(launch_dense(e, *prm, mom, 0, s));
     TRY(run_update_main(e, *prm, U, G, xi, Unext, s));
     // (Moving this last small kernel to the side stream was tried: the event record + wait pair costs
     //  as much GPU idle time as the 7 us kernel itself.)
-    TRY(finish_metrics(e, mom, G, true, s));     // also publishes the step result to the host
+    if (e.met_defer_ok && e.ext_events && e.overlap_chol && e.diag_gamma && e.J == e.Jg) {
+        // one device: the finalisation rides on the next step's U x U reduce launch (cesx_moments_uu_chol) -- no
+        // one-workgroup kernel (7 us) between this update and the next Gram launch; anything else flushes it
+        e.met_deferred = true; e.met_stream = s; e.met_mom = mom;
+    } else {
+        TRY(finish_metrics(e, mom, G, true, s));     // also publishes the step result to the host
+    }
     e.pending = true;
     e.last_prm = *prm;
     return CESX_OK;
@@ -576,6 +609,10 @@ int cesx_result(cesx_handle h, cesx_step_result* out) {
     Engine& e = *reinterpret_cast<Engine*>(h);
     if (!out) { e.err = "cesx_result: null pointer"; return CESX_EINVAL; }
     if (!e.pending) { e.err = "cesx_result: no step has been enqueued"; return CESX_ESTATE; }
+    if (e.met_deferred) {
+        SET_DEVICE(e);
+        FLUSH(e);
+    }
     // Wait for the sequence number the GPU writes last into pinned memory.  A step is a few
     // hundred microseconds, so the first 100 us are a pause-spin (lowest latency); after that the
     // thread yields its core, and from 2 ms on it sleeps in 100 us slices -- a long wait (large
@@ -718,6 +755,7 @@ int cesx_debug_dense(cesx_handle h, double* ubar, double* gbar, double* C, doubl
     if (!h) return CESX_EINVAL;
     Engine& e = *reinterpret_cast<Engine*>(h);
     SET_DEVICE(e);
+    FLUSH(e);
     CESX_HIP(hipDeviceSynchronize());
     const size_t p = e.p, n = e.n;
     if (ubar) CESX_HIP(hipMemcpy(ubar, e.d_ubar, p * 8, hipMemcpyDeviceToHost));

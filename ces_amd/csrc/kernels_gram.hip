@@ -273,9 +273,11 @@ __global__ __launch_bounds__(256)
 void gram_reduce_kernel(const T* __restrict__ slabs, const int* __restrict__ blk_rc, const int* __restrict__ row_own,
                         int nblocks, int tile, MomLayout ml, long long J, int row_lo, int row_hi,
                         int write_N, const double* __restrict__ rowsum_part, const double* __restrict__ tail_src,
-                        double* __restrict__ mom) {
+                        double* __restrict__ mom, const MetricFin fin) {
     using vec_t = typename Mfma<T>::vec_t;
     constexpr int VEC = Mfma<T>::VEC;
+    // the previous update's metric finalisation + publication, riding on this launch as one extra workgroup
+    if (fin.part != nullptr && blockIdx.x == gridDim.x - 1) { metric_final_body(fin); return; }
     const int p = ml.p, n = ml.n;
     __shared__ double part[RED_S][RED_G][VEC];
     const int tt = tile * tile;
@@ -653,28 +655,30 @@ static int launch_gram_t(Engine& e, int part, const void* U, const void* G, hipS
 }
 
 template <typename T>
-static int launch_gram_reduce_t(Engine& e, int part, double* mom, hipStream_t s, hipEvent_t stop) {
+static int launch_gram_reduce_t(Engine& e, int part, double* mom, hipStream_t s, hipEvent_t stop, const MetricFin* fin) {
     GramPart& gp = e.gp[part];
     const GramPlan& pl = gp.plan;
     const long long ngroups = (long long)pl.nblocks * pl.tile * pl.tile / Mfma<T>::VEC;
     const int row_lo = std::min(pl.own_lo * pl.tile, e.p + e.n), row_hi = std::min(pl.own_hi * pl.tile, e.p + e.n);
-    const long long wgs = (ngroups + RED_G - 1) / RED_G + std::max(1, (row_hi - row_lo + RED_G - 1) / RED_G);
+    const long long wgs = (ngroups + RED_G - 1) / RED_G + std::max(1, (row_hi - row_lo + RED_G - 1) / RED_G) + (fin ? 1 : 0);
+    const MetricFin f = fin ? *fin : MetricFin{};
     if (stop)
         hipExtLaunchKernelGGL(gram_reduce_kernel<T>, dim3((unsigned)wgs), dim3(256), 0, s, nullptr, stop, 0,
                               (const T*)gp.d_slabs, (const int*)gp.d_blk_rc, (const int*)gp.d_row_own, pl.nblocks, pl.tile, e.ml,
                               (long long)e.J, row_lo, row_hi, part == 0 ? 1 : 0, (const double*)gp.d_rowsum_part,
-                              part == 1 ? (const double*)e.d_metric_sums : (const double*)nullptr, mom);
+                              part == 1 ? (const double*)e.d_metric_sums : (const double*)nullptr, mom, f);
     else
     hipLaunchKernelGGL(gram_reduce_kernel<T>, dim3((unsigned)wgs), dim3(256), 0, s,
                        (const T*)gp.d_slabs, gp.d_blk_rc, gp.d_row_own, pl.nblocks, pl.tile, e.ml,
                        (long long)e.J, row_lo, row_hi, part == 0 ? 1 : 0, gp.d_rowsum_part,
-                       part == 1 ? e.d_metric_sums : (const double*)nullptr, mom);
+                       part == 1 ? e.d_metric_sums : (const double*)nullptr, mom, f);
     CESX_HIP(hipGetLastError());
     return CESX_OK;
 }
 
-int launch_gram_reduce(Engine& e, int part, double* mom, hipStream_t s, hipEvent_t stop) {
-    return e.cfg.dtype == CESX_F32 ? launch_gram_reduce_t<float>(e, part, mom, s, stop) : launch_gram_reduce_t<double>(e, part, mom, s, stop);
+int launch_gram_reduce(Engine& e, int part, double* mom, hipStream_t s, hipEvent_t stop, const MetricFin* fin) {
+    return e.cfg.dtype == CESX_F32 ? launch_gram_reduce_t<float>(e, part, mom, s, stop, fin)
+                                   : launch_gram_reduce_t<double>(e, part, mom, s, stop, fin);
 }
 
 int launch_gram(Engine& e, int part, const void* U, const void* G, double* mom, hipStream_t s, bool no_reduce) {

@@ -132,34 +132,7 @@ __global__ void dense_shift_terms_kernel(const double* __restrict__ shift_g, con
 // sums[0..1] = sum over workgroups of {q_r^2, q_e^2}; scalars: this shard's contribution
 // to the two data metrics (divided by the GLOBAL ensemble size) and, from the tail of the
 // all-reduced moment buffer, the previous step's global values (multi-device runs)
-__global__ void metric_final_kernel(const double* __restrict__ part, int nparts, const double* __restrict__ mom,
-                                    size_t tail_off, double* __restrict__ sums, Scalars* __restrict__ sc,
-                                    Scalars* host, unsigned long long seq) {
-    __shared__ double red[ST_THREADS / 64];
-    double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < nparts; i += blockDim.x) { a += part[(size_t)i * 2]; b += part[(size_t)i * 2 + 1]; }
-    a = block_sum(a, red);
-    b = block_sum(b, red);
-    if (threadIdx.x == 0) {
-        const double N = mom[0];
-        sums[0] = a; sums[1] = b;
-        sc->bias_data = a / N;
-        sc->self_bias_data = b / N;
-        sc->spare[1] = mom[tail_off] / N;          // lagged global bias-data
-        sc->spare[2] = mom[tail_off + 1] / N;      // lagged global self-bias-data
-    }
-    if (host == nullptr) return;
-    // last kernel of an eks / aldi step: publish the results (see publish_kernel)
-    __threadfence();
-    __syncthreads();
-    const double* src = reinterpret_cast<const double*>(sc);
-    double* dst = reinterpret_cast<double*>(host);
-    constexpr int ND = offsetof(Scalars, seq) / 8;
-    if (threadIdx.x < ND) dst[threadIdx.x] = __hip_atomic_load(&src[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
+__global__ void metric_final_kernel(MetricFin f) { metric_final_body(f); }
 
 // ---------------------------------------------------------------------------
 template <typename T>
@@ -233,11 +206,14 @@ int launch_publish(Engine& e, hipStream_t s) {
 }
 
 // publish = true: this is the last kernel of the step and also writes the results to the host
-int launch_metric_final(Engine& e, const double* mom, bool publish, hipStream_t s) {
+MetricFin metric_fin_args(Engine& e, const double* mom, bool publish) {
     const int nparts = e.diag_gamma ? e.last_metric_parts : (int)((e.J + 63) / 64);
-    hipLaunchKernelGGL(metric_final_kernel, dim3(1), dim3(ST_THREADS), 0, s, e.d_metric_part, nparts, mom,
-                       e.ml.tail(), e.d_metric_sums, e.d_scal, publish ? e.h_scal_dev : (Scalars*)nullptr,
-                       publish ? ++e.seq : 0ull);
+    return MetricFin{e.d_metric_part, nparts, mom, e.ml.tail(), e.d_metric_sums, e.d_scal,
+                     publish ? e.h_scal_dev : (Scalars*)nullptr, publish ? ++e.seq : 0ull};
+}
+
+int launch_metric_final(Engine& e, const double* mom, bool publish, hipStream_t s) {
+    hipLaunchKernelGGL(metric_final_kernel, dim3(1), dim3(ST_THREADS), 0, s, metric_fin_args(e, mom, publish));
     CESX_HIP(hipGetLastError());
     return CESX_OK;
 }
