@@ -214,6 +214,13 @@ struct MetricFin {
 };
 __device__ __forceinline__ void metric_final_body(const MetricFin& f) {
     __shared__ double mf_red[2][4];
+    __shared__ double mf_out[4];
+    constexpr int ND = offsetof(Scalars, seq) / 8;
+    // the scalars earlier kernels of the step wrote (hk, t, bias ...): read FIRST, beside the partial sums -- the
+    // chain of dependent round trips of this one workgroup is what a launch that carries it waits for
+    double mine = 0.0;
+    if (f.host != nullptr && threadIdx.x < ND)
+        mine = __hip_atomic_load(reinterpret_cast<const double*>(f.sc) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     double a = 0.0, b = 0.0;
     for (int i = threadIdx.x; i < f.nparts; i += blockDim.x) { a += f.part[(size_t)i * 2]; b += f.part[(size_t)i * 2 + 1]; }
 #pragma unroll
@@ -225,19 +232,22 @@ __device__ __forceinline__ void metric_final_body(const MetricFin& f) {
         for (int i = 0; i < (int)(blockDim.x >> 6) && i < 4; ++i) { a += mf_red[0][i]; b += mf_red[1][i]; }
         const double N = f.N > 0.0 ? f.N : f.mom[0];
         f.sums[0] = a; f.sums[1] = b;
-        f.sc->bias_data = a / N;
-        f.sc->self_bias_data = b / N;
-        f.sc->spare[1] = f.mom[f.tail_off] / N;          // lagged global bias-data
-        f.sc->spare[2] = f.mom[f.tail_off + 1] / N;      // lagged global self-bias-data
+        mf_out[0] = f.sc->bias_data = a / N;
+        mf_out[1] = f.sc->self_bias_data = b / N;
+        mf_out[2] = f.sc->spare[1] = f.mom[f.tail_off] / N;          // lagged global bias-data
+        mf_out[3] = f.sc->spare[2] = f.mom[f.tail_off + 1] / N;      // lagged global self-bias-data
     }
     if (f.host == nullptr) return;
     // last kernel of an eks / aldi step: publish the results (see publish_kernel)
-    __threadfence();
     __syncthreads();
-    const double* src = reinterpret_cast<const double*>(f.sc);
-    double* dst = reinterpret_cast<double*>(f.host);
-    constexpr int ND = offsetof(Scalars, seq) / 8;
-    if (threadIdx.x < ND) dst[threadIdx.x] = __hip_atomic_load(&src[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < ND) {
+        const int i = threadIdx.x;
+        const double v = i == (int)(offsetof(Scalars, bias_data) / 8) ? mf_out[0]
+                       : i == (int)(offsetof(Scalars, self_bias_data) / 8) ? mf_out[1]
+                       : i == (int)(offsetof(Scalars, spare) / 8) + 1 ? mf_out[2]
+                       : i == (int)(offsetof(Scalars, spare) / 8) + 2 ? mf_out[3] : mine;
+        reinterpret_cast<double*>(f.host)[i] = v;
+    }
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(&f.host->seq, f.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

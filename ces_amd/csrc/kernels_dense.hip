@@ -239,11 +239,16 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
     if (lda == 0) lda = n;
     if (ldl == 0) ldl = np;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int ldt = np + 4;
-    double* PnT = reinterpret_cast<double*>(smem);        // [2][8][ldt]  the panel (k-major), double buffered
-    double* NnT = PnT + 2 * QNB * ldt;                    // [8][ldt]     its negative: the A operand of the trailing update
-    double* ZnT = NnT + QNB * ldt;                        // [8][ldt]     zeros: rows that have no entry in the panel read these
-    for (int i = threadIdx.x; i < QNB * ldt; i += PRT) ZnT[i] = 0.0;
+    // Panel images, k-major: element (k, row relative to the panel's first row) at k * LDT + Z0 + row.  The Z0 = NPMAX
+    // entries in front of every k-row stay ZERO: the rows / columns of a tile that lie left of the panel (finished,
+    // no entry in the panel) have negative relative rows and read these zeros -- the operand address of a tile is
+    // lane constant + 16 * (tile row or column) - kb, one scalar shift and one vector add, no compare / select.
+    // LDT is a compile-time stride: the k + 4 half of an operand pair is an immediate offset of the ds_read.
+    constexpr int NPMAX = SLOTS <= 2 ? 64 : SLOTS <= 5 ? 128 : SLOTS <= 10 ? 192 : 256;
+    constexpr int LDT = 2 * NPMAX + 4, Z0 = NPMAX;
+    double* PnT = reinterpret_cast<double*>(smem);        // [2][8][LDT]  the panel, double buffered
+    double* NnT = PnT + 2 * QNB * LDT;                    // [8][LDT]     its negative: the A operand of the trailing update
+    for (int i = threadIdx.x; i < 3 * QNB * LDT; i += PRT) PnT[i] = 0.0;
     const int tid = threadIdx.x, lane = tid & 63, i8 = lane & 7;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = np / 16;
@@ -251,7 +256,13 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
     const int lc = lane & 15, lr = lane >> 4;             // C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg
 
     d4_t Pt[SLOTS];
-    int tR[SLOTS], tC[SLOTS];
+    // tile coordinates, 4 bits each, 8 slots per register: wave-uniform, extracted with scalar bit-field ops
+    // (an int per slot spills out of the SGPR file and comes back through v_readlane in the trailing loop)
+    constexpr int NPK = (SLOTS + 7) / 8;
+    unsigned pkR[NPK], pkC[NPK];
+#pragma clang loop unroll(full)
+    for (int i = 0; i < NPK; ++i) { pkR[i] = 0; pkC[i] = 0; }
+    int non = 0;                                          // slots of this wave that hold a tile (a prefix)
 #pragma clang loop unroll(full)
     for (int s = 0; s < SLOTS; ++s) {
         // Tiles are dealt round-robin to the 8 waves in COLUMN-descending order (last tile column first,
@@ -266,8 +277,9 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
         const int Cc = T - 1 - m_;
         const int R = Cc + (q - m_ * (m_ + 1) / 2);
         const bool on = q < ntile;
-        tR[s] = __builtin_amdgcn_readfirstlane(on ? R : -1);      // wave-uniform -> SGPRs
-        tC[s] = __builtin_amdgcn_readfirstlane(on ? Cc : 0);
+        pkR[s / 8] |= (unsigned)__builtin_amdgcn_readfirstlane(on ? R : 0) << (4 * (s % 8));
+        pkC[s / 8] |= (unsigned)__builtin_amdgcn_readfirstlane(on ? Cc : 0) << (4 * (s % 8));
+        non += __builtin_amdgcn_readfirstlane(on ? 1 : 0);
 #pragma clang loop unroll(full)
         for (int e = 0; e < 4; ++e) {
             int i = R * 16 + lr + 4 * e, j = Cc * 16 + lc;
@@ -277,36 +289,40 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
             Pt[s][e] = v;
         }
     }
+#define TROW(s_) ((int)((pkR[(s_) / 8] >> (4 * ((s_) % 8))) & 15u))
+#define TCOL(s_) ((int)((pkC[(s_) / 8] >> (4 * ((s_) % 8))) & 15u))
     long long tph[5] = {0, 0, 0, 0, 0}, tl = clock64();
 #define PH(i) if (dbg) { const long long t_ = clock64(); tph[i] += t_ - tl; if (tid == 0 && (i) >= 2) dbg[8 + (kb_dbg / QNB) * 2 + ((i) == 4)] = t_ - tl; tl = t_; }
     int kb_dbg = 0;
     // columns kbn .. kbn+7 of tile s -> buf[col - kbn][row - kbn] (rows at or below the panel's diagonal block)
     // (no per-lane branches: elements outside the panel are written to the 4 pad rows of column 0)
     auto publish = [&](int s, int kbn, double* buf) {
-        const int col = tC[s] * 16 + lc - kbn;
+        const int col = TCOL(s) * 16 + lc - kbn;
         const bool cok = col >= 0 && col < QNB;
 #pragma clang loop unroll(full)
         for (int e = 0; e < 4; ++e) {
-            const int row = tR[s] * 16 + lr + 4 * e - kbn;
-            const int off = (cok && row >= 0) ? col * ldt + row : np - kbn + e;
+            const int row = TROW(s) * 16 + lr + 4 * e - kbn;
+            const int off = (cok && row >= 0) ? col * LDT + Z0 + row : Z0 + np - kbn + e;
             buf[off] = Pt[s][e];
         }
     };
+    __syncthreads();                                      // (the zero fill above)
 #pragma clang loop unroll(full)
     for (int s = 0; s < SLOTS; ++s)
-        if (tR[s] >= 0 && tC[s] == 0) publish(s, 0, PnT);
+        if (s < non && TCOL(s) == 0) publish(s, 0, PnT);
     __syncthreads();
     PH(0)
 
     for (int kb = 0; kb < np; kb += QNB) {
-        double* cur = PnT + ((kb / QNB) & 1) * QNB * ldt;
-        double* nxt = PnT + (((kb / QNB) & 1) ^ 1) * QNB * ldt;
+        double* cur = PnT + ((kb / QNB) & 1) * QNB * LDT + Z0;            // (data origin: relative row 0)
+        double* nxt = PnT + (((kb / QNB) & 1) ^ 1) * QNB * LDT;
+        double* neg = NnT + Z0;
         const int m = np - kb;
         kb_dbg = kb;
         // (b) 8 x 8 diagonal block, redundantly per wave
         double d[QNB];
 #pragma clang loop unroll(full)
-        for (int j = 0; j < QNB; ++j) d[j] = cur[j * ldt + i8];
+        for (int j = 0; j < QNB; ++j) d[j] = cur[j * LDT + i8];
         double rinv[QNB];
         bool bad = false;
 #pragma clang loop unroll(full)
@@ -326,7 +342,7 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
         if (r < m) {
             double x[QNB];
 #pragma clang loop unroll(full)
-            for (int j = 0; j < QNB; ++j) x[j] = cur[j * ldt + r];
+            for (int j = 0; j < QNB; ++j) x[j] = cur[j * LDT + r];
 #pragma clang loop unroll(full)
             for (int j = 0; j < QNB; ++j) {
                 double sacc = x[j];
@@ -337,8 +353,8 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
             double* dst = Lp + (size_t)(kb + r) * ldl + kb;
 #pragma clang loop unroll(full)
             for (int j = 0; j < QNB; ++j) {
-                cur[j * ldt + r] = x[j];
-                NnT[j * ldt + r] = -x[j];
+                cur[j * LDT + r] = x[j];
+                neg[j * LDT + r] = -x[j];
                 dst[j] = x[j];
             }
         }
@@ -347,7 +363,7 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
 #pragma clang loop unroll(full)
             for (int j = 0; j < QNB; ++j) {
                 const double v = j <= tid ? d[j] : 0.0;
-                cur[j * ldt + tid] = v;
+                cur[j * LDT + tid] = v;
                 dst[j] = v;
             }
         }
@@ -361,35 +377,42 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
         const int tact = T - kn / 16;
         const int n_act = tact > 0 ? tact * (tact + 1) / 2 : 0;
         const int nact = n_act > wave ? (n_act - wave + 7) / 8 : 0;       // ... of which this wave holds the first nact slots
-        // operands of one tile: A = -L21 rows of the tile (from the negated image), B = L21 rows of the tile's
-        // columns.  Rows / columns left of the panel (finished) have no panel entry: they read the zero image.
-        // The select is on the ADDRESS, so nothing depends on the loaded values until the MFMA: the reads of
-        // tile s+1 stay in flight behind the MFMAs of tile s.
+        // Operands of one tile: A = -L21 rows of the tile (from the negated image), B = L21 rows of the tile's
+        // columns; finished rows / columns read the zeros in front of the image.  Tiles go in PAIRS: the four
+        // MFMAs of a pair alternate between its two accumulators (the two MFMAs of one tile depend on each other),
+        // and the LDS reads of the next pair are in flight behind them.
         struct Ops { double av[2], bv[2]; };
+        const double* nbase = neg + lr * LDT + lc - kb;
+        const double* cbase = cur + lr * LDT + lc - kb;
         auto load_ops = [&](Ops& o, int s_) {
-            const int ra = tR[s_] * 16 - kb + lc, rb = tC[s_] * 16 - kb + lc;
-            const double* pa = (ra >= 0 ? NnT + ra : ZnT) + lr * ldt;
-            const double* pb = (rb >= 0 ? cur + rb : ZnT) + lr * ldt;
+            const double* pa = nbase + TROW(s_) * 16;
+            const double* pb = cbase + TCOL(s_) * 16;
 #pragma clang loop unroll(full)
-            for (int h = 0; h < 2; ++h) { o.av[h] = pa[4 * h * ldt]; o.bv[h] = pb[4 * h * ldt]; }
+            for (int h = 0; h < 2; ++h) { o.av[h] = pa[4 * h * LDT]; o.bv[h] = pb[4 * h * LDT]; }
         };
-        Ops o0, o1;
-        if (nact > 0) load_ops(o0, 0);
+        Ops oa[2], ob[2];                                 // [pair parity]: first / second tile of the pair
+        if (nact > 0) load_ops(oa[0], 0);
+        if (nact > 1) load_ops(ob[0], 1);
 #pragma clang loop unroll(full)
-        for (int s = 0; s < SLOTS; ++s) {
+        for (int s = 0; s < SLOTS; s += 2) {
             if (s < nact) {
-                Ops& oc = (s & 1) ? o1 : o0;
-                Ops& on_ = (s & 1) ? o0 : o1;
-                if (s + 1 < SLOTS) { if (s + 1 < nact) load_ops(on_, s + 1); }     // next tile's LDS reads behind these MFMAs
-#pragma clang loop unroll(full)
-                for (int h = 0; h < 2; ++h)
-                    Pt[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(oc.av[h], oc.bv[h], Pt[s], 0, 0, 0);
-                if (kn < np && tC[s] == kn / 16) publish(s, kn, nxt);
+                const int pp = (s >> 1) & 1;
+                if (s + 2 < SLOTS) { if (s + 2 < nact) load_ops(oa[pp ^ 1], s + 2); }
+                if (s + 3 < SLOTS) { if (s + 3 < nact) load_ops(ob[pp ^ 1], s + 3); }
+                const bool two = s + 1 < SLOTS && s + 1 < nact;
+                Pt[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(oa[pp].av[0], oa[pp].bv[0], Pt[s], 0, 0, 0);
+                if (s + 1 < SLOTS) { if (two) Pt[s + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ob[pp].av[0], ob[pp].bv[0], Pt[s + 1], 0, 0, 0); }
+                Pt[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(oa[pp].av[1], oa[pp].bv[1], Pt[s], 0, 0, 0);
+                if (s + 1 < SLOTS) { if (two) Pt[s + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ob[pp].av[1], ob[pp].bv[1], Pt[s + 1], 0, 0, 0); }
+                if (kn < np && TCOL(s) == kn / 16) publish(s, kn, nxt);
+                if (s + 1 < SLOTS) { if (two && kn < np && TCOL(s + 1) == kn / 16) publish(s + 1, kn, nxt); }
             }
         }
         __syncthreads();
         PH(4)
     }
+#undef TROW
+#undef TCOL
     if (dbg && tid == 0)
         for (int i = 0; i < 5; ++i) dbg[i] = tph[i];
 #undef PH
@@ -875,7 +898,8 @@ static int gemm(Engine& e, hipStream_t s, int m, int n, int k, double alpha, con
 template <int SLOTS>
 static int potrf_reg_launch(Engine& e, hipStream_t s, int n, int np, const double* A, double* Lp, int lda = 0, int ldl = 0,
                             hipEvent_t stop = nullptr) {      // stop: event bound to this kernel's own completion signal
-    const size_t lds = (size_t)4 * QNB * (np + 4) * 8;       // panel x 2, its negative, zeros
+    constexpr int NPMAX = SLOTS <= 2 ? 64 : SLOTS <= 5 ? 128 : SLOTS <= 10 ? 192 : 256;
+    const size_t lds = (size_t)3 * QNB * (2 * NPMAX + 4) * 8;      // panel x 2, its negative (each k-row behind NPMAX zeros)
     CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_reg_kernel<SLOTS>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (stop)

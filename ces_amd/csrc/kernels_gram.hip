@@ -276,19 +276,22 @@ void gram_reduce_kernel(const T* __restrict__ slabs, const int* __restrict__ blk
                         double* __restrict__ mom, const MetricFin fin) {
     using vec_t = typename Mfma<T>::vec_t;
     constexpr int VEC = Mfma<T>::VEC;
-    // the previous update's metric finalisation + publication, riding on this launch as one extra workgroup
-    if (fin.part != nullptr && blockIdx.x == gridDim.x - 1) { metric_final_body(fin); return; }
+    // the previous update's metric finalisation + publication, riding on this launch as one extra workgroup -- the
+    // FIRST one: its chain of dependent loads, fences and the write to host memory (~8 us) starts with the launch and
+    // ends inside it
+    if (fin.part != nullptr && blockIdx.x == 0) { metric_final_body(fin); return; }
+    const unsigned bid = fin.part != nullptr ? blockIdx.x - 1 : blockIdx.x;
     const int p = ml.p, n = ml.n;
     __shared__ double part[RED_S][RED_G][VEC];
     const int tt = tile * tile;
     const long long ngroups = (long long)nblocks * tt / VEC;
     const int gq = threadIdx.x / RED_G, gl = threadIdx.x % RED_G;
-    const long long idx = (long long)blockIdx.x * RED_G + gl;
-    if ((long long)blockIdx.x * RED_G >= ngroups) {
+    const long long idx = (long long)bid * RED_G + gl;
+    if ((long long)bid * RED_G >= ngroups) {
         // tail workgroups: N, the first moments sum_j (z_ij - s_i) of the rows this launch owns
         // (16 rows x 16 slice parts per workgroup), and (second launch) the lagged data-metric
         // sums that ride at the end of the buffer
-        const int tw = (int)(((long long)blockIdx.x * RED_G - ngroups) / RED_G);
+        const int tw = (int)(((long long)bid * RED_G - ngroups) / RED_G);
         const long long r = row_lo + (long long)tw * RED_G + gl;
         if (tw == 0 && threadIdx.x == 0) {
             if (write_N) mom[0] = (double)J;

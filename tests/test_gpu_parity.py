@@ -576,6 +576,48 @@ def test_comm_overlap_stream_path_matches(eng_mod):
     assert outs[0][1] == outs[1][1]
 
 
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_single_device_fast_path_variants_match(eng_mod, monkeypatch, dtype):
+    """The single-device fast path -- hand-over events bound to kernels (cesx_moments_uu_chol), the scalar and assemble
+    kernels as one launch, the noise block drawn one step ahead, the metric finalisation + publication riding on the
+    NEXT step's U x U reduce launch -- gives bit-identical chains to the plain path (separate markers, kernels and a
+    metric_final kernel per step), in a pipelined loop (begin(i+1) before result(i)) and in a step-by-step one."""
+    from ces_amd.dist import ShardedUpdate
+    p, n, J = 128, 96, 8192
+    d = _synthetic(p, n, J, seed=77)
+    outs = []
+    for fast, pipelined in ((True, True), (True, False), (False, True), (False, False)):
+        for k in ("CESX_EXT_EVENTS", "CESX_DEFER_PUBLISH", "CESX_NOISE_LOOKAHEAD"):
+            monkeypatch.setenv(k, "1" if fast else "0")
+        monkeypatch.setenv("CESX_K2_SPLIT", "0" if fast else "1")
+        eng = eng_mod.Engine(p, n, J, dtype=dtype, seed=9)
+        eng.set_problem(d["y"], d["Gamma"], d["mu"], d["sigma"], d["ustar"])
+        sh = ShardedUpdate(eng)
+        U, G = eng.to_device(d["U0"]), eng.to_device(d["G"])
+        bufs = [eng.empty(p), eng.empty(p)]
+        t_last, chain = 0.0, []
+
+        def prm_of(i, t_last):
+            return eng_mod.step_params(update="aldi", first_step=(i == 0), t_len=min(i, 1), t_last=t_last, step_index=i)
+        nsteps = 5
+        sh.begin(prm_of(0, 0.0), U, G, recenter=True, noise_step=0)
+        for i in range(nsteps):
+            out = sh.finish(prm_of(i, t_last), U, G, xi=None, out=bufs[i % 2])
+            if pipelined and i + 1 < nsteps:
+                sh.begin(prm_of(i + 1, 0.0), out, G, noise_step=i + 1)      # (begin reads prm.update only)
+            res = sh.result()
+            if not pipelined and i + 1 < nsteps:
+                sh.begin(prm_of(i + 1, 0.0), out, G, noise_step=i + 1)
+            t_last = res.t_new
+            chain.append((res.hk, res.t_new, res.bias, res.self_bias, res.bias_data, res.self_bias_data,
+                          res.lag_bias_data, res.lag_self_bias_data))
+            U = out
+        outs.append((U.cpu().numpy().copy(), chain))
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0])
+        assert o[1] == outs[0][1]
+
+
 @pytest.mark.parametrize("update", ["aldi", "eks"])
 def test_pde_model_run_drop_in(eng_mod, update):
     """A ``type == 'pde'`` forward model (Lorenz '63 with carried state W0)

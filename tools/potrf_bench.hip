@@ -17,7 +17,8 @@ int main(int argc, char** argv) {
     double *dA, *dL, *dLp; int* st;
     hipMalloc(&dA, n*n*8); hipMalloc(&dL, n*n*8); hipMalloc(&dLp, np*np*8); hipMalloc(&st, 4);
     hipMemcpy(dA, A.data(), n*n*8, hipMemcpyHostToDevice); hipMemset(st, 0, 4);
-    size_t lds = (size_t)4 * 8 * (np + 4) * 8;
+    const int npmax = SLOTS <= 2 ? 64 : SLOTS <= 5 ? 128 : SLOTS <= 10 ? 192 : 256;
+    size_t lds = (size_t)3 * 8 * (2 * npmax + 4) * 8;
     auto kern = cesx::potrf_reg_kernel<SLOTS>;
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     long long* dbg; hipMalloc(&dbg, 8 * 80); hipMemset(dbg, 0, 8 * 80);
