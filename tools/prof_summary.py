@@ -42,9 +42,12 @@ def main():
     if trace:
         rows = list(csv.DictReader(open(trace[-1])))
         rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-        # a step ends with metric_final_kernel; show the last complete one plus the next step's first launch
-        last = [i for i, r in enumerate(rows) if "metric_final_kernel" in r["Kernel_Name"]]
-        i0, i1 = last[-3] + 1, min(last[-2] + 2, len(rows) - 1)
+        # a step ends with its update kernel (the metric finalisation of a single-device run rides on the next step's
+        # U x U reduce launch); show the last complete one plus the next step's first launches
+        last = [i for i, r in enumerate(rows) if "update2_kernel" in r["Kernel_Name"] or "update3_kernel" in r["Kernel_Name"]]
+        if len(last) < 4:
+            last = [i for i, r in enumerate(rows) if "metric_final_kernel" in r["Kernel_Name"]]
+        i0, i1 = last[-4] + 1, min(last[-3] + 2, len(rows) - 1)
         t0 = int(rows[i0]["Start_Timestamp"])
         with open(os.path.join(out, tag + "_kernel_trace_step.txt"), "w") as f:
             f.write("# one step of `python3 bench.py` under rocprofv3 --kernel-trace (us from the step's first launch;\n"
@@ -82,8 +85,10 @@ def main():
                             "gram_kernel = both Gram launches of a step (gram2_kernel = the LDS-DMA form)")
         per_step = {}
         steps = None
-        if "metric_final_kernel" in summary and "FETCH_SIZE" in summary["metric_final_kernel"]:
-            steps = summary["metric_final_kernel"]["FETCH_SIZE"]["launches"]      # one launch per step
+        for k3 in ("update2_kernel", "update3_kernel", "metric_final_kernel"):      # one launch per step
+            if k3 in summary and "FETCH_SIZE" in summary[k3]:
+                steps = summary[k3]["FETCH_SIZE"]["launches"]
+                break
         for kern, c in summary.items():
             if "FETCH_SIZE" in c and "WRITE_SIZE" in c and steps:
                 tot = (2 * c["FETCH_SIZE"]["mean_per_launch"] * c["FETCH_SIZE"]["launches"]
