@@ -152,7 +152,12 @@ int cesx_step(cesx_handle h, const cesx_step_params* prm, const void* U_dev, con
 
 /* Waits for the last step on this handle and returns what the reference would
    have appended to self.metrics / self.radspec.  Returns CESX_ENOTPD when the
-   ensemble covariance was not positive definite (U_next is then undefined). */
+   ensemble covariance was not positive definite (U_next is then undefined).
+   (On one device the last small kernel of a step -- fixed-order sum of the data-metric
+   partials, copy of the scalars to the host -- is held back so that it can ride on the next
+   step's cesx_moments_uu_chol launch; cesx_result, like every entry point that touches the
+   engine's state, enqueues it at once if it is still pending.  A driver may therefore enqueue
+   the first half of step i+1 before it reads the result of step i, or not: same numbers.) */
 int cesx_result(cesx_handle h, cesx_step_result* out);
 
 /* ---- split entry points (multi-device, testing) ----------------------- */
@@ -219,12 +224,15 @@ int cesx_apply_finish(cesx_handle h, const cesx_step_params* prm, const double* 
 int cesx_draw_noise(cesx_handle h, uint64_t step_index, void* xi_dev, void* stream);
 
 /* Optional: draw the noise block of step `step_index` AHEAD of the update, into an engine-owned
-   buffer, on a low-priority background stream (it fills the CUs the Gram launch leaves idle; the
-   f32-input MFMA shares the SIMD's vector lanes, so Philox + Box-Muller inside the update kernel
-   cost it matrix-pipe cycles).  A later cesx_apply / cesx_apply_finish / cesx_step with
-   xi_dev == NULL and the same prm->step_index reads that block (same numbers as the in-kernel
-   generator, np.random.normal's role at ces/calibrate.py:447/:488/:527); any other step index
-   falls back to drawing inside the update kernel.  cesx_step calls it itself. */
+   buffer, on the engine's side stream behind the next chol(C) (the f32-input MFMA shares the
+   SIMD's vector lanes, so Philox + Box-Muller inside the update kernel cost it matrix-pipe
+   cycles).  The engine keeps two such buffers and draws the block of step_index + 1 as well,
+   so that a run with consecutive step indices finds every block complete one step ahead
+   (CESX_NOISE_LOOKAHEAD=0: one buffer, the step's own block only).  A later cesx_apply /
+   cesx_apply_finish / cesx_step with xi_dev == NULL and a matching prm->step_index reads the
+   block (same numbers as the in-kernel generator, np.random.normal's role at
+   ces/calibrate.py:447/:488/:527); any other step index falls back to drawing inside the
+   update kernel.  cesx_step calls it itself. */
 int cesx_prefetch_noise(cesx_handle h, uint64_t step_index, void* stream);
 
 /* ---- forward-map hook --------------------------- */
