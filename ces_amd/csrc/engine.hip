@@ -468,6 +468,43 @@ int cesx_chol_async(cesx_handle h, int update, const double* mom, void* stream) 
     return launch_chol_async(e, update, mom, (hipStream_t)stream);
 }
 
+// U x U launch + its reduce with the hand-over event (ev_a) bound to the reduce kernel's own completion signal -- no
+// marker packet in front of whatever the caller's stream runs next -- and, when the previous update's metric
+// finalisation is still pending on this stream, that too as the reduce launch's first workgroup.  The side stream
+// is made to wait for ev_a.
+static int moments_uu_handover(Engine& e, const void* U, const void* G, double* mom, hipStream_t s) {
+    if (e.met_deferred && e.met_stream != s) FLUSH(e);
+    TRY(launch_gram(e, 0, U, G, mom, s, true));
+    if (e.met_deferred) {
+        MetricFin f = metric_fin_args(e, e.met_mom, true);
+        f.N = (double)e.Jg;
+        e.met_deferred = false;
+        TRY(launch_gram_reduce(e, 0, mom, s, e.ev_a, &f));
+    } else {
+        TRY(launch_gram_reduce(e, 0, mom, s, e.ev_a));
+    }
+    CESX_HIP(hipStreamWaitEvent(e.side, e.ev_a, 0));
+    return CESX_OK;
+}
+
+int cesx_moments_uu_handover(cesx_handle h, const void* U, const void* G, double* mom, void* stream) {
+    if (!h) return CESX_EINVAL;
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    TRY(moments_check(e, U, G, mom));
+    SET_DEVICE(e);
+    hipStream_t s = (hipStream_t)stream;
+    if (s == e.side || !e.ext_events) {      // nothing to hand over / plain markers: the caller's own ordering applies
+        FLUSH(e);
+        TRY(launch_gram(e, 0, U, G, mom, s));
+        if (s != e.side) {
+            CESX_HIP(hipEventRecord(e.ev_a, s));
+            CESX_HIP(hipStreamWaitEvent(e.side, e.ev_a, 0));
+        }
+        return CESX_OK;
+    }
+    return moments_uu_handover(e, U, G, mom, s);
+}
+
 int cesx_moments_uu_chol(cesx_handle h, int update, const void* U, const void* G, double* mom, void* stream) {
     if (!h) return CESX_EINVAL;
     Engine& e = *reinterpret_cast<Engine*>(h);
@@ -480,18 +517,8 @@ int cesx_moments_uu_chol(cesx_handle h, int update, const void* U, const void* G
         TRY(launch_gram(e, 0, U, G, mom, s));
         return launch_chol_async(e, update, mom, s);
     }
-    if (e.met_deferred && e.met_stream != s) FLUSH(e);
-    // nothing can sit between the reduce of the U x U launch and the hand-over to the side stream: the hand-over
-    // event is the reduce kernel's own completion signal, no marker packet in front of the second Gram launch
-    TRY(launch_gram(e, 0, U, G, mom, s, true));
-    if (e.met_deferred) {
-        MetricFin f = metric_fin_args(e, e.met_mom, true);
-        f.N = (double)e.Jg;
-        e.met_deferred = false;
-        TRY(launch_gram_reduce(e, 0, mom, s, e.ev_a, &f));
-    } else {
-        TRY(launch_gram_reduce(e, 0, mom, s, e.ev_a));
-    }
+    // nothing can sit between the reduce of the U x U launch and the hand-over to the side stream
+    TRY(moments_uu_handover(e, U, G, mom, s));
     return launch_chol_async(e, update, mom, s, true);
 }
 
@@ -571,9 +598,9 @@ int cesx_apply(cesx_handle h, const cesx_step_params* prm, const double* mom, co
     TRY(run_update_main(e, *prm, U, G, xi, Unext, s));
     // (Moving this last small kernel to the side stream was tried: the event record + wait pair costs
     //  as much GPU idle time as the 7 us kernel itself.)
-    if (e.met_defer_ok && e.ext_events && e.overlap_chol && e.diag_gamma && e.J == e.Jg) {
-        // one device: the finalisation rides on the next step's U x U reduce launch (cesx_moments_uu_chol) -- no
-        // one-workgroup kernel (7 us) between this update and the next Gram launch; anything else flushes it
+    if (e.met_defer_ok && e.ext_events && e.overlap_chol && e.diag_gamma) {
+        // the finalisation rides on the next step's U x U reduce launch (cesx_moments_uu_chol / _handover on this
+        // stream) -- no one-workgroup kernel (7 us) between this update and the next Gram launch; anything else flushes it
         e.met_deferred = true; e.met_stream = s; e.met_mom = mom;
     } else {
         TRY(finish_metrics(e, mom, G, true, s));     // also publishes the step result to the host

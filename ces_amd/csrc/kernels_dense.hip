@@ -1258,8 +1258,10 @@ int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s, b
     // the whole U-only part of K2 (centre, C, M, then chol(C)) goes to the side stream: the main
     // stream continues with the second Gram launch straight after the U x U reduce
     if (s != e.side) {                             // (a caller already on the side stream needs no hand-over)
-        if (!ev_a_bound) CESX_HIP(hipEventRecord(e.ev_a, s));      // (bound: ev_a is the U x U reduce kernel's own signal)
-        CESX_HIP(hipStreamWaitEvent(e.side, e.ev_a, 0));
+        if (!ev_a_bound) {          // (bound: ev_a is the U x U reduce kernel's own signal, the side stream waits for it already)
+            CESX_HIP(hipEventRecord(e.ev_a, s));
+            CESX_HIP(hipStreamWaitEvent(e.side, e.ev_a, 0));
+        }
     }
     // (few workgroups -> 1024 threads each: 8 x 256 threads took 25 us for the 65 k elements of C, latency bound)
     hipLaunchKernelGGL(center_kernel, dim3(std::min(NPB, e.center_u_wgs)), dim3(e.center_u_wgs < NPB ? 1024 : DT), 0, e.side, mv, e.d_shift64, e.d_y, e.d_ustar,

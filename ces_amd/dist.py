@@ -114,13 +114,23 @@ class ShardedUpdate:
             eng.prefetch_noise(noise_step)
         nuu = eng.moments_uu_len()
         mom = self._moment_buffer()
-        if self.overlap_comm or self.side_gram:
+        if self.overlap_comm and not self.side_gram and hasattr(eng, "moments_uu_handover"):
+            # main stream: U x U Gram (the device to itself) -> hand-over -> the rest of the Gram;
+            # side stream (high priority), beside the rest of the Gram: all-reduce of the head -> C, L = chol(C)
+            if self._cs is None:        # the engine's own side stream: no third stream to share a hardware queue
+                self._cs = eng.side_stream()
+            eng.moments_uu_handover(U, G, out=mom)
+            with torch.cuda.stream(self._cs):
+                self._all_reduce(mom[:nuu])          # N, sum(u - s), S_aa: all chol(C) needs
+                eng.chol_async(prm, mom)
+            eng.moments_rest(U, G, mom)
+        elif self.overlap_comm or self.side_gram:
             cur = torch.cuda.current_stream(eng.device)
             if self._cs is None:        # the engine's own side stream: no third stream to share a hardware queue
                 self._cs = eng.side_stream() if hasattr(eng, "side_stream") else torch.cuda.Stream(device=eng.device)
             self._cs.wait_stream(cur)                # U, G and the centring shift are ready
-            # side stream (high priority): U x U Gram -> all-reduce of the head -> C, L = chol(C);
-            # main stream, at the same time: the rest of the Gram (it does not depend on the collective)
+            # CESX_SIDE_GRAM=1 (measured slower: the two Gram launches fight for the CUs, the U x U one finishes late):
+            # side stream: U x U Gram -> all-reduce of the head -> C, L = chol(C); main stream: the rest of the Gram
             with torch.cuda.stream(self._cs):
                 eng.moments_uu(U, G, out=mom)
             eng.moments_rest(U, G, mom)

@@ -25,7 +25,7 @@ EXPORTS = ("cesx_abi_version", "cesx_create", "cesx_destroy", "cesx_last_error",
            "cesx_moments", "cesx_apply", "cesx_apply_drift", "cesx_apply_finish", "cesx_draw_noise",
            "cesx_forward_lineal", "cesx_debug_dense", "cesx_profile_enable", "cesx_profile_read",
            "cesx_moments_uu_len", "cesx_moments_uu", "cesx_chol_async", "cesx_moments_rest", "cesx_side_stream",
-           "cesx_prefetch_noise", "cesx_forward_set_lineal", "cesx_forward_apply", "cesx_moments_uu_chol")
+           "cesx_prefetch_noise", "cesx_forward_set_lineal", "cesx_forward_apply", "cesx_moments_uu_chol", "cesx_moments_uu_handover")
 
 
 class Config(C.Structure):
@@ -95,6 +95,7 @@ def load_library(path=None):
     lib.cesx_draw_noise.argtypes = [vp, u64, vp, vp]
     lib.cesx_prefetch_noise.argtypes = [vp, u64, vp]
     lib.cesx_moments_uu_chol.argtypes = [vp, C.c_int32, vp, vp, vp, vp]
+    lib.cesx_moments_uu_handover.argtypes = [vp, vp, vp, vp, vp]
     lib.cesx_forward_lineal.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.cesx_forward_set_lineal.argtypes = [vp, vp, vp, vp]
     lib.cesx_forward_apply.argtypes = [vp, vp, vp, vp]
@@ -406,6 +407,13 @@ class Engine:
         with torch.cuda.device(self.device):
             self._check(self.lib.cesx_moments_uu_chol(self._h, int(prm.update), U.data_ptr(), G.data_ptr(),
                                                       mom.data_ptr(), self._stream()))
+        return mom
+
+    def moments_uu_handover(self, U, G, out=None):
+        """moments_uu on the current stream, then the engine's side stream waits for it (cesx_moments_uu_handover)."""
+        mom = torch.empty(self.moments_len(), dtype=torch.float64, device=self.device) if out is None else out
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cesx_moments_uu_handover(self._h, U.data_ptr(), G.data_ptr(), mom.data_ptr(), self._stream()))
         return mom
 
     def moments_rest(self, U, G, mom):

@@ -194,6 +194,11 @@ int cesx_moments_rest(cesx_handle h, const void* U_dev, const void* G_dev, doubl
    the hand-over to the side stream is then the U x U reduce kernel's own completion signal instead of a marker
    packet in front of the second Gram launch (~6 us per step at C2).  Same results as the two calls. */
 int cesx_moments_uu_chol(cesx_handle h, int update, const void* U_dev, const void* G_dev, double* mom_dev, void* stream);
+/* The sharded form of the same hand-over: cesx_moments_uu on `stream`, after which the engine's SIDE stream waits
+   for it (again through the reduce kernel's own completion signal).  The driver then issues the all-reduce of the
+   buffer's head and cesx_chol_async on cesx_side_stream(), and goes on with cesx_moments_rest on `stream`: the
+   U x U launch has the device to itself, the collective and chol(C) run beside the second launch. */
+int cesx_moments_uu_handover(cesx_handle h, const void* U_dev, const void* G_dev, double* mom_dev, void* stream);
 
 /* The engine's side stream (a hipStream_t).  A sharded driver issues the all-reduce of the
    leading part of the moment buffer on it (and then calls cesx_chol_async with it as
