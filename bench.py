@@ -208,28 +208,34 @@ def e2e_block(engine, prob, p, n, J, dtype, update, dev_index):
 
         def __call__(self, theta):
             return prob["A"] @ theta
-    fwd_ms = []
+    fwd_ms, stamps = [], []
 
     def g_ens(theta, m):
         t0 = time.perf_counter()
         g = prob["A"] @ theta
-        fwd_ms.append(1e3 * (time.perf_counter() - t0))
+        t1 = time.perf_counter()
+        fwd_ms.append(1e3 * (t1 - t0))
+        stamps.append((t0, t1))
         return g
-    nst = 6
+    nst = 12
     eks = sampling(p=p, n_obs=n, J=J)
     eks.mu, eks.sigma, eks.ustar = prob["mu"], prob["sigma"], prob["ustar"]
     eks.engine_dtype, eks.noise, eks.device, eks.device_loop = np.dtype(dtype).name, "device", dev_index, False
     eks.G_ens = g_ens
-    eks.T = 2
+    eks.T = 3
     eks.run(prob["y"], U0, host_lineal(), prob["Gamma"], None, trace=False, t_tol=1e30)      # builds engine + pinned buffers
     eks.T = nst
-    del fwd_ms[:]
+    del fwd_ms[:], stamps[:]
     t0 = time.perf_counter()
     eks.run(prob["y"], eks.Ustar, host_lineal(), prob["Gamma"], None, trace=False, t_tol=1e30)
     el = time.perf_counter() - t0
     fwd = sum(fwd_ms) / (nst + 1)                           # run evaluates the map once more for the final ensemble
+    # one update call = from the end of one forward evaluation to the start of the next
+    calls = [1e3 * (stamps[i + 1][0] - stamps[i][1]) for i in range(len(stamps) - 1)]
     out["host_arrays"] = dict(value=J * nst / el, unit="particle-updates/s", steps=nst, ms_per_step=1e3 * el / nst,
                               host_forward_ms=fwd, update_call_ms=1e3 * el / nst - fwd * (nst + 1) / nst,
+                              host_forward_ms_median=float(np.median(fwd_ms)),
+                              update_call_ms_median=float(np.median(calls)) if calls else None,
                               host_threads=nthreads,
                               includes="sampling.run(trace=False) with a host forward map (numpy A @ U), float64 numpy "
                                        "arrays across PCIe into and out of every update; PCIe Gen5 floor for the "
