@@ -436,18 +436,21 @@ int gram_max_stage_rows();
 int launch_noise(Engine& e, uint64_t step_index, void* xi, hipStream_t s);
 int launch_stage_forward(Engine& e, const void* A, const void* b, hipStream_t s);   // A, b -> d_Wfwd, d_Wfwd_f, d_bfwd
 
-// RAII-less helper: records an event pair around a launch when profiling is on
+// Event pair for one profiled launch (cesx_profile_*).  bound = false: the pair is RECORDED around the launch (two
+// marker packets: they delay the stream by ~6 us each and the interval includes that).  bound = true: the caller
+// passes a / b to hipExtLaunchKernel, which ties them to the kernel's own start / end time stamps -- the interval
+// is the kernel's duration as rocprofv3 reports it, and no marker sits in front of the next launch.
 struct ProfScope {
-    Engine& e; int which; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(Engine& e_, int which_, hipStream_t s_) : e(e_), which(which_), s(s_) {
+    Engine& e; int which; hipStream_t s; hipEvent_t a = nullptr, b = nullptr; bool bound;
+    ProfScope(Engine& e_, int which_, hipStream_t s_, bool bound_ = false) : e(e_), which(which_), s(s_), bound(bound_) {
         if (!e.profile || which < 0) return;
         auto get = [&]() { hipEvent_t ev = nullptr; if (!e.prof_pool.empty()) { ev = e.prof_pool.back(); e.prof_pool.pop_back(); } else (void)hipEventCreate(&ev); return ev; };
         a = get(); b = get();
-        (void)hipEventRecord(a, s);
+        if (!bound) (void)hipEventRecord(a, s);
     }
     ~ProfScope() {
         if (!a) return;
-        (void)hipEventRecord(b, s);
+        if (!bound) (void)hipEventRecord(b, s);
         e.prof_ev[which].push_back({a, b});
     }
 };

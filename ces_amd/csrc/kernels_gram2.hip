@@ -32,6 +32,7 @@
 // and U, G are 16-byte aligned; otherwise the register-staged kernel runs.
 // Bound: MFMA (v_mfma_f32_32x32x2_f32 / v_mfma_f64_16x16x4_f64).
 #include "cesx_internal.h"
+#include <hip/hip_ext.h>
 
 namespace cesx {
 
@@ -330,7 +331,13 @@ static int launch_gram2_t(Engine& e, int part, const void* U, const void* G, hip
     auto kern = gram2_kernel<T>;
     CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     {
-        ProfScope prof(e, 0, s);
+        ProfScope prof(e, 0, s, true);
+        if (prof.a)
+            hipExtLaunchKernelGGL(kern, dim3(pl.total_wgs), dim3(G2_THREADS), (unsigned)lds, s, prof.a, prof.b, 0,
+                                  (const T*)U, (const T*)G, (const T*)e.d_shiftT, e.p, e.n, (long long)e.J,
+                                  (const int*)gp.d_type_hdr, pl.ntypes, (const int*)gp.d_rows, (const int*)gp.d_wblk,
+                                  (T*)gp.d_slabs, gp.d_rowsum_part);
+        else
         hipLaunchKernelGGL(kern, dim3(pl.total_wgs), dim3(G2_THREADS), lds, s, (const T*)U, (const T*)G,
                            (const T*)e.d_shiftT, e.p, e.n, (long long)e.J, gp.d_type_hdr, pl.ntypes, gp.d_rows,
                            gp.d_wblk, (T*)gp.d_slabs, gp.d_rowsum_part);

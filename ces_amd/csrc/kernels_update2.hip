@@ -19,6 +19,7 @@
 // (it would otherwise drain the ring with vmcnt(0) at the first ds_read of every tile).
 // Bound: MFMA (v_mfma_f32_32x32x2_f32).
 #include "cesx_internal.h"
+#include <hip/hip_ext.h>
 
 namespace cesx {
 
@@ -525,8 +526,9 @@ int launch_update2(Engine& e, int out_rows, const void* Wf, int ktot, const void
     e.last_update_grid_x = (int)grid.x;
     e.last_update_grid = (int)(grid.x * grid.y);
     {
-        ProfScope prof(e, opt.prof, s);
-        hipLaunchKernelGGL(kern, grid, dim3(U2_THREADS), lds, s, a);
+        ProfScope prof(e, opt.prof, s, true);
+        if (prof.a) hipExtLaunchKernelGGL(kern, grid, dim3(U2_THREADS), (unsigned)lds, s, prof.a, prof.b, 0, a);
+        else hipLaunchKernelGGL(kern, grid, dim3(U2_THREADS), lds, s, a);
     }
     CESX_HIP(hipGetLastError());
     return CESX_OK;

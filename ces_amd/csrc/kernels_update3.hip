@@ -20,6 +20,7 @@
 //  * one barrier per k-tile; two workgroups per CU cover each other's barrier and epilogue.
 // Bound: MFMA.
 #include "cesx_internal.h"
+#include <hip/hip_ext.h>
 
 namespace cesx {
 
@@ -290,8 +291,9 @@ int launch_update3(Engine& e, int out_rows, const void* Wd, int ktot, const void
     e.last_update_grid_x = (int)grid.x;
     e.last_update_grid = (int)(grid.x * grid.y);
     {
-        ProfScope prof(e, opt.prof, s);
-        hipLaunchKernelGGL(update3_kernel, grid, dim3(U3_THREADS), lds, s, a);
+        ProfScope prof(e, opt.prof, s, true);
+        if (prof.a) hipExtLaunchKernelGGL(update3_kernel, grid, dim3(U3_THREADS), (unsigned)lds, s, prof.a, prof.b, 0, a);
+        else hipLaunchKernelGGL(update3_kernel, grid, dim3(U3_THREADS), lds, s, a);
     }
     CESX_HIP(hipGetLastError());
     return CESX_OK;
