@@ -395,6 +395,39 @@ def test_prefetched_noise_block(eng_mod, dtype, tol, update):
     assert rel_err(a, g) > 1e-3
 
 
+def test_noise_lookahead_with_irregular_step_indices(eng_mod, monkeypatch):
+    """The two-buffer lookahead (the block of step s + 1 drawn behind chol(C) of step s) must never hand an update a
+    block of the wrong step: chains whose step indices jump, repeat and go backwards give, step by step, the same
+    ensembles as the same chains with the lookahead off and with the noise drawn inside the update kernel."""
+    from ces_amd.dist import ShardedUpdate
+    p, n, J = 64, 48, 4096
+    d = _synthetic(p, n, J, seed=91)
+    steps = [5, 6, 7, 9, 3, 4, 4, 5, 11]
+    outs = []
+    for mode in ("lookahead", "single", "in_kernel"):
+        monkeypatch.setenv("CESX_NOISE_LOOKAHEAD", "0" if mode == "single" else "1")
+        if mode == "in_kernel":
+            monkeypatch.setenv("CESX_NO_NOISE_PREFETCH", "1")
+        else:
+            monkeypatch.delenv("CESX_NO_NOISE_PREFETCH", raising=False)
+        eng = eng_mod.Engine(p, n, J, dtype="float32", seed=5)
+        eng.set_problem(d["y"], d["Gamma"], d["mu"], d["sigma"], d["ustar"])
+        sh = ShardedUpdate(eng)
+        U, G = eng.to_device(d["U0"]), eng.to_device(d["G"])
+        bufs = [eng.empty(p), eng.empty(p)]
+        chain = []
+        for k, si in enumerate(steps):
+            prm = eng_mod.step_params(update="aldi", first_step=(k == 0), t_len=min(k, 1), t_last=0.01 * k, step_index=si)
+            sh.begin(prm, U, G, recenter=(k == 0), noise_step=si)
+            U = sh.finish(prm, U, G, xi=None, out=bufs[k % 2])
+            chain.append(U.cpu().numpy().copy())
+            sh.result()
+        outs.append(chain)
+    for k in range(len(steps)):
+        assert np.array_equal(outs[0][k], outs[1][k]), "lookahead vs single buffer, step %d" % k
+        assert rel_err(outs[0][k], outs[2][k]) < 2e-6, "prefetched vs in-kernel noise, step %d" % k
+
+
 @pytest.mark.parametrize("dtype,tol", [("float64", 1e-9), ("float32", 1e-4)])
 def test_logical_shards_add_up(eng_mod, dtype, tol):
     """moments of N column shards sum to the moments of the whole
