@@ -267,7 +267,7 @@ void gram_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __re
 // handles RED_G 16-byte groups (4 f32 / 2 f64 along a block row) x RED_S slice
 // parts (each lane sums nslices / RED_S slices with up to 8 loads in flight);
 // the parts are combined through LDS in a fixed order.
-constexpr int RED_G = 16, RED_S = 16;
+constexpr int RED_G = 32, RED_S = 8;
 template <typename T>
 __global__ __launch_bounds__(256)
 void gram_reduce_kernel(const T* __restrict__ slabs, const int* __restrict__ blk_rc, const int* __restrict__ row_own,
