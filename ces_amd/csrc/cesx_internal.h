@@ -335,11 +335,9 @@ struct Engine {
     Scalars* h_scal = nullptr;           // pinned, device-mapped: the GPU writes results straight into it
     Scalars* h_scal_dev = nullptr;       // device address of h_scal
     unsigned long long seq = 0;
-    hipEvent_t ev = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;   // ev_c: side-stream centring done
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;      // hand-over main -> side (U x U moments reduced) / side -> main (chol(C) done)
     hipStream_t side = nullptr;      // side stream (high priority): U x U Gram, chol(C), the step's last small kernel
-    hipStream_t bg = nullptr;        // background stream (low priority): noise blocks drawn ahead into idle CUs
     hipEvent_t ev_x[2] = {nullptr, nullptr};   // prefetched noise block b is complete (side stream)
-    hipEvent_t ev_in = nullptr, ev_k3 = nullptr, ev_m = nullptr;   // (spare)
     // Noise blocks drawn ahead by cesx_prefetch_noise, [p][J] engine dtype each.  Two of them: behind chol(C) of the
     // step that asked for block s the side stream draws block s (unless an earlier step already did) AND block s + 1
     // (the lookahead), so that from the second step on the update kernel finds its block complete -- ordered before

@@ -181,11 +181,6 @@ const char* cesx_last_error(cesx_handle h) {
 static hipError_t create_side_stream(Engine& e) {
     int lo = 0, hi = 0;
     const bool prio = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo;
-    // background stream: LOW priority (its own hardware queue); its kernels only take CUs nothing else wants
-    if (!(prio && hipStreamCreateWithPriority(&e.bg, hipStreamNonBlocking, lo) == hipSuccess)) {
-        hipError_t rc = hipStreamCreateWithFlags(&e.bg, hipStreamNonBlocking);
-        if (rc != hipSuccess) return rc;
-    }
     if (prio && hipStreamCreateWithPriority(&e.side, hipStreamNonBlocking, hi) == hipSuccess) return hipSuccess;
     return hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking);
 }
@@ -321,13 +316,8 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
 #undef DM
     if (hipHostMalloc(reinterpret_cast<void**>(&e.h_scal), sizeof(Scalars), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void**>(&e.h_scal_dev), e.h_scal, 0) != hipSuccess ||
-        hipEventCreateWithFlags(&e.ev, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e.ev_a, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e.ev_b, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e.ev_c, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e.ev_in, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e.ev_k3, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e.ev_m, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e.ev_x[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e.ev_x[1], hipEventDisableTiming) != hipSuccess ||
         create_side_stream(e) != hipSuccess) {
@@ -372,14 +362,11 @@ void cesx_destroy(cesx_handle h) {
         for (auto& pr : e.prof_ev[w]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto ev : e.prof_pool) (void)hipEventDestroy(ev);
     if (e.h_scal) (void)hipHostFree(e.h_scal);
-    if (e.ev) (void)hipEventDestroy(e.ev);
     if (e.ev_a) (void)hipEventDestroy(e.ev_a);
     if (e.ev_b) (void)hipEventDestroy(e.ev_b);
-    if (e.ev_c) (void)hipEventDestroy(e.ev_c);
-    for (hipEvent_t ev : {e.ev_in, e.ev_k3, e.ev_m, e.ev_x[0], e.ev_x[1]})
+    for (hipEvent_t ev : {e.ev_x[0], e.ev_x[1]})
         if (ev) (void)hipEventDestroy(ev);
     if (e.side) (void)hipStreamDestroy(e.side);
-    if (e.bg) (void)hipStreamDestroy(e.bg);
     for (void* q : e.d_xi)
         if (q) (void)hipFree(q);
     delete &e;
