@@ -221,6 +221,11 @@ __device__ __forceinline__ void metric_final_body(const MetricFin& f) {
     double mine = 0.0;
     if (f.host != nullptr && threadIdx.x < ND)
         mine = __hip_atomic_load(reinterpret_cast<const double*>(f.sc) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double lag0 = 0.0, lag1 = 0.0, Nm = f.N;          // (thread 0's inputs from the moment buffer: also up front)
+    if (threadIdx.x == 0) {
+        lag0 = f.mom[f.tail_off]; lag1 = f.mom[f.tail_off + 1];
+        if (!(Nm > 0.0)) Nm = f.mom[0];
+    }
     double a = 0.0, b = 0.0;
     for (int i = threadIdx.x; i < f.nparts; i += blockDim.x) { a += f.part[(size_t)i * 2]; b += f.part[(size_t)i * 2 + 1]; }
 #pragma unroll
@@ -230,12 +235,12 @@ __device__ __forceinline__ void metric_final_body(const MetricFin& f) {
     if (threadIdx.x == 0) {
         a = 0.0; b = 0.0;
         for (int i = 0; i < (int)(blockDim.x >> 6) && i < 4; ++i) { a += mf_red[0][i]; b += mf_red[1][i]; }
-        const double N = f.N > 0.0 ? f.N : f.mom[0];
+        const double N = Nm;
         f.sums[0] = a; f.sums[1] = b;
         mf_out[0] = f.sc->bias_data = a / N;
         mf_out[1] = f.sc->self_bias_data = b / N;
-        mf_out[2] = f.sc->spare[1] = f.mom[f.tail_off] / N;          // lagged global bias-data
-        mf_out[3] = f.sc->spare[2] = f.mom[f.tail_off + 1] / N;      // lagged global self-bias-data
+        mf_out[2] = f.sc->spare[1] = lag0 / N;          // lagged global bias-data
+        mf_out[3] = f.sc->spare[2] = lag1 / N;          // lagged global self-bias-data
     }
     if (f.host == nullptr) return;
     // last kernel of an eks / aldi step: publish the results (see publish_kernel)
