@@ -148,35 +148,58 @@ __global__ void scale_cols_kernel(int rows, int cols, const double* __restrict__
     if (idx < (long long)rows * cols) out[idx] = A[idx] * w[idx % cols];
 }
 
-// C(m x n) = alpha * A(m x k) * B(k x n) with arbitrary element strides
+// C(m x n) = alpha * A(m x k) * B(k x n) with arbitrary element strides, fp64, on the matrix pipe: one wave per
+// 16 x 16 block of C (a workgroup = 2 x 2 blocks), v_mfma_f64_16x16x4_f64 with operands read straight from global
+// memory -- the matrices of K2 are a few hundred KB and L2-resident, a lane's A operand is A[i][k + lane/16], its B
+// operand B[k + lane/16][j] -- eight k-steps per batch, the next batch's loads in flight behind the current MFMAs.
+// (The LDS-staged VALU kernel this replaces took 40 us for 256^3: load, barrier, multiply, barrier, eight times.)
+using gemm_d4_t = double __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(DT)
 void gemm_kernel(int m, int n, int k, double alpha, const double* __restrict__ A, long long a0, long long a1,
                  const double* __restrict__ B, long long b0, long long b1, double* Cm, int ldc,
                  const double* Cin = nullptr) {       // Cin (may be Cm itself): C = Cin + alpha A B
-    __shared__ double sA[32][33], sB[32][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // ty in 0..7
-    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
-    double acc[4] = {0, 0, 0, 0};
-    for (int k0 = 0; k0 < k; k0 += 32) {
-        for (int r = ty; r < 32; r += 8) {
-            const int ia = i0 + r, ka = k0 + tx;
-            sA[r][tx] = (ia < m && ka < k) ? A[ia * a0 + ka * a1] : 0.0;
-            const int kb = k0 + r, jb = j0 + tx;
-            sB[r][tx] = (kb < k && jb < n) ? B[kb * b0 + jb * b1] : 0.0;
-        }
-        __syncthreads();
-#pragma unroll 8
-        for (int kk = 0; kk < 32; ++kk) {
-            const double b = sB[kk][tx];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r0 = (blockIdx.y * 2 + (wave >> 1)) * 16, c0 = (blockIdx.x * 2 + (wave & 1)) * 16;
+    if (r0 >= m || c0 >= n) return;
+    const int i = r0 + (lane & 15), j = c0 + (lane & 15), kk = lane >> 4;
+    const bool iok = i < m, jok = j < n;
+    const double* pa = A + (long long)(iok ? i : 0) * a0;
+    const double* pb = B + (long long)(jok ? j : 0) * b1;
+    constexpr int UN = 8;
+    gemm_d4_t acc = {0.0, 0.0, 0.0, 0.0};
+    double av[2][UN], bv[2][UN];
+    auto load = [&](int buf, int k0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] += sA[ty + 8 * r][kk] * b;
+        for (int u = 0; u < UN; ++u) {
+            const int kc = k0 + 4 * u + kk;
+            const bool kok = kc < k;
+            av[buf][u] = (iok && kok) ? pa[(long long)kc * a1] : 0.0;
+            bv[buf][u] = (jok && kok) ? pb[(long long)kc * b0] : 0.0;
         }
-        __syncthreads();
+    };
+    load(0, 0);
+    int buf = 0;
+    for (int k0 = 0; k0 < k; k0 += 4 * UN) {
+        if (k0 + 4 * UN < k) {
+            if (buf == 0) load(1, k0 + 4 * UN); else load(0, k0 + 4 * UN);
+        }
+        if (buf == 0) {
+#pragma unroll
+            for (int u = 0; u < UN; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0][u], bv[0][u], acc, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int u = 0; u < UN; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1][u], bv[1][u], acc, 0, 0, 0);
+        }
+        buf ^= 1;
     }
+    // C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int i = i0 + ty + 8 * r, j = j0 + tx;
-        if (i < m && j < n) Cm[(size_t)i * ldc + j] = (Cin ? Cin[(size_t)i * ldc + j] : 0.0) + alpha * acc[r];
+        const int row = r0 + kk + 4 * r;
+        if (row < m && jok) {
+            const size_t o = (size_t)row * ldc + j;
+            Cm[o] = (Cin ? Cin[o] : 0.0) + alpha * acc[r];
+        }
     }
 }
 
