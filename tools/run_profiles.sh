@@ -1,0 +1,15 @@
+#!/bin/bash
+# Round profiles on the GPU box (run through gpurun from the repo root):  bash tools/run_profiles.sh TAG CONFIG
+#   kernel trace + stats, then one rocprofv3 --pmc pass per counter (the guide's rule: counters in their own runs).
+# Results land under gpurun_out/prof_${TAG}_*; condense them here with tools/prof_summary.py.
+set -o pipefail
+TAG=$1; CFG=${2:-C2}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+ARGS="bench.py --config $CFG --no-cpu-baseline --no-extras --steps 12 --warmup 3"
+export CESX_BENCH_PREWARM=8
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_k -- python3 $ARGS > gpurun_out/prof_${TAG}_k.log 2>&1 || exit 2
+for ctr in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
+  rocprofv3 --pmc $ctr --output-format csv -d gpurun_out/prof_${TAG}_$ctr -- python3 $ARGS > gpurun_out/prof_${TAG}_$ctr.log 2>&1 || exit 3
+done
+python3 bench.py --config $CFG > gpurun_out/prof_${TAG}_bench.json 2> gpurun_out/prof_${TAG}_bench.err
+echo done $TAG $CFG
