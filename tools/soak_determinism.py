@@ -28,7 +28,51 @@ def screen(p, n, J, update, reps, dtype="float32"):
     print("%-14s %s p=%d n=%d J=%d: %d repeats, %d differ" % (update, dtype, p, n, J, reps, bad))
     return bad
 
+def chain(p, n, J, nsteps, pipelined, dtype="float32"):
+    """A chained run through ShardedUpdate (the drivers' loop): the output of step i is the input of step i + 1, G = A U
+    on the device.  pipelined: begin(i+1) before result(i) -- the path with the deferred publication, the bound
+    hand-over events and the noise lookahead all in play."""
+    from ces_amd.dist import ShardedUpdate
+    prob = bench.synthetic_problem(p, n)
+    eng = engine.Engine(p, n, J, dtype=dtype, seed=11)
+    eng.set_problem(prob["y"], prob["Gamma"], prob["mu"], prob["sigma"], prob["ustar"])
+    sh = ShardedUpdate(eng)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    U = torch.as_tensor(prob["ustar"], device="cuda", dtype=eng.torch_dtype) + torch.randn((p, J), generator=g, device="cuda", dtype=eng.torch_dtype)
+    A = torch.as_tensor(prob["A"], device="cuda", dtype=eng.torch_dtype)
+    bufs = [eng.empty(p), eng.empty(p)]
+    Gs = [eng.forward_lineal(A, U), None]
+    t_last, hks = 0.0, []
+    def prm(i, t_last):
+        return engine.step_params(update="aldi", first_step=(i == 0), t_len=min(i, 1), t_last=t_last, step_index=i)
+    sh.begin(prm(0, 0.0), U, Gs[0], recenter=True, noise_step=0)
+    for i in range(nsteps):
+        out = sh.finish(prm(i, t_last), U, Gs[i % 2], xi=None, out=bufs[i % 2])
+        if i + 1 < nsteps:
+            Gs[(i + 1) % 2] = eng.forward_lineal(A, out)
+            if pipelined:
+                sh.begin(prm(i + 1, 0.0), out, Gs[(i + 1) % 2], noise_step=i + 1)
+        res = sh.result()
+        if i + 1 < nsteps and not pipelined:
+            sh.begin(prm(i + 1, 0.0), out, Gs[(i + 1) % 2], noise_step=i + 1)
+        t_last = res.t_new
+        hks.append((res.hk, res.bias_data, res.self_bias_data, res.bias))
+        U = out
+    return U.clone(), hks
+
+def chain_screen(p, n, J, nsteps, dtype="float32"):
+    a, ha = chain(p, n, J, nsteps, True, dtype)
+    b, hb = chain(p, n, J, nsteps, True, dtype)
+    c, hc = chain(p, n, J, nsteps, False, dtype)
+    bad = int(not torch.equal(a, b)) + int(ha != hb) + int(not torch.equal(a, c)) + int(ha != hc)
+    print("chain %s p=%d n=%d J=%d, %d steps: pipelined twice + step-by-step, %d mismatches (t_end %.4f)" %
+          (dtype, p, n, J, nsteps, bad, sum(h[0] for h in ha)))
+    return bad
+
 bad = 0
+bad += chain_screen(256, 256, 65536, 1500)
+bad += chain_screen(96, 80, 5000, 1500)
+bad += chain_screen(256, 256, 8192, 400, "float64")
 bad += screen(256, 256, 65536, "aldi", 400)
 bad += screen(256, 256, 65536, "aldi_constant", 100)
 bad += screen(256, 256, 65536, "eks", 60)
