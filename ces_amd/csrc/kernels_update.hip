@@ -369,19 +369,36 @@ __global__ void absmax_final_kernel(const double* __restrict__ part, int nparts,
     if (threadIdx.x == 0) out[0] = red[0];
 }
 
-// xi block alone (tests of the generator): xi[r][j] for r < p
-template <typename T>
-__global__ void noise_kernel(T* __restrict__ xi, int p, long long J, long long j_offset, unsigned seed_lo,
-                             unsigned seed_hi, unsigned step) {
-    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+// xi block alone (the block drawn ahead by cesx_prefetch_noise; tests of the generator): xi[r][j] for r < p.
+// A thread draws the 4 x 4 block of rows 4q..4q+3 x particles j0..j0+3 -- four independent Philox chains in flight,
+// one 16-byte store per row -- when VEC4 (J a multiple of 4, 16-byte aligned rows); one particle otherwise.  The
+// numbers are a function of (seed, step, row quad, global particle index) alone.
+template <typename T, bool VEC4>
+__global__ __launch_bounds__(256)
+void noise_kernel(T* __restrict__ xi, int p, long long J, long long j_offset, unsigned seed_lo,
+                  unsigned seed_hi, unsigned step) {
+    constexpr int NP = VEC4 ? 4 : 1;
+    const long long j0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * NP;
     const int q = blockIdx.y;
-    if (j >= J) return;
-    const unsigned long long gj = (unsigned long long)(j_offset + j);
-    const uint4x r = philox4x32_10((uint32_t)gj, (uint32_t)(gj >> 32), (uint32_t)q, step, seed_lo, seed_hi);
-    T z[4];
-    normal4(r, z);
-    for (int e = 0; e < 4; ++e)
-        if (4 * q + e < p) xi[(size_t)(4 * q + e) * J + j] = z[e];
+    if (j0 >= J) return;
+    T z[NP][4];
+#pragma unroll
+    for (int c = 0; c < NP; ++c) {
+        const unsigned long long gj = (unsigned long long)(j_offset + j0 + c);
+        const uint4x r = philox4x32_10((uint32_t)gj, (uint32_t)(gj >> 32), (uint32_t)q, step, seed_lo, seed_hi);
+        normal4(r, z[c]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (4 * q + e >= p) break;
+        T* dst = xi + (size_t)(4 * q + e) * J + j0;
+        if (VEC4) {
+            typedef T v4 __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<v4*>(dst) = v4{z[0][e], z[NP > 1 ? 1 : 0][e], z[NP > 2 ? 2 : 0][e], z[NP > 3 ? 3 : 0][e]};
+        } else {
+            dst[0] = z[0][e];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -474,15 +491,18 @@ int launch_absmax_final(Engine& e, int nparts, double* absmax_out, hipStream_t s
 }
 
 int launch_noise(Engine& e, uint64_t step_index, void* xi, hipStream_t s) {
-    dim3 grid((unsigned)((e.J + 255) / 256), (unsigned)((e.p + 3) / 4));
-    if (e.cfg.dtype == CESX_F32)
-        hipLaunchKernelGGL(noise_kernel<float>, grid, dim3(256), 0, s, (float*)xi, e.p, (long long)e.J,
-                           (long long)e.cfg.j_offset, (unsigned)e.cfg.seed, (unsigned)(e.cfg.seed >> 32),
-                           (unsigned)step_index);
-    else
-        hipLaunchKernelGGL(noise_kernel<double>, grid, dim3(256), 0, s, (double*)xi, e.p, (long long)e.J,
-                           (long long)e.cfg.j_offset, (unsigned)e.cfg.seed, (unsigned)(e.cfg.seed >> 32),
-                           (unsigned)step_index);
+    const bool vec4 = e.J % 4 == 0 && ((uintptr_t)xi % (4 * e.esz)) == 0;
+    const long long per = vec4 ? 4 : 1;
+    dim3 grid((unsigned)((e.J / per + 255) / 256), (unsigned)((e.p + 3) / 4));
+    auto go = [&](auto kern, auto* ptr) {
+        hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, ptr, e.p, (long long)e.J, (long long)e.cfg.j_offset,
+                           (unsigned)e.cfg.seed, (unsigned)(e.cfg.seed >> 32), (unsigned)step_index);
+    };
+    if (e.cfg.dtype == CESX_F32) {
+        if (vec4) go(noise_kernel<float, true>, (float*)xi); else go(noise_kernel<float, false>, (float*)xi);
+    } else {
+        if (vec4) go(noise_kernel<double, true>, (double*)xi); else go(noise_kernel<double, false>, (double*)xi);
+    }
     CESX_HIP(hipGetLastError());
     return CESX_OK;
 }
