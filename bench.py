@@ -373,8 +373,8 @@ def main():
         return res
 
     # untimed pre-warm before the W warmup steps: the first ~30 steps after start-up run 3-5 % slower
-    # (clock / power state, code objects, allocator); 64 steps = 32 ms reach the steady state
-    prewarm = int(os.environ.get("CESX_BENCH_PREWARM", "64"))
+    # (clock / power state, code objects, allocator); 192 steps = 80 ms reach the steady state with margin
+    prewarm = int(os.environ.get("CESX_BENCH_PREWARM", "192"))
     run_steps(0, prewarm)
     t_hist[0] = 0.0
     eng.profile_enable(True)                    # creates the event pool outside the timed region
@@ -393,12 +393,16 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     del stamps[:]
+    import gc
+    gc.collect()
+    gc.disable()                                # no collector pause inside the timed region (a few hundred us each)
     t0 = time.perf_counter()
     res = run_steps(args.warmup, args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     per_step = np.diff(np.array([t0] + stamps)) * 1e3       # ms between consecutive results (pipelined loop)
     prof["on"] = False
     eng.profile_enable(False)
