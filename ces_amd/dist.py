@@ -100,8 +100,8 @@ class ShardedUpdate:
         driver may enqueue ``begin`` of step i+1 BEFORE it reads the result of step i: the
         host's read (ces/calibrate.py:387 tests ``t`` every iteration) then overlaps the Gram
         of the next step instead of idling the GPU.  ``noise_step``: Philox step index of the
-        update this ``begin`` belongs to -- its noise block is then drawn ahead on the engine's
-        background stream (cesx_prefetch_noise) instead of inside the update kernel.
+        update this ``begin`` belongs to -- its noise block (and that of the next step) is then drawn
+        ahead on the engine's side stream (cesx_prefetch_noise) instead of inside the update kernel.
 
         Whether the head all-reduce runs on the side stream is decided ONCE, at construction
         (``overlap_comm``): a collective that may already have been enqueued is never retried,
