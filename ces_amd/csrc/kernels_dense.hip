@@ -949,7 +949,9 @@ __global__ __launch_bounds__(PRT, 2)
 void trsm_reg_kernel(int nr, int nc, const double* __restrict__ A, int lda, const double* __restrict__ L, int ldl,
                      double* __restrict__ X, int ldx) {
     __shared__ double XP[QNB][64 + 4];        // the panel: current values, then the solution (column major)
-    __shared__ double LB[QNB][256 + 4];       // L[r][kb + j] for r >= kb + j, 0 above the diagonal
+    __shared__ double LBs[2][QNB][256 + 4];   // L[r][kb + j] for r >= kb + j, 0 above the diagonal; double buffered:
+                                              // the next panel's columns are fetched from global memory while this
+                                              // panel is solved and applied (a ~2 us round trip per panel otherwise)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = nc / 16;                    // tile columns
@@ -971,9 +973,29 @@ void trsm_reg_kernel(int nr, int nc, const double* __restrict__ A, int lda, cons
             Pt[s][e] = (on && i < nr) ? (A ? A[(size_t)i * lda + j] : (i == j + lda ? 1.0 : 0.0)) : 0.0;
         }
     }
+    // panel columns of L: thread -> (column j = tid & 7, rows (kbn & ~15) + (tid >> 3) + 64 u), nc <= 256: u < 4
+    const int lj = tid & 7;
+    double lreg[4];
+    auto load_l = [&](int kbn) {
+#pragma clang loop unroll(full)
+        for (int u = 0; u < 4; ++u) {
+            const int r = (kbn & ~15) + (tid >> 3) + 64 * u;
+            lreg[u] = (kbn < nc && r < nc && r >= kbn + lj) ? L[(size_t)r * ldl + kbn + lj] : 0.0;
+        }
+    };
+    auto store_l = [&](int kbn, int buf) {
+#pragma clang loop unroll(full)
+        for (int u = 0; u < 4; ++u) {
+            const int r = (kbn & ~15) + (tid >> 3) + 64 * u;
+            if (kbn < nc && r < nc) LBs[buf][lj][r] = lreg[u];
+        }
+    };
+    load_l(0);
+    store_l(0, 0);
     for (int kb = 0; kb < nc; kb += QNB) {
         const int kn = kb + QNB;
-        // (a) the panel's columns of the tiles that hold them -> XP; L[., kb .. kb+7] -> LB
+        double (*LB)[256 + 4] = LBs[(kb / QNB) & 1];
+        // (a) the panel's columns of the tiles that hold them -> XP; the NEXT panel's columns of L on their way
 #pragma clang loop unroll(full)
         for (int s = 0; s < SLOTS; ++s) {
             if (tR[s] >= 0 && tC[s] == kb / 16) {
@@ -984,10 +1006,7 @@ void trsm_reg_kernel(int nr, int nc, const double* __restrict__ A, int lda, cons
                 }
             }
         }
-        for (int r = (kb & ~15) + (tid >> 3); r < nc; r += PRT / 8) {
-            const int j = tid & 7;
-            LB[j][r] = r >= kb + j ? L[(size_t)r * ldl + kb + j] : 0.0;
-        }
+        load_l(kn);
         __syncthreads();
         // (b) one row per thread: x L_kk^T = a
         if (tid < 64) {
@@ -1023,6 +1042,7 @@ void trsm_reg_kernel(int nr, int nc, const double* __restrict__ A, int lda, cons
                     Pt[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[h], bv[h], Pt[s], 0, 0, 0);
             }
         }
+        store_l(kn, ((kb / QNB) & 1) ^ 1);
         __syncthreads();
     }
 }
