@@ -374,8 +374,24 @@ def main():
 
     # untimed pre-warm before the W warmup steps: the first ~30 steps after start-up run 3-5 % slower
     # (clock / power state, code objects, allocator); 192 steps = 80 ms reach the steady state with margin
-    prewarm = int(os.environ.get("CESX_BENCH_PREWARM", "192"))
-    run_steps(0, prewarm)
+    prewarm_min = int(os.environ.get("CESX_BENCH_PREWARM", "192"))
+    prewarm, last = 0, None
+    while prewarm < 1536:
+        # in batches of 32 steps until the batch time has settled (after a start-up or an idle GPU the clocks take
+        # tens of milliseconds, sometimes more, to come up), at least prewarm_min steps
+        tb = time.perf_counter()
+        run_steps(0, 32)
+        torch.cuda.synchronize()
+        tb = time.perf_counter() - tb
+        prewarm += 32
+        settled = last is not None and abs(tb - last) <= 0.015 * last
+        last = tb
+        if world > 1 or rehearse:               # every rank must run the same number of steps (collectives inside)
+            flag = torch.tensor([1.0 if settled else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            settled = bool(flag.item() > 0.5)
+        if prewarm >= prewarm_min and (settled or prewarm_min == 0):
+            break
     t_hist[0] = 0.0
     eng.profile_enable(True)                    # creates the event pool outside the timed region
     eng.profile_enable(False)
