@@ -765,6 +765,63 @@ int cesx_profile_read(cesx_handle h, int which, double* total_ms, int* launches)
     return CESX_OK;
 }
 
+// Host-only: builds the Gram work partition a handle of this shape would use (no device needed) and checks its
+// invariants.  Returns the number of violations; info[0..5] = {types, workgroups, blocks, busiest workgroup's
+// tiles x blocks-per-SIMD, max staged row blocks, slabs}.
+int cesx_debug_gram_plan(int p, int n_obs, int dtype, int part, int wg_budget, long long J_local, int* info) {
+    if (p < 1 || n_obs < 1 || (dtype != CESX_F32 && dtype != CESX_F64) || part < 0 || part > 1 || J_local < 1) return -1;
+    try {
+        const int P = p + n_obs, tile = gram_tile(dtype), kt = gram_kt(dtype), nbw = gram_nbw(dtype);
+        const int pbU = (p + tile - 1) / tile;
+        const long long ntiles = (J_local + kt - 1) / kt;
+        const GramPlan pl = make_gram_plan(P, tile, nbw, gram_max_stage_rows(), part + 1, pbU, 1, wg_budget, ntiles);
+        const int nbr = (P + tile - 1) / tile;
+        int bad = 0;
+        std::vector<int> seen((size_t)nbr * nbr, 0);
+        long long wgs = 0, slabs = 0, worst = 0;
+        if ((int)pl.type_hdr.size() != pl.ntypes * 8) ++bad;
+        for (int t = 0; t < pl.ntypes && !bad; ++t) {
+            const int* h = &pl.type_hdr[(size_t)t * 8];
+            const int nrb = h[0], rows_off = h[1], blocks_off = h[2], nblk = h[3], wg0 = h[4], nsl = h[5];
+            if (nrb < 1 || nrb * tile > gram_max_stage_rows() || nrb > pl.max_rb) ++bad;
+            if (nsl < 1 || (long long)nsl > std::max<long long>(1, ntiles)) ++bad;
+            if (wg0 != wgs || h[6] != slabs) ++bad;
+            wgs += nsl; slabs += (long long)nsl * nblk;
+            const long long tps = (ntiles + nsl - 1) / nsl;
+            if (tps * nsl < ntiles) ++bad;
+            int per_simd[4] = {0, 0, 0, 0}, cnt = 0;
+            for (int w = 0; w < 16; ++w)
+                for (int b = 0; b < nbw; ++b) {
+                    const int* e3 = &pl.wblk[((size_t)blocks_off + (size_t)w * nbw + b) * 3];
+                    if (e3[0] < 0) continue;
+                    if (e3[0] >= nrb || e3[1] >= nrb || e3[2] < 0 || e3[2] >= nblk) { ++bad; continue; }
+                    const int R = pl.rows[rows_off + e3[0]] & 0xffff, C = pl.rows[rows_off + e3[1]] & 0xffff;
+                    if (R >= nbr || C > R) { ++bad; continue; }
+                    ++seen[(size_t)R * nbr + C];
+                    ++per_simd[w & 3]; ++cnt;
+                }
+            if (cnt != nblk) ++bad;
+            const int mx = std::max(std::max(per_simd[0], per_simd[1]), std::max(per_simd[2], per_simd[3]));
+            worst = std::max(worst, tps * mx);
+        }
+        int nwant = 0;
+        for (int R = 0; R < nbr; ++R)
+            for (int C = 0; C <= R; ++C) {
+                const bool uu = R < pbU && C < pbU;
+                const bool wanted = part == 0 ? uu : !uu;
+                nwant += wanted ? 1 : 0;
+                if (seen[(size_t)R * nbr + C] != (wanted ? 1 : 0)) ++bad;      // every wanted block exactly once, no other
+            }
+        if (nwant != pl.nblocks) ++bad;
+        if (wgs != pl.total_wgs || slabs != pl.total_slabs) ++bad;
+        if (pl.nblocks > 0 && pl.total_wgs > std::max(wg_budget, pl.ntypes)) ++bad;
+        if (info) { info[0] = pl.ntypes; info[1] = pl.total_wgs; info[2] = pl.nblocks; info[3] = (int)worst; info[4] = pl.max_rb; info[5] = pl.total_slabs; }
+        return bad;
+    } catch (...) {
+        return -2;
+    }
+}
+
 int cesx_debug_dense(cesx_handle h, double* ubar, double* gbar, double* C, double* L, double* K, double* M) {
     if (!h) return CESX_EINVAL;
     Engine& e = *reinterpret_cast<Engine*>(h);

@@ -25,7 +25,7 @@ EXPORTS = ("cesx_abi_version", "cesx_create", "cesx_destroy", "cesx_last_error",
            "cesx_moments", "cesx_apply", "cesx_apply_drift", "cesx_apply_finish", "cesx_draw_noise",
            "cesx_forward_lineal", "cesx_debug_dense", "cesx_profile_enable", "cesx_profile_read",
            "cesx_moments_uu_len", "cesx_moments_uu", "cesx_chol_async", "cesx_moments_rest", "cesx_side_stream",
-           "cesx_prefetch_noise", "cesx_forward_set_lineal", "cesx_forward_apply", "cesx_moments_uu_chol", "cesx_moments_uu_handover")
+           "cesx_prefetch_noise", "cesx_forward_set_lineal", "cesx_forward_apply", "cesx_moments_uu_chol", "cesx_moments_uu_handover", "cesx_debug_gram_plan")
 
 
 class Config(C.Structure):
@@ -100,6 +100,7 @@ def load_library(path=None):
     lib.cesx_forward_set_lineal.argtypes = [vp, vp, vp, vp]
     lib.cesx_forward_apply.argtypes = [vp, vp, vp, vp]
     lib.cesx_debug_dense.argtypes = [vp, dp, dp, dp, dp, dp, dp]
+    lib.cesx_debug_gram_plan.argtypes = [i32, i32, i32, i32, i32, C.c_longlong, C.POINTER(C.c_int)]
     lib.cesx_profile_enable.argtypes = [vp, i32]
     lib.cesx_profile_read.argtypes = [vp, i32, dp, C.POINTER(C.c_int)]
     if lib.cesx_abi_version() != ABI_VERSION:

@@ -267,6 +267,13 @@ int cesx_forward_apply(cesx_handle h, const void* U_dev, void* G_dev, void* stre
 int cesx_profile_enable(cesx_handle h, int on);
 int cesx_profile_read(cesx_handle h, int which, double* total_ms, int* launches);
 
+/* Host-only introspection for tests: the work partition of the moments launch `part` (0: U x U blocks, 1: the
+   others) for a handle of this shape and workgroup budget, checked for its invariants (every wanted block of the
+   lower triangle exactly once, slices x whole tiles cover J, staged rows fit in LDS, workgroups within the budget).
+   Returns the number of violations (0 = sound), < 0 on bad arguments; info[6] (optional) = {types, workgroups,
+   blocks, busiest workgroup's tiles x blocks per SIMD, max staged row blocks, slabs}.  Needs no device. */
+int cesx_debug_gram_plan(int p, int n_obs, int dtype, int part, int wg_budget, long long J_local, int* info);
+
 /* Copies the engine's current small dense state to HOST buffers (any may be
    NULL): ubar (p), gbar (n), C (p x p), L = chol(C) (p x p), K (p x n),
    M = C Sigma^{-1} (p x p).  Synchronises. */

@@ -120,3 +120,27 @@ def test_product_path_fails_loudly_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError, match="no CPU path"):
         engine.Engine(2, 3, 8)
+
+
+def test_gram_work_partition_invariants(lib):
+    """The work partition of both moments launches (make_gram_plan, kernels_gram.hip; host code, no device): for a
+    sweep of shapes, shard sizes, dtypes and workgroup budgets every wanted block of the lower triangle is dealt to
+    exactly one wave of one type, the slices of a type cover J in whole tiles, the staged rows fit in LDS and the
+    launch stays within its workgroup budget; at the benchmark shape the busiest workgroup of the second launch is
+    within 3 % of a perfectly level one."""
+    info = (ctypes.c_int * 6)()
+    shapes = [(256, 256), (2, 2), (10, 6), (33, 17), (64, 50), (96, 80), (300, 40), (40, 300), (250, 250), (512, 512),
+              (700, 96), (130, 520)]
+    for p, n in shapes:
+        for dtype in (0, 1):
+            for J in (32, 1004, 4096, 65536, 524288):
+                for budget in (256, 248, 224, 64, 3):
+                    for part in (0, 1):
+                        bad = lib.cesx_debug_gram_plan(p, n, dtype, part, budget, J, info)
+                        assert bad == 0, (p, n, dtype, J, budget, part, bad, list(info))
+    # C2, second launch, 248 workgroups: 100 blocks x 2048 tiles over 4 SIMDs x 248 workgroups = 206.5 block-tiles each
+    assert lib.cesx_debug_gram_plan(256, 256, 0, 1, 248, 65536, info) == 0
+    assert info[2] == 100 and info[1] <= 248 and info[3] <= 1.03 * 100 * 2048 / 4 / info[1] + 1
+    assert lib.cesx_debug_gram_plan(256, 256, 0, 0, 256, 65536, info) == 0
+    assert info[2] == 36 and info[1] == 256
+    assert lib.cesx_debug_gram_plan(0, 4, 0, 0, 256, 64, None) < 0
