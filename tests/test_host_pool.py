@@ -1,0 +1,63 @@
+"""CPU checks of the host-side result-array pool of the drop-in path (ces_amd/engine.py::Engine._HostOutPool):
+arrays the loop is done with go round instead of being unmapped and page-faulted again -- but never one that
+somebody still refers to."""
+import time
+
+import numpy as np
+
+from ces_amd.engine import Engine
+
+
+def _wait(cond, timeout=5.0):
+    t0 = time.time()
+    while not cond() and time.time() - t0 < timeout:
+        time.sleep(0.002)
+    return cond()
+
+
+def test_pool_hands_out_fresh_writable_float64_arrays():
+    pool = Engine._HostOutPool(depth=2)
+    a = pool.get((8, 70000))
+    b = pool.get((8, 70000))
+    assert a.shape == b.shape == (8, 70000) and a.dtype == np.float64 and a.flags.c_contiguous
+    assert a.ctypes.data != b.ctypes.data
+    a[:] = 1.0
+    b[:] = 2.0
+    assert float(a.sum()) == 8 * 70000 and float(b.sum()) == 2 * 8 * 70000
+
+
+def test_discarded_array_is_recycled_only_when_unreferenced():
+    pool = Engine._HostOutPool(depth=2)
+    shape = (4, 200000)                      # 6.4 MB: above the helper's "large array" threshold
+    a = pool.get(shape)
+    addr = a.ctypes.data
+    pool.discard([a])
+    del a                                     # the caller drops its reference right after discard()
+    assert _wait(lambda: pool.recycled == 1)
+    got = [pool.get(shape) for _ in range(4)]
+    assert addr in [g.ctypes.data for g in got], "the discarded array should come round again"
+    # a discarded array that is still referenced elsewhere must NOT be handed out again
+    keep = pool.get(shape)
+    keep[:] = 7.0
+    before = pool.recycled
+    pool.discard([keep])                      # `keep` stays referenced here
+    time.sleep(0.05)
+    others = [pool.get(shape) for _ in range(4)]
+    assert pool.recycled == before
+    assert keep.ctypes.data not in [g.ctypes.data for g in others]
+    assert float(keep[0, 0]) == 7.0
+
+
+def test_pool_ignores_foreign_shapes_and_views():
+    pool = Engine._HostOutPool(depth=1)
+    shape = (4, 200000)
+    a = pool.get(shape)
+    base = np.empty((8, 200000))
+    view = base[:4]                           # not the owner of its data
+    other = np.empty((2, 200000))             # another shape
+    before = pool.recycled
+    pool.discard([view, other])
+    del view, other
+    time.sleep(0.05)
+    assert pool.recycled == before
+    assert a.shape == shape
