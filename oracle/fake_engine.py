@@ -15,6 +15,7 @@ import torch
 
 class FakeEngine:
     def __init__(self, p, n_obs, J, J_global=None, j_offset=0, seed=1234):
+        self.calls = []
         self.p, self.n_obs, self.J = p, n_obs, J
         self.seed = seed
         self.drawn_steps = []           # Philox step indices the driver asked noise for
@@ -73,6 +74,15 @@ class FakeEngine:
 
     def chol_async(self, prm, mom):
         pass                                     # the stand-in factors C inside apply()
+
+    # the sharded driver's stream-overlap branch (ces_amd/dist.py): on the CPU there are no streams, the order of
+    # the calls and of the collectives is what a gloo test of that branch checks
+    def moments_uu_handover(self, U, G, out=None):
+        self.calls.append("uu_handover")
+        return self.moments_uu(U, G, out=out)
+
+    def side_stream(self):
+        return None                              # torch.cuda.stream(None) is a no-op context
 
     def moments_rest(self, U, G, mom):
         p = self.p

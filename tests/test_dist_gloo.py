@@ -35,7 +35,7 @@ def _problem(p, n, J, T, seed=3):
     return dict(A=A, ustar=ustar, Gamma=Gamma, sigma=sigma, mu=mu, y=y, U0=U0, xis=xis)
 
 
-def _worker(rank, world, port, update, kwargs, q, device_hook=False, dims=(5, 4, 37, 6)):
+def _worker(rank, world, port, update, kwargs, q, device_hook=False, dims=(5, 4, 37, 6), overlap=False):
     sys.path.insert(0, ROOT)
     from ces_amd.dist import ShardedSampler, shard_range
     from ces_amd.utils import lineal
@@ -47,6 +47,8 @@ def _worker(rank, world, port, update, kwargs, q, device_hook=False, dims=(5, 4,
     eng = FakeEngine(p, n, hi - lo, J_global=J, j_offset=lo)
     smp = ShardedSampler(eng, p, n, J)
     smp.T = T
+    if overlap:                              # the N > 1 GPU branch of ShardedUpdate.begin (hand-over + side-stream collective)
+        smp.sh.overlap_comm = True
     class HostLineal:                        # the stand-in has no device hook: host loop per particle
         type, n_obs, model_name = "map", n, "lineal"
 
@@ -61,6 +63,8 @@ def _worker(rank, world, port, update, kwargs, q, device_hook=False, dims=(5, 4,
                     update=update, xis=d["xis"][:, :, lo:hi], t_tol=1e9, **kwargs)
         gathered = [None] * world
         dist.all_gather_object(gathered, (lo, U.numpy()))
+        if overlap:
+            assert eng.calls.count("uu_handover") >= T, eng.calls
         if rank == 0:
             full = np.concatenate([g[1] for g in sorted(gathered, key=lambda g: g[0])], axis=1)
             q.put((full, {k: list(v) for k, v in smp.metrics.items()}, list(smp.radspec)))
@@ -108,6 +112,26 @@ def _check_against_oracle(full, metrics, radspec, dims, update, kwargs):
     for k in ("self-bias", "self-bias-data", "bias-data", "bias", "t"):
         assert len(metrics[k]) == T
         assert np.allclose(metrics[k], st.metrics[k], rtol=1e-9), k
+
+
+@pytest.mark.parametrize("update,kwargs,hook", [("aldi", {}, True), ("aldi", {}, False), ("aldi_constant", {"switch": 0.5}, True)])
+def test_two_ranks_stream_overlap_branch(update, kwargs, hook):
+    """The branch of ShardedUpdate.begin that N > 1 GPU runs take (U x U moments with the hand-over on the caller's
+    stream, all-reduce of the head + chol(C) under the side-stream context, the rest of the moments, the second
+    all-reduce) driven by two gloo ranks on the CPU: the same collectives in the same order on every rank, the same
+    numbers as the single-process oracle."""
+    dims = (5, 4, 37, 6)
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, update, kwargs, q, hook, dims, True)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    full, metrics, radspec = q.get(timeout=120)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    _check_against_oracle(full, metrics, radspec, dims, update, kwargs)
 
 
 @pytest.mark.parametrize("update,kwargs,hook", [("aldi_constant", {"switch": 0.5}, True), ("aldi", {}, False)])
