@@ -209,7 +209,7 @@ int launch_publish(Engine& e, hipStream_t s) {
 MetricFin metric_fin_args(Engine& e, const double* mom, bool publish) {
     const int nparts = e.diag_gamma ? e.last_metric_parts : (int)((e.J + 63) / 64);
     return MetricFin{e.d_metric_part, nparts, mom, e.ml.tail(), e.d_metric_sums, e.d_scal,
-                     publish ? e.h_scal_dev : (Scalars*)nullptr, publish ? ++e.seq : 0ull};
+                     publish ? e.h_scal_dev : (Scalars*)nullptr, publish ? ++e.seq : 0ull, 0.0};
 }
 
 int launch_metric_final(Engine& e, const double* mom, bool publish, hipStream_t s) {
