@@ -51,6 +51,7 @@ constexpr int G2_SLOT = G2_MAX_ROWS * G2_ROWB;           // one tile in LDS: 64 
 #ifdef G2_CLOCKS
 __device__ long long g_gram2_clk[4096 * 4];
 __device__ long long g_gram2_bar[4096 * 16];      // per wave: cycles spent in the per-tile barrier
+__device__ long long g_gram2_pro[4096 * 4];       // prologue phases of wave 0: tables | row table + sync | first DMA | shift + barrier
 #endif
 
 template <typename T>
@@ -108,6 +109,9 @@ void gram2_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __r
     for (int b = 0; b < NBW; ++b)
 #pragma unroll
         for (int r = 0; r < M::NACC; ++r) acc[b][r] = 0;
+#ifdef G2_CLOCKS
+    const long long gp1 = clock64();
+#endif
 
     // J-slice of this workgroup in whole tiles (J % KT == 0)
     const long long ntiles = J / KT;
@@ -131,6 +135,9 @@ void gram2_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __r
         rowshift[row] = sh;
     }
     __syncthreads();
+#ifdef G2_CLOCKS
+    const long long gp2 = clock64();
+#endif
 
     // DMA pieces of this wave: piece q = wave + 16 i = (block row q / NGROUP, k-group q % NGROUP);
     // lane = (row of the block row, physical chunk).  Per-lane source pointers live in registers and advance by
@@ -212,9 +219,18 @@ void gram2_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __r
     if (t0 < t1) {
         issue_tile(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef G2_CLOCKS
+        if (tid == 0 && blockIdx.x < 4096) g_gram2_pro[blockIdx.x * 4 + 2] = clock64() - gp2;
+#endif
         shift_tile(0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef G2_CLOCKS
+    if (tid == 0 && blockIdx.x < 4096) {
+        g_gram2_pro[blockIdx.x * 4 + 0] = gp1 - gclk0; g_gram2_pro[blockIdx.x * 4 + 1] = gp2 - gp1;
+        g_gram2_pro[blockIdx.x * 4 + 3] = clock64() - gp2;
+    }
+#endif
 #ifdef G2_CLOCKS
     const long long gclk1 = clock64();
     long long gbar = 0;

@@ -78,6 +78,14 @@ int run(int subset, int budget, int p, int n, long long J) {
             double ww = 0, lp = 0; for (int i = w0; i < w0 + ns; ++i) { ww += c[4 * i + 3]; lp += c[4 * i + 1]; }
             printf("    type %2d: %3d blocks, %2d row blocks, %3d slices: WG wall %.1f us, loop %.0f cycles\n", t, pl.type_hdr[t * 8 + 3], pl.type_hdr[t * 8 + 0], ns, ww / ns / 100, lp / ns);
         }
+        {
+            std::vector<long long> pr(grid.x * 4);
+            hipMemcpyFromSymbol(pr.data(), HIP_SYMBOL(g_gram2_pro), pr.size() * 8);
+            double q[4] = {0, 0, 0, 0};
+            for (unsigned i = 0; i < grid.x; ++i) for (int k = 0; k < 4; ++k) q[k] += pr[4 * i + k];
+            printf("  prologue phases (avg cycles): tables+acc %.0f | row table+sync %.0f | first DMA wait %.0f | DMA+shift+barrier %.0f\n",
+                   q[0] / grid.x, q[1] / grid.x, q[2] / grid.x, q[3] / grid.x);
+        }
         printf("  wave 0 per WG: prologue %.0f, loop %.0f, epilogue %.0f cycles; WG wall %.1f us (max %.1f) -> %.0f MHz\n", a0 / grid.x, a1 / grid.x, a2 / grid.x,
                w / grid.x / 100, wmax / 100, (a0 + a1 + a2) / w * 100);
     }
