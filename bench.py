@@ -73,6 +73,20 @@ def limit_host_threads():
     return n
 
 
+def sysfs_sclk():
+    """The shader-clock level sysfs marks as current (an instantaneous sample: between two kernels it may read a
+    sleep state; the in-kernel clock is `clock.k3_ghz`)."""
+    import glob
+    for path in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+        try:
+            cur = [ln.strip() for ln in open(path) if "*" in ln]
+            if cur:
+                return cur[0]
+        except OSError:
+            pass
+    return None
+
+
 def synthetic_problem(p, n, seed=20240):
     """SURVEY.md 8(d) [decision]: A ~ N(0,1)/sqrt(p), Gamma = 0.01 I, mu = 0, Sigma = 100 I."""
     rng = np.random.default_rng(seed)
@@ -372,46 +386,60 @@ def main():
             t_hist[0] = res.t_new
         return res
 
-    # untimed pre-warm before the W warmup steps: the first ~30 steps after start-up run 3-5 % slower
-    # (clock / power state, code objects, allocator); 192 steps = 80 ms reach the steady state with margin
-    prewarm_min = int(os.environ.get("CESX_BENCH_PREWARM", "192"))
-    prewarm, last = 0, None
-    while prewarm < 1536:
-        # in batches of 32 steps until the batch time has settled (after a start-up or an idle GPU the clocks take
-        # tens of milliseconds, sometimes more, to come up), at least prewarm_min steps
-        tb = time.perf_counter()
-        run_steps(0, 32)
-        torch.cuda.synchronize()
-        tb = time.perf_counter() - tb
-        prewarm += 32
-        settled = last is not None and abs(tb - last) <= 0.015 * last
-        last = tb
-        if world > 1 or rehearse:               # every rank must run the same number of steps (collectives inside)
-            flag = torch.tensor([1.0 if settled else 0.0], device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            settled = bool(flag.item() > 0.5)
-        if prewarm >= prewarm_min and (settled or prewarm_min == 0):
-            break
-    t_hist[0] = 0.0
-    eng.profile_enable(True)                    # creates the event pool outside the timed region
-    eng.profile_enable(False)
-    prof["on"] = not os.environ.get("CESX_BENCH_NOPROF")
-    if args.warmup:
-        # the last warm-up step is sampled as well (and thrown away): whatever the runtime sets up on the first
-        # time-stamped launch of a queue happens here, not inside the timed region
-        prof["at"] = args.warmup - 1
-        run_steps(0, args.warmup)
-    eng.profile_read(0), eng.profile_read(1)
-    eng.profile_enable(False)
-    prof["steps"] = 0
-    prof["at"] = args.warmup + args.steps // 2
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    del stamps[:]
+    # Untimed pre-warm, time-based.  What it has to remove (measured, tools/ramp_probe.py, profiles/r03_ramp.txt):
+    # the step itself is at its steady-state rate from the first 0.25 s of a run -- there is no seconds-long clock
+    # ramp -- but whenever the GPU has been IDLE for more than a few milliseconds (it drops into a sleep state:
+    # sysfs sclk 95 MHz) the next ~20-30 steps run 10-15 % slower, about 2 ms in all.  A 20-step timed region is
+    # 8 ms long, so one such wake-up inside it costs 20 % (0.49 against 0.41 ms/step: the round-1/2 driver numbers,
+    # whose timed region started behind a synchronize + gc.collect() + event reads).  So: step continuously for
+    # at least CESX_BENCH_PREWARM_S seconds (default 2) in windows of 512 steps until the window time has stopped
+    # falling (cap 10 s; every rank takes the same decision), do everything that idles the GPU (garbage collection,
+    # event-pool creation, the first time-stamped launches) BEFORE the last pre-warm window, and let nothing but
+    # the contract's barrier + synchronize sit between the W warm-up steps and the timed region.
     import gc
     gc.collect()
     gc.disable()                                # no collector pause inside the timed region (a few hundred us each)
+    eng.profile_enable(True)                    # creates the event pool outside the timed region
+    eng.profile_enable(False)
+    prof["on"] = not os.environ.get("CESX_BENCH_NOPROF")
+    prewarm_min_s = float(os.environ.get("CESX_BENCH_PREWARM_S", "2.0"))
+    prewarm, win_ms, t_pre = 0, [], time.perf_counter()
+    WIN = 512
+    while True:
+        # the first window carries one HIP-event-sampled step (thrown away): whatever the runtime sets up on the
+        # first time-stamped launch of a queue happens here
+        prof["at"] = 8 if (prewarm == 0 and prof["on"]) else -1
+        tb = time.perf_counter()
+        run_steps(0, WIN)
+        torch.cuda.synchronize()
+        win_ms.append((time.perf_counter() - tb) * 1e3 / WIN)
+        if prewarm == 0 and prof["on"]:
+            eng.profile_read(0), eng.profile_read(1)
+        prewarm += WIN
+        spent = time.perf_counter() - t_pre
+        # settled: the mean of the last two windows is within 0.5 % of (or above) the two before
+        settled = len(win_ms) >= 4 and sum(win_ms[-2:]) >= 0.995 * sum(win_ms[-4:-2])
+        done = (spent >= prewarm_min_s and settled) or spent >= 10.0 or prewarm_min_s <= 0
+        if world > 1 or rehearse:               # every rank must run the same number of steps (collectives inside)
+            flag = torch.tensor([1.0 if done else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            done = bool(flag.item() > 0.5)
+        if done:
+            break
+    prewarm_s = time.perf_counter() - t_pre
+    sclk_before = sysfs_sclk()
+    t_hist[0] = 0.0
+    prof["at"] = -1
+    run_steps(0, 64)                            # (the reads above idled the GPU for a moment: back to work first)
+    if args.warmup:
+        run_steps(0, args.warmup)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    # exactly ONE step of the timed region -- the middle one -- is HIP-event sampled (`roofline.profiled_steps`)
+    prof["steps"] = 0
+    prof["at"] = args.warmup + args.steps // 2
+    del stamps[:]
     t0 = time.perf_counter()
     res = run_steps(args.warmup, args.steps)
     torch.cuda.synchronize()
@@ -422,6 +450,11 @@ def main():
     per_step = np.diff(np.array([t0] + stamps)) * 1e3       # ms between consecutive results (pipelined loop)
     prof["on"] = False
     eng.profile_enable(False)
+    # the clock the sampled K3 launch ran at (in-kernel s_memtime / s_memrealtime), a bare-MFMA calibration of this
+    # device right behind the timed region, and the sysfs sclk samples around it
+    k3_clock = eng.profile_clock() if prof["steps"] else None
+    calib_tf, calib_ghz = eng.calibrate_mfma(5.0)
+    sclk_after = sysfs_sclk()
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -469,8 +502,24 @@ def main():
     step_s = elapsed / args.steps
     esz = np.dtype(args.dtype).itemsize
     alg_bytes = float(esz * (3 * p + 2 * n)) * J               # s (3p + 2n) per particle-update
+    traffic_source = None
+    if traffic_tab:
+        traffic_source = ("profiles/traffic.json[%s] <- profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an "
+                          "EARLIER run of this configuration (2 x FETCH + WRITE, the guide's gfx950 correction), not "
+                          "counters of this run" % (cfg_name, traffic_tab.get("_source", "?")))
+    counter_bytes = (float(sum(v for k, v in traffic_tab.items() if not k.startswith("_") and isinstance(v, (int, float))
+                               # (aliases, the set-up's forward map and the first step's recentring pass are not per step)
+                               and k not in ("gram_kernel", "update_kernel", "colsum_final_kernel", "rowsum_kernel",
+                                             "set_shift_kernel")))
+                     if traffic_tab else None)
     roofline = dict(bound="mfma", kernel=dom, achieved=round(kern[dom]["tflops"], 2), peak=peak,
                     unit="TFLOP/s", frac=round(kern[dom]["tflops"] / peak, 4), traffic=traffic,
+                    traffic_source=traffic_source,
+                    calibration=dict(tflops=round(calib_tf, 2), clock_ghz=round(calib_ghz, 4),
+                                     frac_of_calibration=round(kern[dom]["tflops"] / calib_tf, 4) if calib_tf > 0 else None,
+                                     what="bare %s loop (operands in registers, 4 accumulators per wave, 2 x 256 threads "
+                                          "per CU, random operands), ~5 ms, launched right behind the timed region"
+                                          % ("v_mfma_f32_32x32x2_f32" if dname == "float32" else "v_mfma_f64_16x16x4_f64")),
                     avg_launch_ms=round(kern[dom]["ms"], 4), profiled_steps=prof["steps"],
                     kernels={k: dict(avg_launch_ms=round(v["ms"], 4), launches_per_step=v["launches"],
                                      tflops=round(v["tflops"], 2), frac=round(v["tflops"] / peak, 4),
@@ -485,6 +534,9 @@ def main():
                               if traffic and kern[dom]["ms"] > 0 else None),
                     hbm_peak_gbs=HBM_PEAK_GBS,
                     step_algorithmic_bytes=alg_bytes,
+                    # every kernel of a step by the same counters (incl. the xi block's write + read and the Gram's
+                    # slab round trip): what the step really moves, from the same earlier PMC run as `traffic`
+                    step_counter_bytes=counter_bytes,
                     step_algorithmic_hbm_frac=round(alg_bytes / step_s / 1e9 / HBM_PEAK_GBS, 4))
     if world == 1 and not rehearse:
         par = "dp1: one GPU holds the whole ensemble, no collective is issued"
@@ -496,7 +548,14 @@ def main():
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * step_s,
                ms_per_step_median=float(np.median(per_step)), ms_per_step_min=float(np.min(per_step)),
                ms_per_step_max=float(np.max(per_step)),
-               prewarm_steps=prewarm, rccl_nranks=rccl_nranks,
+               prewarm_steps=prewarm, prewarm_s=round(prewarm_s, 3), prewarm_window_ms=[round(w, 4) for w in win_ms],
+               rccl_nranks=rccl_nranks,
+               clock=dict(k3_ghz=round(k3_clock, 4) if k3_clock else None,
+                          k3_how="s_memtime / s_memrealtime of one wave of the HIP-event-sampled update launch inside "
+                                 "the timed region",
+                          calibration_ghz=round(calib_ghz, 4), sclk_before=sclk_before, sclk_after=sclk_after,
+                          sclk_how="sysfs pp_dpm_sclk level marked current, sampled before the warm-up steps and "
+                                   "after the calibration loop (an instantaneous reading)"),
                higher_is_better=True, scaling="weak", vs_baseline=None,
                dtype={"float32": "f32", "float64": "f64"}[dname], data="synthetic",
                config=dict(workload="%s per GPU: synthetic linear-Gaussian forward map, J=%d particles/GPU "
@@ -507,7 +566,7 @@ def main():
                                         "with on-device noise and the host's read of hk / t / metrics of every step. "
                                         "A ring of 4 resident (U, G = A U) batches is cycled; the forward map and the "
                                         "feedback of U_next are NOT in the timed step (see e2e.device_chain for the "
-                                        "chained loop); %d untimed pre-warm steps precede the warm-up" % prewarm),
+                                        "chained loop); %d untimed pre-warm steps (%.1f s) precede the warm-up" % (prewarm, prewarm_s)),
                roofline=roofline)
     if world == 1 and not rehearse and not args.no_extras:
         del batches, out, sh, eng

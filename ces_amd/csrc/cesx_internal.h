@@ -335,6 +335,7 @@ struct Engine {
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[2];
     std::vector<hipEvent_t> prof_pool;
+    long long* d_clk = nullptr;    // [4] {s_memtime, s_memrealtime} ticks of the last PROFILED update launch (workgroup 0, wave 0)
     // results
     cesx_step_result* h_res = nullptr;   // pinned
     Scalars* h_scal = nullptr;           // pinned, device-mapped: the GPU writes results straight into it
@@ -362,7 +363,8 @@ struct Engine {
     // U x U reduce launch (cesx_moments_uu_chol); every other entry point flushes it as a kernel of its own first
     bool met_deferred = false, met_defer_ok = true;      // CESX_DEFER_PUBLISH=0 switches the deferral off
     hipStream_t met_stream = nullptr;
-    const double* met_mom = nullptr;
+    double* d_lag = nullptr;       // [3] {N, lagged sum q_r^2, lagged sum q_e^2} of the moment buffer of the last cesx_apply (K2 copies
+                                   // them here: the deferred finalisation reads engine-owned memory, not the caller's buffer)
     cesx_step_params last_prm{};
 };
 
@@ -428,7 +430,7 @@ __host__ __device__ inline size_t wd_index(int i, int k, int nkt) {
 }
 int launch_data_metrics(Engine& e, const void* G, hipStream_t s);   // dense Gamma: separate pass
 int launch_metric_final(Engine& e, const double* mom, bool publish, hipStream_t s);
-MetricFin metric_fin_args(Engine& e, const double* mom, bool publish);     // (publish: takes the next sequence number)
+MetricFin metric_fin_args(Engine& e, const double* mom, bool publish);     // (publish: takes the next sequence number; mom == nullptr: the engine's own copy d_lag)
 int launch_publish(Engine& e, hipStream_t s);
 int launch_absmax_final(Engine& e, int nparts, double* absmax_out, hipStream_t s);
 int potrf_ld(int n);
@@ -438,6 +440,7 @@ int gram_kt(int dtype);
 int gram_max_stage_rows();
 int launch_noise(Engine& e, uint64_t step_index, void* xi, hipStream_t s);
 int launch_stage_forward(Engine& e, const void* A, const void* b, hipStream_t s);   // A, b -> d_Wfwd, d_Wfwd_f, d_bfwd
+int launch_calibrate(Engine& e, double target_ms, double* tflops, double* clock_ghz, hipStream_t s);   // kernels_calib.hip
 
 // Event pair for one profiled launch (cesx_profile_*).  bound = false: the pair is RECORDED around the launch (two
 // marker packets: they delay the stream by ~6 us each and the interval includes that).  bound = true: the caller

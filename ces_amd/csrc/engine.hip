@@ -158,7 +158,7 @@ int finish_metrics(Engine& e, const double* mom, const void* G, bool publish, hi
 int flush_metrics(Engine& e) {
     if (!e.met_deferred) return CESX_OK;
     e.met_deferred = false;
-    return launch_metric_final(e, e.met_mom, true, e.met_stream);
+    return launch_metric_final(e, nullptr, true, e.met_stream);
 }
 #define FLUSH(e) TRY(flush_metrics(e))
 
@@ -313,6 +313,8 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
     DM(e.d_mv, (size_t)6 * mx * 8); DM(e.d_part, 256 * 4 * 8);
     DM(e.d_scal, sizeof(Scalars)); DM(e.d_absmax, 8); DM(e.d_c0, 8);
     DM(e.d_absmax_part, (size_t)update_grid_blocks(e, p) * 8);
+    DM(e.d_clk, 4 * 8);
+    DM(e.d_lag, 3 * 8);
 #undef DM
     if (hipHostMalloc(reinterpret_cast<void**>(&e.h_scal), sizeof(Scalars), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void**>(&e.h_scal_dev), e.h_scal, 0) != hipSuccess ||
@@ -355,7 +357,7 @@ void cesx_destroy(cesx_handle h) {
                     e.gp[1].d_type_hdr, e.gp[1].d_rows, e.gp[1].d_wblk, e.gp[1].d_blk_rc, e.gp[1].d_row_own, e.gp[1].d_slabs, e.gp[1].d_rowsum_part, e.d_sums, e.d_ubar, e.d_gbar, e.d_m, e.d_dg,
                     e.d_wdel, e.d_C, e.d_L, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_Kp, e.d_M, e.d_P, e.d_PK,
                     e.d_t1, e.d_t2, e.d_t3, e.d_t4, e.d_Lp, e.d_lanczos, e.d_mv, e.d_part, e.d_scal, e.d_absmax,
-                    e.d_c0, e.d_absmax_part};
+                    e.d_c0, e.d_absmax_part, e.d_clk, e.d_lag};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     for (int w = 0; w < 2; ++w)
@@ -463,7 +465,7 @@ static int moments_uu_handover(Engine& e, const void* U, const void* G, double* 
     if (e.met_deferred && e.met_stream != s) FLUSH(e);
     TRY(launch_gram(e, 0, U, G, mom, s, true));
     if (e.met_deferred) {
-        MetricFin f = metric_fin_args(e, e.met_mom, true);
+        MetricFin f = metric_fin_args(e, nullptr, true);
         f.N = (double)e.Jg;
         e.met_deferred = false;
         TRY(launch_gram_reduce(e, 0, mom, s, e.ev_a, &f));
@@ -588,7 +590,7 @@ int cesx_apply(cesx_handle h, const cesx_step_params* prm, const double* mom, co
     if (e.met_defer_ok && e.ext_events && e.overlap_chol && e.diag_gamma) {
         // the finalisation rides on the next step's U x U reduce launch (cesx_moments_uu_chol / _handover on this
         // stream) -- no one-workgroup kernel (7 us) between this update and the next Gram launch; anything else flushes it
-        e.met_deferred = true; e.met_stream = s; e.met_mom = mom;
+        e.met_deferred = true; e.met_stream = s;      // (reads the engine's own d_lag, not `mom`)
     } else {
         TRY(finish_metrics(e, mom, G, true, s));     // also publishes the step result to the host
     }
@@ -763,6 +765,27 @@ int cesx_profile_read(cesx_handle h, int which, double* total_ms, int* launches)
     *total_ms = tot;
     *launches = cnt;
     return CESX_OK;
+}
+
+int cesx_profile_clock(cesx_handle h, double* clock_ghz) {
+    if (!h) return CESX_EINVAL;
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    if (!clock_ghz) { e.err = "cesx_profile_clock: null pointer"; return CESX_EINVAL; }
+    SET_DEVICE(e);
+    CESX_HIP(hipDeviceSynchronize());
+    long long t[4] = {0, 0, 0, 0};         // {s_memtime, s_memrealtime} at the start, then at the end, of one wave
+    CESX_HIP(hipMemcpy(t, e.d_clk, 32, hipMemcpyDeviceToHost));
+    *clock_ghz = t[3] > t[1] ? (double)(t[2] - t[0]) / (double)(t[3] - t[1]) * 0.1 : 0.0;      // s_memrealtime ticks at 100 MHz
+    return CESX_OK;
+}
+
+int cesx_calibrate_mfma(cesx_handle h, double target_ms, double* tflops, double* clock_ghz, void* stream) {
+    if (!h) return CESX_EINVAL;
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    if (!(target_ms > 0.0) || target_ms > 1000.0 || !tflops) { e.err = "cesx_calibrate_mfma: bad argument"; return CESX_EINVAL; }
+    SET_DEVICE(e);
+    FLUSH(e);
+    return launch_calibrate(e, target_ms, tflops, clock_ghz, (hipStream_t)stream);
 }
 
 // Host-only: builds the Gram work partition a handle of this shape would use (no device needed) and checks its

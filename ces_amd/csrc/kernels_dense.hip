@@ -49,7 +49,8 @@ void center_kernel(MomView mv, const double* __restrict__ shift, const double* _
                    double* __restrict__ ubar, double* __restrict__ gbar, double* __restrict__ mvec,
                    double* __restrict__ dg, double* __restrict__ C, double* __restrict__ Cug,
                    double* __restrict__ See, double* __restrict__ Srr, double* __restrict__ K,
-                   double* __restrict__ M, double* __restrict__ part, Scalars* __restrict__ sc) {
+                   double* __restrict__ M, double* __restrict__ part, Scalars* __restrict__ sc,
+                   double* __restrict__ lag) {
     __shared__ double red[1024 / 64];      // (launched with 256 or, for the U-only part beside a Gram launch, 1024 threads)
     // what & 1: the part that depends on U alone (C, M = C Sigma^{-1}, ubar, tr S_uu, |ubar - u*|^2):
     //           everything chol(C) needs, available before the rest of the Gram is finished
@@ -62,6 +63,11 @@ void center_kernel(MomView mv, const double* __restrict__ shift, const double* _
     }
     const int p = mv.p, n = mv.n;
     const double N = mv.N();
+    // what a deferred metric finalisation (Engine::met_deferred) needs of this buffer, copied into engine-owned
+    // memory: the caller's moment buffer need not outlive cesx_apply
+    if ((what & 2) && lag != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+        lag[0] = N; lag[1] = mv.mom[mv.ml().tail()]; lag[2] = mv.mom[mv.ml().tail() + 1];
+    }
     const double div = unbiased ? N - 1.0 : N;
     const double* sa = mv.sa();
     const double* sb = mv.sb();
@@ -1203,7 +1209,7 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
     hipLaunchKernelGGL(center_kernel, dim3(NPB), dim3(DT), 0, s, mv, e.d_shift64, e.d_y, e.d_ustar,
                        e.diag_gamma ? e.d_gw : (const double*)nullptr,
                        e.diag_sigma ? e.d_sw : (const double*)nullptr, unbiased, early ? 2 : 3, e.d_ubar, e.d_gbar,
-                       e.d_m, e.d_dg, e.d_C, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_M, e.d_part, e.d_scal);
+                       e.d_m, e.d_dg, e.d_C, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_M, e.d_part, e.d_scal, e.d_lag);
     CESX_HIP(hipGetLastError());
     if (!early)
         if ((rc = potrf(e, s, p, e.d_C, e.d_L))) return rc;
@@ -1310,7 +1316,7 @@ int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s, b
     hipLaunchKernelGGL(center_kernel, dim3(std::min(NPB, e.center_u_wgs)), dim3(e.center_u_wgs < NPB ? 1024 : DT), 0, e.side, mv, e.d_shift64, e.d_y, e.d_ustar,
                        e.diag_gamma ? e.d_gw : (const double*)nullptr,
                        e.diag_sigma ? e.d_sw : (const double*)nullptr, unbiased, 1, e.d_ubar, e.d_gbar,
-                       e.d_m, e.d_dg, e.d_C, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_M, e.d_part, e.d_scal);
+                       e.d_m, e.d_dg, e.d_C, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_M, e.d_part, e.d_scal, (double*)nullptr);
     CESX_HIP(hipGetLastError());
     int rc;
     if ((rc = potrf(e, e.side, p, e.d_C, e.d_L, e.ev_b))) return rc;      // ev_b: C, M, ubar, L -- what K2's scalar and assemble kernels read

@@ -208,7 +208,8 @@ int launch_publish(Engine& e, hipStream_t s) {
 // publish = true: this is the last kernel of the step and also writes the results to the host
 MetricFin metric_fin_args(Engine& e, const double* mom, bool publish) {
     const int nparts = e.diag_gamma ? e.last_metric_parts : (int)((e.J + 63) / 64);
-    return MetricFin{e.d_metric_part, nparts, mom, e.ml.tail(), e.d_metric_sums, e.d_scal,
+    // mom == nullptr: {N, lag0, lag1} as K2's centring kernel copied them into the engine's d_lag
+    return MetricFin{e.d_metric_part, nparts, mom ? mom : e.d_lag, mom ? e.ml.tail() : (size_t)1, e.d_metric_sums, e.d_scal,
                      publish ? e.h_scal_dev : (Scalars*)nullptr, publish ? ++e.seq : 0ull, 0.0};
 }
 

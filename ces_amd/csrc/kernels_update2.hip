@@ -49,6 +49,7 @@ struct Upd2Args {
     int tri_seg;
     int stagger_from;     // workgroups with a linear index >= this start late (see the kernel)
     int stagger_n;        // ... by this many s_sleep(100) = 6.4k cycles each
+    long long* clk;       // profiled launches only: wave 0 of workgroup (0, 0) writes its {s_memtime, s_memrealtime} ticks
 };
 
 // wait until at most `n` of this wave's DMAs are outstanding, retire its LDS traffic, barrier
@@ -126,6 +127,12 @@ void update2_kernel(const Upd2Args a) {
 #endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the clock this launch ran at: shader-clock and 100 MHz reference time stamps of one wave at its start and end
+    // (cesx_profile_clock; the start stamps go straight to memory: nothing stays live in SGPRs across the K loop)
+    if (a.clk != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0) {
+        const long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) { a.clk[0] = c0; a.clk[1] = r0; }
+    }
     const int li = lane & 31, lh = lane >> 5;
     const long long jt0 = (long long)blockIdx.x * U2_BN;
     const int rc0 = blockIdx.y * U2_RC;
@@ -456,6 +463,10 @@ void update2_kernel(const Upd2Args a) {
             a.absmax_part[blockIdx.y * gridDim.x + blockIdx.x] = m;
         }
     }
+    if (a.clk != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0) {
+        const long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) { a.clk[2] = c1; a.clk[3] = r1; }
+    }
 #ifdef U2_CLOCKS
     if (tid == 0 && a.metric_part) {      // dev instrumentation: core-clock and 100 MHz wall-clock ticks of this workgroup
         a.metric_part[blockIdx.x * 2 + 0] = (double)(clock64() - clk0);
@@ -527,6 +538,7 @@ int launch_update2(Engine& e, int out_rows, const void* Wf, int ktot, const void
     e.last_update_grid = (int)(grid.x * grid.y);
     {
         ProfScope prof(e, opt.prof, s, true);
+        a.clk = prof.a ? e.d_clk : nullptr;
         if (prof.a) hipExtLaunchKernelGGL(kern, grid, dim3(U2_THREADS), (unsigned)lds, s, prof.a, prof.b, 0, a);
         else hipLaunchKernelGGL(kern, grid, dim3(U2_THREADS), lds, s, a);
     }

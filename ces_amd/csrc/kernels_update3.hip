@@ -41,6 +41,7 @@ struct Upd3Args {
     double* absmax_part;
     const double* rowc; double* metric_part; int metric_seg;
     int tri_seg;
+    long long* clk;       // profiled launches only: wave 0 of workgroup (0, 0) writes its {s_memtime, s_memrealtime} ticks
 };
 
 __global__ __launch_bounds__(U3_THREADS, 2)
@@ -55,6 +56,11 @@ void update3_kernel(const Upd3Args a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // (cesx_profile_clock; the start stamps go straight to memory: nothing stays live in SGPRs across the K loop)
+    if (a.clk != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0) {
+        const long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) { a.clk[0] = c0; a.clk[1] = r0; }
+    }
     const int li = lane & 15, lr = lane >> 4;
     const long long jt0 = (long long)blockIdx.x * U3_BN;
     const int rc0 = blockIdx.y * U3_RC;
@@ -246,6 +252,10 @@ void update3_kernel(const Upd3Args a) {
         __syncthreads();
         if (tid == 0) a.absmax_part[blockIdx.y * gridDim.x + blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
     }
+    if (a.clk != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0) {
+        const long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) { a.clk[2] = c1; a.clk[3] = r1; }
+    }
 }
 
 // returns CESX_OK, an error, or -1 when the launch does not qualify (caller falls back to update_kernel)
@@ -292,6 +302,7 @@ int launch_update3(Engine& e, int out_rows, const void* Wd, int ktot, const void
     e.last_update_grid = (int)(grid.x * grid.y);
     {
         ProfScope prof(e, opt.prof, s, true);
+        a.clk = prof.a ? e.d_clk : nullptr;
         if (prof.a) hipExtLaunchKernelGGL(update3_kernel, grid, dim3(U3_THREADS), (unsigned)lds, s, prof.a, prof.b, 0, a);
         else hipLaunchKernelGGL(update3_kernel, grid, dim3(U3_THREADS), lds, s, a);
     }

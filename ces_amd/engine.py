@@ -25,7 +25,8 @@ EXPORTS = ("cesx_abi_version", "cesx_create", "cesx_destroy", "cesx_last_error",
            "cesx_moments", "cesx_apply", "cesx_apply_drift", "cesx_apply_finish", "cesx_draw_noise",
            "cesx_forward_lineal", "cesx_debug_dense", "cesx_profile_enable", "cesx_profile_read",
            "cesx_moments_uu_len", "cesx_moments_uu", "cesx_chol_async", "cesx_moments_rest", "cesx_side_stream",
-           "cesx_prefetch_noise", "cesx_forward_set_lineal", "cesx_forward_apply", "cesx_moments_uu_chol", "cesx_moments_uu_handover", "cesx_debug_gram_plan")
+           "cesx_prefetch_noise", "cesx_forward_set_lineal", "cesx_forward_apply", "cesx_moments_uu_chol", "cesx_moments_uu_handover", "cesx_debug_gram_plan",
+           "cesx_profile_clock", "cesx_calibrate_mfma")
 
 
 class Config(C.Structure):
@@ -103,6 +104,8 @@ def load_library(path=None):
     lib.cesx_debug_gram_plan.argtypes = [i32, i32, i32, i32, i32, C.c_longlong, C.POINTER(C.c_int)]
     lib.cesx_profile_enable.argtypes = [vp, i32]
     lib.cesx_profile_read.argtypes = [vp, i32, dp, C.POINTER(C.c_int)]
+    lib.cesx_profile_clock.argtypes = [vp, dp]
+    lib.cesx_calibrate_mfma.argtypes = [vp, C.c_double, dp, dp, vp]
     if lib.cesx_abi_version() != ABI_VERSION:
         raise ImportError("libcesx.so ABI %d != binding ABI %d" % (lib.cesx_abi_version(), ABI_VERSION))
     if path == LIB_PATH:
@@ -164,6 +167,9 @@ class Engine:
         self._problem = None
 
     def __del__(self):
+        pool = self.__dict__.pop("_out_pool", None)
+        if pool is not None:
+            pool.close()
         h, self._h = getattr(self, "_h", None), None
         if h:
             self.lib.cesx_destroy(h)
@@ -255,19 +261,33 @@ class Engine:
         (ces/calibrate.py:443/:484/:525 build ``Uk`` from temporaries) and the trace keeps it alive, so
         the drop-in must hand out fresh memory too -- and at J = 65 536, p = 256 the first touch of 134 MB
         of new pages costs 12-20 ms, more than everything else in the call together.  The pool keeps a
-        few arrays of the current shape allocated and touched by a background thread; ``get`` is then a
-        queue pop."""
+        few arrays per shape allocated and touched by a background thread; ``get`` is then a list pop.
+        One ready list per shape (a trace of U (p, J) and G (n, J) alternates two shapes); the two most recently
+        asked-for shapes are kept, older ones are dropped on the helper thread.  All counters are guarded by one
+        condition variable; ``get`` never waits longer than ``wait_s`` for the helper (it allocates itself then)."""
+
+        keep_shapes = 2
+        wait_s = 2.0
 
         def __init__(self, depth=2):
             import queue
             import threading
-            self.depth, self.shape = depth, None
+            self.depth = depth
+            self.shape = None                     # the shape asked for last
             self.recycled = 0
-            self.pending = 0                      # fresh arrays asked for and not yet delivered
-            self.q = queue.Queue()
+            self.cv = threading.Condition()
+            self.ready = {}                       # shape -> arrays with their pages mapped (insertion order = LRU)
+            self.pending = {}                     # shape -> fresh arrays asked for and not yet delivered
             self.req = queue.Queue()
-            self.th = threading.Thread(target=self._work, daemon=True)
+            self.th = threading.Thread(target=self._work, daemon=True, name="cesx-hostpool")
             self.th.start()
+
+        def close(self):
+            """Stop the helper thread and release the prepared arrays (Engine.__del__)."""
+            self.req.put(None)
+            with self.cv:
+                self.ready.clear()
+                self.pending.clear()
 
         _touch_pool = None
 
@@ -292,26 +312,37 @@ class Engine:
 
         def _work(self):
             while True:
-                shape = self.req.get()
-                if shape is None:
+                item = self.req.get()
+                if item is None:
                     return
-                if isinstance(shape, list):          # arrays handed over by discard()
-                    self._take_back(shape)
+                if isinstance(item, list):           # arrays handed over by discard()
+                    self._take_back(item)
                     continue
-                self.q.put((shape, self._fresh(shape)))
-                self.pending -= 1
+                with self.cv:
+                    wanted = item in self.ready       # (the shape may have been evicted since it was asked for)
+                a = self._fresh(item) if wanted else None
+                with self.cv:
+                    self.pending[item] = max(0, self.pending.get(item, 0) - 1)
+                    if a is not None and item in self.ready:
+                        self.ready[item].append(a)
+                    self.cv.notify_all()
+                del a
 
         def _take_back(self, arrays):
-            """Arrays the caller is done with.  One that nobody else refers to, of the shape being handed out, goes
-            back into the ready queue -- its pages are mapped, the next ``get`` costs neither a page fault nor, here,
-            an ``munmap`` (together 16-20 ms per 134 MB array and iteration); anything else is dropped (unmapped) on
-            this thread.  The caller drops its own references right after ``discard`` returns: wait for that."""
+            """Arrays the caller is done with.  One that nobody else refers to, of a shape being handed out, goes
+            back into that shape's ready list -- its pages are mapped, the next ``get`` costs neither a page fault
+            nor, here, an ``munmap`` (together 16-20 ms per 134 MB array and iteration); anything else is dropped
+            (unmapped) on this thread.  The caller drops its own references right after ``discard`` returns: wait
+            for that."""
             import sys
             import time
             while arrays:
                 a = arrays.pop()
-                ok = (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.owndata and a.flags.c_contiguous
-                      and tuple(a.shape) == self.shape and self.q.qsize() <= self.depth)
+                ok = isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.owndata and a.flags.c_contiguous
+                if ok:
+                    with self.cv:
+                        lst = self.ready.get(tuple(a.shape))
+                        ok = lst is not None and len(lst) <= self.depth
                 if ok:
                     for _ in range(20):                      # holders: `a` and getrefcount's argument
                         if sys.getrefcount(a) <= 2:
@@ -319,8 +350,12 @@ class Engine:
                         time.sleep(0.0005)
                     ok = sys.getrefcount(a) <= 2
                 if ok:
-                    self.q.put((self.shape, a))
-                    self.recycled += 1
+                    with self.cv:
+                        lst = self.ready.get(tuple(a.shape))
+                        if lst is not None:
+                            lst.append(a)
+                            self.recycled += 1
+                            self.cv.notify_all()
                 del a
 
         def discard(self, arrays):
@@ -329,22 +364,46 @@ class Engine:
             if self.th.is_alive():
                 self.req.put(list(arrays))
 
+        def _top_up(self, shape):
+            """(lock held) ask the helper for fresh arrays until ready + pending reaches the depth."""
+            want = self.depth - len(self.ready[shape]) - self.pending.get(shape, 0)
+            for _ in range(max(0, want)):
+                self.pending[shape] = self.pending.get(shape, 0) + 1
+                self.req.put(shape)
+
         def get(self, shape):
+            import time
             shape = tuple(int(x) for x in shape)
-            if shape != self.shape:                 # new shape: what was prepared for the old one is skipped below
-                self.shape = shape
-                for _ in range(self.depth):
-                    self.pending += 1
-                    self.req.put(shape)
             if not self.th.is_alive():
                 return self._fresh(shape)
-            while True:
-                got_shape, a = self.q.get()
-                if got_shape == shape:
-                    if self.q.qsize() + self.pending < self.depth:     # keep the pool at its depth (recycled arrays count)
-                        self.pending += 1
-                        self.req.put(shape)
-                    return a
+            dropped = []
+            with self.cv:
+                self.shape = shape
+                lst = self.ready.pop(shape, None)
+                self.ready[shape] = lst if lst is not None else []        # (re-inserted: most recently used)
+                while len(self.ready) > self.keep_shapes:                  # evict the least recently used shape
+                    old = next(iter(self.ready))
+                    dropped.extend(self.ready.pop(old))
+                    self.pending.pop(old, None)
+                self._top_up(shape)
+                deadline = time.monotonic() + self.wait_s
+                while not self.ready[shape]:
+                    left = deadline - time.monotonic()
+                    if left <= 0 or not self.th.is_alive():
+                        break
+                    self.cv.wait(min(left, 0.05))
+                a = self.ready[shape].pop() if self.ready[shape] else None
+                self._top_up(shape)
+            if dropped:
+                self.req.put(dropped)                                      # unmapped on the helper thread
+            return a if a is not None else self._fresh(shape)
+
+    def _host_pool(self):
+        """The engine's one result-array pool (created on first use; its helper thread ends with the engine)."""
+        pool = self.__dict__.get("_out_pool")
+        if pool is None:
+            pool = self._out_pool = self._HostOutPool()
+        return pool
 
     def to_host(self, t):
         """Device tensor of the engine dtype -> NEW float64 numpy array (the reference's dtype)."""
@@ -369,8 +428,7 @@ class Engine:
                     evs.append(torch.cuda.Event())
                 evs[k].record(st)
                 parts.append((sl, evs[k]))
-        pool = self.__dict__.setdefault("_out_pool", self._HostOutPool())
-        out = pool.get(tuple(t.shape))
+        out = self._host_pool().get(tuple(t.shape))
         dst = torch.from_numpy(out)
         with self._HostThreads(self.copy_threads):
             for sl, ev in parts:
@@ -380,8 +438,7 @@ class Engine:
 
     def discard_host(self, *arrays):
         """Hand large host arrays the caller no longer needs to the helper thread for release."""
-        pool = self.__dict__.setdefault("_out_pool", self._HostOutPool())
-        pool.discard([a for a in arrays if isinstance(a, np.ndarray) and a.nbytes >= (1 << 22)])
+        self._host_pool().discard([a for a in arrays if isinstance(a, np.ndarray) and a.nbytes >= (1 << 22)])
 
     def empty(self, rows):
         return torch.empty((rows, self.J), dtype=self.torch_dtype, device=self.device)
@@ -557,6 +614,19 @@ class Engine:
         ms, cnt = C.c_double(), C.c_int()
         self._check(self.lib.cesx_profile_read(self._h, int(which), C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
+
+    def profile_clock(self):
+        """Shader clock (GHz) of the last profiled update launch (cesx_profile_clock)."""
+        ghz = C.c_double()
+        self._check(self.lib.cesx_profile_clock(self._h, C.byref(ghz)))
+        return ghz.value
+
+    def calibrate_mfma(self, target_ms=5.0):
+        """(TFLOP/s, GHz) of a bare MFMA loop of the engine dtype on this device (cesx_calibrate_mfma)."""
+        tf, ghz = C.c_double(), C.c_double()
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cesx_calibrate_mfma(self._h, float(target_ms), C.byref(tf), C.byref(ghz), self._stream()))
+        return tf.value, ghz.value
 
     def debug_dense(self):
         p, n = self.p, self.n_obs

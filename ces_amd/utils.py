@@ -32,6 +32,19 @@ class lineal(object):
             out = out + self.noise_sigma * np.random.normal()
         return out
 
+    def _fingerprint(self):
+        out = []
+        for a in (self.A, self.b):
+            a = np.asarray(a)
+            flat = a.reshape(-1)
+            out.append((a.shape, a.dtype.str, flat[::max(1, flat.size // 64)].tobytes(), float(flat.sum()) if flat.size else 0.0))
+        return tuple(out)
+
+    def invalidate_device(self):
+        """Forget the map installed in an engine (build-only): the next ``forward_device`` uploads A and b again."""
+        self._dev_A = self._dev_b = self._dev_fp = None
+        self._dev_token = 0
+
     # build-only hook (SURVEY.md 8f rank 1): evaluate the whole shard on device
     def forward_device(self, engine, U_dev, out=None):
         if self.flag_noise:
@@ -45,13 +58,18 @@ class lineal(object):
             if np.ndim(self.b) > 0 or self.b != 0:
                 b = np.broadcast_to(np.asarray(self.b, dtype=np.float64), (self.n_obs,))
             return engine.forward_lineal(self.A, U_dev, b=b, out=out)
-        key = (id(self.A), id(self.b))
-        if getattr(self, "_dev_key", None) != key or getattr(engine, "_fwd_token", None) is not getattr(self, "_dev_token", 0):
+        # the installed map is reused while A and b are THE SAME OBJECTS (strong references are kept, so an id cannot be
+        # recycled) and a cheap fingerprint of their contents (shape, dtype, 64 strided samples, the sum) is unchanged:
+        # an in-place edit of A or b between two calls re-installs the map.  ``invalidate_device()`` forces it.
+        fp = self._fingerprint()
+        if (getattr(self, "_dev_A", None) is not self.A or getattr(self, "_dev_b", None) is not self.b
+                or getattr(self, "_dev_fp", None) != fp
+                or getattr(engine, "_fwd_token", None) is not getattr(self, "_dev_token", 0)):
             b = None
             if np.ndim(self.b) > 0 or self.b != 0:
                 b = np.broadcast_to(np.asarray(self.b, dtype=np.float64), (self.n_obs,))
             self._dev_token = engine.forward_set_lineal(np.asarray(self.A), b)      # (another model may have installed its map)
-            self._dev_key = key
+            self._dev_A, self._dev_b, self._dev_fp = self.A, self.b, fp
         return engine.forward_apply(U_dev, out=out)
 
 

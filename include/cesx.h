@@ -157,7 +157,12 @@ int cesx_step(cesx_handle h, const cesx_step_params* prm, const void* U_dev, con
    partials, copy of the scalars to the host -- is held back so that it can ride on the next
    step's cesx_moments_uu_chol launch; cesx_result, like every entry point that touches the
    engine's state, enqueues it at once if it is still pending.  A driver may therefore enqueue
-   the first half of step i+1 before it reads the result of step i, or not: same numbers.) */
+   the first half of step i+1 before it reads the result of step i, or not: same numbers.
+   Lifetime rule that follows: the held-back kernel is enqueued on the `stream` that was passed to
+   cesx_apply / cesx_step, so that stream must stay valid until cesx_result (or any other entry
+   point of this handle) has been called; the moment buffer passed to cesx_apply is NOT read again
+   after cesx_apply returns and its kernels have run -- what the held-back kernel needs of it is
+   copied into engine-owned memory by cesx_apply's own kernels.) */
 int cesx_result(cesx_handle h, cesx_step_result* out);
 
 /* ---- split entry points (multi-device, testing) ----------------------- */
@@ -266,6 +271,15 @@ int cesx_forward_apply(cesx_handle h, const void* U_dev, void* G_dev, void* stre
    number of launches since the last read, and resets the counters. */
 int cesx_profile_enable(cesx_handle h, int on);
 int cesx_profile_read(cesx_handle h, int which, double* total_ms, int* launches);
+/* Shader clock (GHz) the last PROFILED update launch (K3) ran at: one wave of it stamps s_memtime and the 100 MHz
+   s_memrealtime at its start and end (profiled launches only; the others execute no stamp).  Synchronises.
+   0.0 when no profiled launch has run. */
+int cesx_profile_clock(cesx_handle h, double* clock_ghz);
+/* What this device sustains on the bare matrix instruction of the engine's dtype (v_mfma_f32_32x32x2_f32 /
+   v_mfma_f64_16x16x4_f64, operands in registers, every SIMD busy) for about target_ms milliseconds: TFLOP/s
+   and the in-kernel shader clock.  A roofline fraction can then be read against the datasheet peak and against
+   this box's own rate.  Measurement support only; synchronises. */
+int cesx_calibrate_mfma(cesx_handle h, double target_ms, double* tflops, double* clock_ghz, void* stream);
 
 /* Host-only introspection for tests: the work partition of the moments launch `part` (0: U x U blocks, 1: the
    others) for a handle of this shape and workgroup budget, checked for its invariants (every wanted block of the

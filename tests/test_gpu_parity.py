@@ -718,3 +718,36 @@ def test_rank_deficient_ensemble_fp32_request_runs_in_fp64(eng_mod):
     st = oc.OracleState(p, n, J, d["mu"], d["sigma"], d["ustar"])
     want = oc.literal_step(st, d["y"], d["U0"], d["G"], d["Gamma"], d["xi"], update="aldi")
     assert rel_err(Uk, want) < 1e-7
+
+
+def test_in_place_modified_ensemble_gets_a_fresh_centring_pass(eng_mod):
+    """The drop-in class skips the centring pass for an ensemble the engine itself produced (K2 predicted its
+    mean).  A caller that edits the returned array IN PLACE -- here: moves every particle by 300 standard
+    deviations -- must not be served with the stale shift: with it the fp32 second moments lose all their
+    digits (cancellation); the 4096-sample check of sampling._device_update sees the edit and recentres."""
+    from ces_amd.calibrate import sampling
+    from oracle import ces_numpy as oc
+    rng = np.random.default_rng(5)
+    p, n, J = 16, 12, 4096
+    A = rng.standard_normal((n, p)) / np.sqrt(p)
+    ustar = rng.standard_normal((p, 1))
+    Gamma, sigma, mu = 0.01 * np.eye(n), 100.0 * np.eye(p), np.zeros((p, 1))
+    y = (A @ ustar).ravel() + 0.1 * rng.standard_normal(n)
+    eks = sampling(p=p, n_obs=n, J=J)
+    eks.mu, eks.sigma, eks.ustar = mu, sigma, ustar
+    eks.engine_dtype = "float32"
+    eks.Uall = [None]                                   # "first step" for the reference's len(self.Uall) == 1 test
+    U0 = rng.standard_normal((p, J))
+    xi0, xi1 = rng.standard_normal((p, J)), rng.standard_normal((p, J))
+    U1 = eks.eks_update_aldi(y, U0, A @ U0, Gamma, 0, xi=xi0)
+    assert isinstance(U1, np.ndarray)
+    U1 += 300.0                                         # in place: the object identity survives, the contents do not
+    eks.Uall.append(None)
+    U2 = eks.eks_update_aldi(y, U1, A @ U1, Gamma, 1, xi=xi1)
+    st = oc.OracleState(p, n, J, mu, sigma, ustar)
+    st.trace_len = 2
+    st.metrics["t"].append(eks.metrics["t"][0])
+    cast = lambda a: a.astype(np.float32).astype(np.float64)
+    ref = oc.factored_step(st, y, cast(U1), cast(A @ U1), Gamma, cast(xi1), update="aldi")
+    assert rel_err(U2, ref) < TOL32
+    assert eks.metrics["bias"][-1] == pytest.approx(st.metrics["bias"][-1], rel=TOL32)

@@ -61,3 +61,49 @@ def test_pool_ignores_foreign_shapes_and_views():
     time.sleep(0.05)
     assert pool.recycled == before
     assert a.shape == shape
+
+
+def test_engine_keeps_one_pool_and_its_thread_ends_with_the_engine():
+    """Engine.to_host / discard_host must not start a helper thread per call (round-2 advisor finding: a
+    ``setdefault(..., _HostOutPool())`` built -- and leaked -- one pool per call)."""
+    import threading
+    eng = Engine.__new__(Engine)                  # no device needed for the host-side pool
+    eng._h = None
+    before = threading.active_count()
+    pools = {id(eng._host_pool()) for _ in range(50)}
+    assert len(pools) == 1
+    big = [np.empty((4, 200000)) for _ in range(3)]
+    for _ in range(20):
+        eng.discard_host(*big)
+    assert threading.active_count() <= before + 1 + 8      # the helper (+ the shared prefault workers, if started)
+    th = eng._host_pool().th
+    eng.__del__()
+    th.join(timeout=5.0)
+    assert not th.is_alive()
+    assert "_out_pool" not in eng.__dict__
+
+
+def test_alternating_shapes_keep_their_own_ready_lists():
+    pool = Engine._HostOutPool(depth=2)
+    sa, sb = (4, 200000), (3, 200000)
+    got = []
+    for _ in range(6):                                      # the trace of U (p, J) and G (n, J) alternates shapes
+        got.append(pool.get(sa))
+        got.append(pool.get(sb))
+    assert [g.shape for g in got] == [sa, sb] * 6
+    assert len({g.ctypes.data for g in got}) == 12          # all distinct while referenced
+    with pool.cv:
+        assert set(pool.ready) == {sa, sb}
+    # a third shape evicts the least recently used one
+    pool.get((2, 200000))
+    with pool.cv:
+        assert set(pool.ready) == {sb, (2, 200000)}
+    pool.close()
+
+
+def test_get_falls_back_when_the_helper_is_gone():
+    pool = Engine._HostOutPool(depth=1)
+    pool.close()
+    pool.th.join(timeout=5.0)
+    a = pool.get((2, 1000))
+    assert a.shape == (2, 1000) and a.dtype == np.float64

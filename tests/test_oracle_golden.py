@@ -108,3 +108,25 @@ def test_c1_posterior_sanity_band(golden_traj):
     posterior mean [-1.0367, 2.0870]); sampling error only allows a band."""
     U = golden_traj["aldi_Uall"][-1]
     assert np.allclose(U.mean(axis=1), [-1.03673079, 2.08697021], atol=0.15)
+
+
+def test_philox_oracle_matches_random123_known_answers():
+    """oracle/philox.py restates Philox4x32-10; these are the three known-answer vectors Random123 ships for it
+    (kat_vectors: counter x 4, key x 2 -> output x 4).  The device generator is compared against this oracle
+    in the -m gpu tests, so the chain device == oracle == published algorithm is closed here."""
+    from oracle import philox
+    kat = [
+        ((0x00000000, 0x00000000, 0x00000000, 0x00000000), (0x00000000, 0x00000000),
+         (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+        ((0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff), (0xffffffff, 0xffffffff),
+         (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+        ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+         (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+    ]
+    for ctr, key, want in kat:
+        got = philox.philox4x32_10(*[np.array([c], dtype=np.uint32) for c in ctr], key[0], key[1])
+        assert tuple(int(g[0]) for g in got) == want, (ctr, key)
+    # vectorised call = element-wise calls
+    ctrs = np.array([k[0] for k in kat], dtype=np.uint32).T
+    got = philox.philox4x32_10(ctrs[0][:1], ctrs[1][:1], ctrs[2][:1], ctrs[3][:1], kat[0][1][0], kat[0][1][1])
+    assert int(got[0][0]) == kat[0][2][0]
