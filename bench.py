@@ -259,6 +259,138 @@ def e2e_block(engine, prob, p, n, J, dtype, update, dev_index):
     return out
 
 
+def engine_leg(engine, name, p, n, J, dtype, steps, dev_index, prewarm_s=0.6, update="aldi"):
+    """A short engine-only leg of another BASELINE.json configuration on one GPU, measured like the headline (ring of 4
+    resident batches, pipelined begin / finish / result, continuous stepping up to the timed region, one
+    HIP-event-sampled step in its middle): ms/step, particle-updates/s and the K1 / K3 roofline fractions."""
+    from ces_amd.dist import ShardedUpdate
+    dev = torch.device("cuda", dev_index)
+    prob = synthetic_problem(p, n)
+    eng = engine.Engine(p, n, J, dtype=dtype, device=dev_index, seed=1234)
+    eng.set_problem(prob["y"], prob["Gamma"], prob["mu"], prob["sigma"], prob["ustar"])
+    sh = ShardedUpdate(eng)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(4242)
+    ustar_d = torch.as_tensor(prob["ustar"], device=dev, dtype=eng.torch_dtype)
+    batches = []
+    for b in range(4):
+        U = ustar_d + (1.0 + 0.05 * b) * torch.randn((p, J), generator=gen, device=dev, dtype=eng.torch_dtype)
+        batches.append((U, eng.forward_lineal(prob["A"], U)))
+    out = eng.empty(p)
+    prm0 = engine.step_params(update=update)
+    t_hist, at = [0.0], [-1]
+    eng.profile_enable(True)
+    eng.profile_enable(False)
+
+    def begin(i):
+        U, G = batches[i % 4]
+        eng.profile_enable(i == at[0])
+        sh.begin(prm0, U, G, recenter=(i == 0), noise_step=i)
+
+    def finish(i):
+        U, G = batches[i % 4]
+        eng.profile_enable(i == at[0])
+        prm = engine.step_params(update=update, first_step=(i == 0), t_len=min(i, 1), t_last=t_hist[0], step_index=i)
+        sh.finish(prm, U, G, xi=None, out=out)
+
+    def run_steps(first, count):
+        begin(first)
+        for i in range(first, first + count):
+            finish(i)
+            if i + 1 < first + count:
+                begin(i + 1)
+            t_hist[0] = eng.result().t_new
+    at[0] = 4                                    # first time-stamped launches: outside the timed region
+    run_steps(0, 16)
+    eng.profile_read(0), eng.profile_read(1)
+    at[0] = -1
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < prewarm_s:
+        run_steps(0, 64)
+    torch.cuda.synchronize()
+    at[0] = 3 + steps // 2
+    t0 = time.perf_counter()
+    run_steps(3, steps)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    eng.profile_enable(False)
+    ghz = eng.profile_clock()
+    g_ms, g_cnt = eng.profile_read(0)
+    u_ms, u_cnt = eng.profile_read(1)
+    peak = MFMA_PEAK_TF[np.dtype(dtype).name]
+    k1f, k3f = float(p + n) ** 2 * J, 2.0 * p * (2 * p + n) * J
+    kern = {"gram_kernel(K1)": dict(avg_launch_ms=round(g_ms, 4), launches_per_step=g_cnt,
+                                    tflops=round(k1f / (g_ms * 1e-3) / 1e12, 2) if g_ms > 0 else None,
+                                    frac=round(k1f / (g_ms * 1e-3) / 1e12 / peak, 4) if g_ms > 0 else None),
+            "update_kernel(K3)": dict(avg_launch_ms=round(u_ms, 4), launches_per_step=u_cnt,
+                                      tflops=round(k3f / (u_ms * 1e-3) / 1e12, 2) if u_ms > 0 else None,
+                                      frac=round(k3f / (u_ms * 1e-3) / 1e12 / peak, 4) if u_ms > 0 else None)}
+    esz = np.dtype(dtype).itemsize
+    rec = dict(workload="%s: J=%d, d=p=%d, n_obs=%d, %s, update=%s, synthetic linear-Gaussian inputs resident in HBM, "
+                        "on-device noise, engine only" % (name, J, p, n, np.dtype(dtype).name, update),
+               value=J * steps / el, unit="particle-updates/s", steps=steps, ms_per_step=1e3 * el / steps,
+               dtype={"float32": "f32", "float64": "f64"}[np.dtype(dtype).name],
+               roofline=dict(bound="mfma", peak=peak, unit="TFLOP/s", kernels=kern,
+                             step_flops_frac=round((k1f + k3f) / (el / steps) / 1e12 / peak, 4),
+                             step_algorithmic_bytes=float(esz * (3 * p + 2 * n)) * J,
+                             step_algorithmic_hbm_frac=round(esz * (3 * p + 2 * n) * J / (el / steps) / 1e9 / HBM_PEAK_GBS, 4)),
+               k3_clock_ghz=round(ghz, 4) if ghz else None)
+    del batches, out, sh, eng
+    torch.cuda.empty_cache()
+    return rec
+
+
+def darcy_leg(engine, dev_index, J=512, T=2):
+    """BASELINE.json configs[3] end to end at a J the host finishes in seconds: the host Darcy forward map
+    (ces_amd/darcy.py, model_trunc(p=64), 50 observations; the reference's MATLAB map restated, parity unpinned)
+    + the GPU update, driven like examples/scripts/darcy-flow.py:43-93 through sampling.run."""
+    from ces_amd import darcy
+    from ces_amd.calibrate import sampling
+    full = darcy.model(); full.set_initial(); full.n_obs = 50
+    Ufull = full(full.ustar, full_solution=True)
+    rng = np.random.RandomState(1)
+    obs_index = rng.choice(int(full.p), 50, replace=False, p=Ufull / Ufull.sum())
+    model = darcy.model_trunc(p=64); model.set_initial(); model.n_obs = 50; model.obs_index = obs_index
+    gamma = 0.005
+    Gamma = gamma ** 2 * np.identity(50)
+    y_obs = model(model.ustar) + gamma * rng.normal(0, 1, 50)
+    eks = sampling(p=model.p, n_obs=model.n_obs, J=J)
+    eks.ustar = model.ustar.reshape(model.p, -1)
+    eks.mu, eks.sigma = np.zeros((model.p, 1)), 100.0 * np.identity(model.p)
+    eks.engine_dtype, eks.noise, eks.device, eks.T = "float32", "device", dev_index, T
+    fwd, upd = [], []
+    g_ens = eks.G_ens
+
+    def timed_g_ens(theta, m):
+        t0 = time.perf_counter()
+        g = g_ens(theta, m)
+        fwd.append(time.perf_counter() - t0)
+        return g
+    eks.G_ens = timed_g_ens
+    upd_fn = eks.eks_update_aldi
+
+    def timed_update(*a, **k):
+        t0 = time.perf_counter()
+        r = upd_fn(*a, **k)
+        upd.append(time.perf_counter() - t0)
+        return r
+    eks.eks_update_aldi = timed_update
+    U0 = 10 * rng.normal(0, 1, [eks.p, J])
+    t0 = time.perf_counter()
+    eks.run(y_obs, U0, model, Gamma, np.linalg.cholesky(Gamma), t_tol=1e30, trace=False)
+    el = time.perf_counter() - t0
+    fwd_s, upd_ms = float(np.mean(fwd)), float(np.median(upd)) * 1e3
+    return dict(J=J, iterations=len(upd), wall_s=round(el, 3), host_forward_s_per_iteration=round(fwd_s, 4),
+                host_forward_ms_per_particle=round(1e3 * fwd_s / J, 4), update_call_ms=round(upd_ms, 4),
+                forward_share=round(sum(fwd) / el, 4),
+                extrapolated_J8192=dict(host_forward_s_per_iteration=round(fwd_s / J * 8192, 2),
+                                        note="one host core, serial G_ens (ces/calibrate.py:123-130); the update of the "
+                                             "J=8192 ensemble is the engine-only ms_per_step above"),
+                includes="sampling.run(trace=False): per iteration one host forward evaluation of every particle "
+                         "(sparse solve of the 5-point Darcy operator), float64 arrays across PCIe into and out of the "
+                         "update (host-array calling convention), the final forward evaluation")
+
+
 def self_launch(args):
     """No launcher (WORLD_SIZE unset) and --gpus N > 1: start the N ranks as children of this process, which
     has not touched the GPU, relay their output, exit with their status."""
@@ -304,16 +436,27 @@ def main():
     rehearse = world == 1 and os.environ.get("CESX_FORCE_COLLECTIVES") == "1"   # one-rank run of the N > 1 code path
     rccl_nranks = 0                               # ranks RCCL saw in an actual all-reduce (0: no communicator)
     if world > 1 or rehearse:
-        if rehearse:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-            os.environ["CESX_FORCE_COMM_OVERLAP"] = "1"
-        else:
-            dist.init_process_group("nccl", device_id=dev)
-        one = torch.ones(1, device=dev)
-        dist.all_reduce(one)
-        rccl_nranks = int(one.item())
+        # RCCL prints a version banner on stdout when its first communicator comes up: this process's stdout carries
+        # the ONE JSON line, so file descriptor 1 points at stderr while the communicator is created
+        sys.stdout.flush()
+        saved_out = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if rehearse:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29533")
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+                os.environ["CESX_FORCE_COMM_OVERLAP"] = "1"
+            else:
+                dist.init_process_group("nccl", device_id=dev)
+            one = torch.ones(1, device=dev)
+            dist.all_reduce(one)
+            rccl_nranks = int(one.item())
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_out, 1)
+            os.close(saved_out)
 
     from ces_amd import build, engine
     from ces_amd.dist import ShardedUpdate
@@ -361,12 +504,14 @@ def main():
         U, G = batches[i % NB]
         if prof["on"]:
             eng.profile_enable(i == prof["at"])
+            sh.sample_collectives = i == prof["at"]      # (sharded runs: event pairs around the step's all-reduces)
         sh.begin(prm0, U, G, recenter=(i == 0), noise_step=i)
 
     def finish(i):
         U, G = batches[i % NB]
         if prof["on"]:
             eng.profile_enable(i == prof["at"])
+            sh.sample_collectives = i == prof["at"]
             prof["steps"] += int(i == prof["at"])
         prm = engine.step_params(update=args.update, first_step=(i == 0), t_len=min(i, 1), t_last=t_hist[0],
                                  step_index=i)
@@ -415,6 +560,7 @@ def main():
         win_ms.append((time.perf_counter() - tb) * 1e3 / WIN)
         if prewarm == 0 and prof["on"]:
             eng.profile_read(0), eng.profile_read(1)
+            sh.read_collective_ms()
         prewarm += WIN
         spent = time.perf_counter() - t_pre
         # settled: the mean of the last two windows is within 0.5 % of (or above) the two before
@@ -452,6 +598,9 @@ def main():
     eng.profile_enable(False)
     # the clock the sampled K3 launch ran at (in-kernel s_memtime / s_memrealtime), a bare-MFMA calibration of this
     # device right behind the timed region, and the sysfs sclk samples around it
+    sh.sample_collectives = False
+    coll_ms = sh.read_collective_ms()
+    gap_ms = eng.profile_gap() if prof["steps"] else None      # end of the second Gram launch -> start of K3, sampled step
     k3_clock = eng.profile_clock() if prof["steps"] else None
     calib_tf, calib_ghz = eng.calibrate_mfma(5.0)
     sclk_after = sysfs_sclk()
@@ -540,6 +689,9 @@ def main():
                     step_algorithmic_hbm_frac=round(alg_bytes / step_s / 1e9 / HBM_PEAK_GBS, 4))
     if world == 1 and not rehearse:
         par = "dp1: one GPU holds the whole ensemble, no collective is issued"
+    elif sh.single_allreduce:
+        par = ("particle-sharded dp%d over RCCL: ONE all-reduce(sum) of the %d-double fp64 moment buffer per step after "
+               "the complete Gram, chol(C) in line (CESX_SINGLE_ALLREDUCE=1)" % (world, eng.moments_len()))
     else:
         par = ("particle-sharded dp%d over RCCL: all-reduce(sum) of the %d-double fp64 moment buffer per step, sent in "
                "two pieces (%d-double head on the side stream beside the second Gram launch, then the rest)"
@@ -567,11 +719,35 @@ def main():
                                         "A ring of 4 resident (U, G = A U) batches is cycled; the forward map and the "
                                         "feedback of U_next are NOT in the timed step (see e2e.device_chain for the "
                                         "chained loop); %d untimed pre-warm steps (%.1f s) precede the warm-up" % (prewarm, prewarm_s)),
-               roofline=roofline)
+               roofline=roofline,
+               # what a SCALE line needs to explain its own efficiency (rank 0, the sampled step of the timed region)
+               sampled_step=dict(gram_end_to_k3_start_ms=round(gap_ms, 4) if gap_ms is not None else None,
+                                 collective_mode=("none" if world == 1 and not rehearse else
+                                                  "single" if sh.single_allreduce else "head+tail"),
+                                 collectives_per_step=(0 if world == 1 and not rehearse else 1 if sh.single_allreduce else 2),
+                                 collective_ms={k: dict(doubles=v[0], ms=round(v[1], 4)) for k, v in coll_ms.items()},
+                                 how="HIP events: kernel-bound stop of the second Gram launch -> kernel-bound start of K3; "
+                                     "a recorded event pair around each all-reduce on the stream that issues it (the pair "
+                                     "itself adds a few us to the sampled step)"))
     if world == 1 and not rehearse and not args.no_extras:
         del batches, out, sh, eng
         torch.cuda.empty_cache()
         rec["parity_err"] = parity_check(engine, prob, p, n, args.dtype, args.update)
+        if is_c2:
+            # the other single-GPU configurations of BASELINE.json, short legs (never `value`):
+            #   C5      configs[4] per GPU: fp64, p = n_obs = 512, J = 32 768 (the reference's own precision)
+            #   C2_f64  the headline shape at the reference's precision
+            #   C4      configs[3]: p = 64, n_obs = 50, J = 8 192 -- the update alone (latency-bound regime) and, at a J the
+            #           host finishes in seconds, end to end with the host Darcy map
+            extra = {}
+            extra["C5"] = engine_leg(engine, "C5 per GPU", 512, 512, 32768, "float64", 10, local, prewarm_s=0.5)
+            extra["C2_f64"] = engine_leg(engine, "C2 shape in fp64", 256, 256, 65536, "float64", 10, local, prewarm_s=0.5)
+            extra["C4"] = engine_leg(engine, "C4 update only", 64, 50, 8192, "float32", 40, local, prewarm_s=0.4)
+            try:
+                extra["C4"]["e2e_darcy"] = darcy_leg(engine, local)
+            except Exception as ex:             # (scipy missing, ...): the engine legs above still stand
+                extra["C4"]["e2e_darcy"] = dict(error=repr(ex))
+            rec["extra"] = extra
         rec["e2e"] = e2e_block(engine, prob, p, n, J, args.dtype, args.update, local)
     if world == 1 and not args.no_cpu_baseline:
         rec["cpu_baseline"] = cpu_baseline(prob, p, n, J, np.dtype(args.dtype).type)

@@ -210,6 +210,7 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
     if (const char* kv = std::getenv("CESX_K2_SPLIT")) e.k2_fused = kv[0] == '0';
     if (const char* xv = std::getenv("CESX_EXT_EVENTS")) e.ext_events = xv[0] != '0';
     if (const char* dv = std::getenv("CESX_DEFER_PUBLISH")) e.met_defer_ok = dv[0] != '0';
+    if (const char* fv = std::getenv("CESX_FUSE_CENTER")) e.fuse_center_ok = fv[0] != '0';
     auto fail = [&](int rc) { g_create_err = e.err; cesx_destroy(reinterpret_cast<cesx_handle>(ep)); return rc; };
     int rc;
     DeviceGuard dg(cfg->device);
@@ -764,6 +765,21 @@ int cesx_profile_read(cesx_handle h, int which, double* total_ms, int* launches)
     e.prof_ev[which].clear();
     *total_ms = tot;
     *launches = cnt;
+    return CESX_OK;
+}
+
+int cesx_profile_gap(cesx_handle h, double* gap_ms) {
+    if (!h) return CESX_EINVAL;
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    if (!gap_ms) { e.err = "cesx_profile_gap: null pointer"; return CESX_EINVAL; }
+    *gap_ms = -1.0;
+    if (e.prof_ev[0].empty() || e.prof_ev[1].empty()) return CESX_OK;
+    SET_DEVICE(e);
+    hipEvent_t gram_end = e.prof_ev[0].back().second, upd_start = e.prof_ev[1].back().first;
+    CESX_HIP(hipEventSynchronize(e.prof_ev[1].back().second));
+    float ms = 0.f;
+    CESX_HIP(hipEventElapsedTime(&ms, gram_end, upd_start));
+    *gap_ms = ms;
     return CESX_OK;
 }
 

@@ -55,8 +55,10 @@ void center_kernel(MomView mv, const double* __restrict__ shift, const double* _
     // what & 1: the part that depends on U alone (C, M = C Sigma^{-1}, ubar, tr S_uu, |ubar - u*|^2):
     //           everything chol(C) needs, available before the rest of the Gram is finished
     // what & 2: the part that involves G
+    // what & 4: the status word stays (chol(C) with the centring fused into its load already ran for these moments
+    //           and may have reported CESX_ENOTPD: potrf_reg_kernel resets the word itself then)
     if ((what & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-        sc->status = CESX_OK;
+        if (!(what & 4)) sc->status = CESX_OK;
         sc->radspec = 0.0;
         sc->spare[0] = 0.0;
         sc->absmax = 0.0;
@@ -264,9 +266,22 @@ template <int SLOTS>
 __global__ __launch_bounds__(PRT, 2)
 void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __restrict__ Lp, int* status,
                       long long* dbg = nullptr,     // dbg: per-phase cycle counts (tools/potrf_bench only)
-                      int lda = 0, int ldl = 0) {   // row strides of A / Lp (0: n / np); a diagonal block of a larger matrix
+                      int lda = 0, int ldl = 0,     // row strides of A / Lp (0: n / np); a diagonal block of a larger matrix
+                      // cen_sa != nullptr: A is the RAW second moment S_aa of the packed buffer and the covariance is
+                      // formed while it is loaded, C_ij = (S_ij - sa_i sa_j / N) / div + 1e-8 [i == j] -- the arithmetic
+                      // of center_kernel, element for element (ces/calibrate.py:424/:476/:512), so the U-only centring
+                      // kernel no longer sits in front of the factorisation on the side stream; the status word is
+                      // reset here then
+                      const double* __restrict__ cen_sa = nullptr, const double* __restrict__ cen_N = nullptr,
+                      int cen_unbiased = 0) {
     if (lda == 0) lda = n;
     if (ldl == 0) ldl = np;
+    double cN = 1.0, cdiv = 1.0;
+    if (cen_sa != nullptr) {
+        cN = *cen_N;
+        cdiv = cen_unbiased ? cN - 1.0 : cN;
+        if (threadIdx.x == 0) *status = CESX_OK;
+    }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // Panel images, k-major: element (k, row relative to the panel's first row) at k * LDT + Z0 + row.  The Z0 = NPMAX
     // entries in front of every k-row stay ZERO: the rows / columns of a tile that lie left of the panel (finished,
@@ -314,7 +329,10 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
             int i = R * 16 + lr + 4 * e, j = Cc * 16 + lc;
             double v = (i == j) ? 1.0 : 0.0;              // identity padding
             if (j > i) { const int t = i; i = j; j = t; } // diagonal tiles are kept fully symmetric
-            if (on && i < n) v = A[(size_t)i * lda + j];
+            if (on && i < n) {
+                v = A[(size_t)i * lda + j];
+                if (cen_sa != nullptr) v = (v - cen_sa[i] * cen_sa[j] / cN) / cdiv + (i == j ? 1e-8 : 0.0);
+            }
             Pt[s][e] = v;
         }
     }
@@ -924,19 +942,22 @@ static int gemm(Engine& e, hipStream_t s, int m, int n, int k, double alpha, con
     return CESX_OK;
 }
 
+struct PotrfCen { const double* sa = nullptr; const double* N = nullptr; int unbiased = 0; };    // centring fused into the load
+
 template <int SLOTS>
 static int potrf_reg_launch(Engine& e, hipStream_t s, int n, int np, const double* A, double* Lp, int lda = 0, int ldl = 0,
-                            hipEvent_t stop = nullptr) {      // stop: event bound to this kernel's own completion signal
+                            hipEvent_t stop = nullptr,        // stop: event bound to this kernel's own completion signal
+                            PotrfCen cen = PotrfCen()) {
     constexpr int NPMAX = SLOTS <= 2 ? 64 : SLOTS <= 5 ? 128 : SLOTS <= 10 ? 192 : 256;
     const size_t lds = (size_t)3 * QNB * (2 * NPMAX + 4) * 8;      // panel x 2, its negative (each k-row behind NPMAX zeros)
     CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_reg_kernel<SLOTS>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (stop)
         hipExtLaunchKernelGGL(potrf_reg_kernel<SLOTS>, dim3(1), dim3(PRT), (unsigned)lds, s, nullptr, stop, 0, n, np, A, Lp,
-                              &e.d_scal->status, (long long*)nullptr, lda, ldl);
+                              &e.d_scal->status, (long long*)nullptr, lda, ldl, cen.sa, cen.N, cen.unbiased);
     else
     hipLaunchKernelGGL(potrf_reg_kernel<SLOTS>, dim3(1), dim3(PRT), lds, s, n, np, A, Lp, &e.d_scal->status, (long long*)nullptr,
-                       lda, ldl);
+                       lda, ldl, cen.sa, cen.N, cen.unbiased);
     CESX_HIP(hipGetLastError());
     return CESX_OK;
 }
@@ -1066,12 +1087,12 @@ __global__ void pad_copy_kernel(int n, int np, const double* __restrict__ A, dou
 int potrf_ld(int n) { return (n + PNB - 1) / PNB * PNB; }
 
 static int potrf_reg_any(Engine& e, hipStream_t s, int n, int np, const double* A, double* Lp, int lda, int ldl,
-                         hipEvent_t stop = nullptr) {
+                         hipEvent_t stop = nullptr, PotrfCen cen = PotrfCen()) {
     const int T = np / 16, ntile = T * (T + 1) / 2, slots = (ntile + 7) / 8;
-    if (slots <= 2) return potrf_reg_launch<2>(e, s, n, np, A, Lp, lda, ldl, stop);       // np <= 64
-    if (slots <= 5) return potrf_reg_launch<5>(e, s, n, np, A, Lp, lda, ldl, stop);       // np <= 128
-    if (slots <= 10) return potrf_reg_launch<10>(e, s, n, np, A, Lp, lda, ldl, stop);     // np <= 192
-    if (slots <= 17) return potrf_reg_launch<17>(e, s, n, np, A, Lp, lda, ldl, stop);     // np <= 256
+    if (slots <= 2) return potrf_reg_launch<2>(e, s, n, np, A, Lp, lda, ldl, stop, cen);       // np <= 64
+    if (slots <= 5) return potrf_reg_launch<5>(e, s, n, np, A, Lp, lda, ldl, stop, cen);       // np <= 128
+    if (slots <= 10) return potrf_reg_launch<10>(e, s, n, np, A, Lp, lda, ldl, stop, cen);     // np <= 192
+    if (slots <= 17) return potrf_reg_launch<17>(e, s, n, np, A, Lp, lda, ldl, stop, cen);     // np <= 256
     e.err = "potrf: diagonal block too large for the register kernel";
     return CESX_EINVAL;
 }
@@ -1206,9 +1227,12 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
     // read what the side stream wrote (trace / bias partials, later L).  One event each way per step -- every
     // record / wait pair costs ~6 us of idle GPU.
     const bool early = e.chol_inflight;
+    // (early, centring fused into the Cholesky's load: the U part is done HERE, with the G part, and leaves the
+    //  status word alone -- the side stream carried nothing but the factorisation)
+    const int what = !early ? 3 : e.chol_fused_center ? (3 | 4) : 2;
     hipLaunchKernelGGL(center_kernel, dim3(NPB), dim3(DT), 0, s, mv, e.d_shift64, e.d_y, e.d_ustar,
                        e.diag_gamma ? e.d_gw : (const double*)nullptr,
-                       e.diag_sigma ? e.d_sw : (const double*)nullptr, unbiased, early ? 2 : 3, e.d_ubar, e.d_gbar,
+                       e.diag_sigma ? e.d_sw : (const double*)nullptr, unbiased, what, e.d_ubar, e.d_gbar,
                        e.d_m, e.d_dg, e.d_C, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_M, e.d_part, e.d_scal, e.d_lag);
     CESX_HIP(hipGetLastError());
     if (!early)
@@ -1312,14 +1336,30 @@ int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s, b
             CESX_HIP(hipStreamWaitEvent(e.side, e.ev_a, 0));
         }
     }
+    int rc;
+    e.chol_fused_center = e.fuse_center_ok && potrf_ld(p) <= 256;
+    if (e.chol_fused_center) {
+        // p <= 256 (one register-resident factorisation): the covariance is formed while the kernel loads the raw
+        // second moments -- no centring launch (13 us + a kernel boundary) in front of the 100-us Cholesky, which is
+        // what the caller's stream ends up waiting for; cesx_apply's own centring launch does the U part with the G
+        // part (C, M, ubar, the trace / bias partials: nothing the factorisation needs)
+        const int np = potrf_ld(p);
+        PotrfCen cen{mv.mom + e.ml.sa(), mv.mom, unbiased};
+        if (e.ext_events) {
+            if ((rc = potrf_reg_any(e, e.side, p, np, mv.mom + e.ml.Saa(), e.d_L, p, 0, e.ev_b, cen))) return rc;
+        } else {
+            if ((rc = potrf_reg_any(e, e.side, p, np, mv.mom + e.ml.Saa(), e.d_L, p, 0, nullptr, cen))) return rc;
+            CESX_HIP(hipEventRecord(e.ev_b, e.side));
+        }
+    } else {
     // (few workgroups -> 1024 threads each: 8 x 256 threads took 25 us for the 65 k elements of C, latency bound)
     hipLaunchKernelGGL(center_kernel, dim3(std::min(NPB, e.center_u_wgs)), dim3(e.center_u_wgs < NPB ? 1024 : DT), 0, e.side, mv, e.d_shift64, e.d_y, e.d_ustar,
                        e.diag_gamma ? e.d_gw : (const double*)nullptr,
                        e.diag_sigma ? e.d_sw : (const double*)nullptr, unbiased, 1, e.d_ubar, e.d_gbar,
                        e.d_m, e.d_dg, e.d_C, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_M, e.d_part, e.d_scal, (double*)nullptr);
     CESX_HIP(hipGetLastError());
-    int rc;
     if ((rc = potrf(e, e.side, p, e.d_C, e.d_L, e.ev_b))) return rc;      // ev_b: C, M, ubar, L -- what K2's scalar and assemble kernels read
+    }
     ++e.chol_seq;
     if (e.xi_want >= 0 && e.d_xi[0]) {
         // noise blocks asked for by cesx_prefetch_noise (cesx_internal.h): this step's, unless the lookahead of an

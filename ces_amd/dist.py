@@ -45,11 +45,23 @@ def shard_range(J, world, rank):
 class ShardedUpdate:
     """Drives one engine (this rank's shard) through sharded steps."""
 
-    def __init__(self, engine, group=None, overlap_comm=None):
+    def __init__(self, engine, group=None, overlap_comm=None, single_allreduce=None):
         self.engine = engine
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._recentered = False
+        # CESX_SINGLE_ALLREDUCE=1 (or single_allreduce=True): the north star's literal form -- ONE all-reduce of the
+        # whole moment buffer per step, after the complete Gram, with chol(C) in line behind it (on the critical
+        # path).  The default splits the same payload in two (head beside the second Gram launch, then the rest) so
+        # that chol(C) runs beside the Gram; which of the two wins on a real xGMI ring is for the 8-GPU run to say
+        # (bench.py prints the collective times and the Gram-end -> K3-start gap of a sampled step for both).
+        if single_allreduce is None:
+            single_allreduce = os.environ.get("CESX_SINGLE_ALLREDUCE", "0") == "1"
+        self.single_allreduce = bool(single_allreduce)
+        self.n_collectives = 0            # all-reduces issued so far (tests assert the per-step count)
+        self.collective_doubles = 0       # ... and their total payload
+        self.sample_collectives = False   # record an event pair around every all-reduce of the current step
+        self._coll_events = []
         # On GPUs the first all-reduce (the U x U head of the moment buffer) and chol(C) run on a
         # second stream while the main stream goes on with the rest of the Gram: the collective
         # costs no GPU idle time.  CESX_FORCE_COMM_OVERLAP=1 takes that path on one rank too (tests).
@@ -69,14 +81,34 @@ class ShardedUpdate:
         # one-rank rehearsal of the multi-GPU path: issue the collectives even though world == 1
         self._force_collectives = dist.is_initialized() and os.environ.get("CESX_FORCE_COLLECTIVES") == "1"
 
-    def _all_reduce(self, t, op=dist.ReduceOp.SUM):
+    def _all_reduce(self, t, op=dist.ReduceOp.SUM, tag="moments"):
         if self.world > 1 or self._force_collectives:
+            self.n_collectives += 1
+            self.collective_doubles += int(t.numel())
+            timed = self.sample_collectives and t.is_cuda
+            if timed:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(torch.cuda.current_stream(t.device))
             dist.all_reduce(t, op=op, group=self.group)
+            if timed:
+                b.record(torch.cuda.current_stream(t.device))
+                self._coll_events.append((tag, int(t.numel()), a, b))
         return t
+
+    def read_collective_ms(self):
+        """{tag: [doubles, ms]} of the all-reduces sampled since the last call (``sample_collectives``); synchronises."""
+        out = {}
+        for tag, numel, a, b in self._coll_events:
+            b.synchronize()
+            cur = out.setdefault(tag, [0, 0.0])
+            cur[0] += numel
+            cur[1] += a.elapsed_time(b)
+        self._coll_events = []
+        return out
 
     def recenter(self, U, G):
         """Centring shift = global ensemble means (same value on every rank)."""
-        sums = self._all_reduce(self.engine.colsum(U, G))
+        sums = self._all_reduce(self.engine.colsum(U, G), tag="recenter")
         self.engine.set_shift(sums)
         self._recentered = True
 
@@ -110,10 +142,18 @@ class ShardedUpdate:
         eng = self.engine
         if recenter or not self._recentered:
             self.recenter(U, G)
-        if noise_step is not None and hasattr(eng, "prefetch_noise"):
-            eng.prefetch_noise(noise_step)
+        if noise_step is not None and hasattr(eng, "prefetch_noise") and not self.single_allreduce:
+            eng.prefetch_noise(noise_step)       # (drawn behind chol(C) on the side stream: the single-collective mode has none)
         nuu = eng.moments_uu_len()
         mom = self._moment_buffer()
+        if self.single_allreduce:
+            # the whole Gram, ONE all-reduce of the whole buffer; cesx_apply then finds no chol(C) in flight and
+            # factors C in line (K2 of launch_dense) -- no side stream, no second collective
+            eng.moments_uu(U, G, out=mom)             # (= cesx_moments: both Gram launches back to back)
+            eng.moments_rest(U, G, mom)
+            self._all_reduce(mom, tag="whole")
+            self._mom = mom
+            return mom
         if self.overlap_comm and not self.side_gram and hasattr(eng, "moments_uu_handover"):
             # main stream: U x U Gram (the device to itself) -> hand-over -> the rest of the Gram;
             # side stream (high priority), beside the rest of the Gram: all-reduce of the head -> C, L = chol(C)
@@ -121,7 +161,7 @@ class ShardedUpdate:
                 self._cs = eng.side_stream()
             eng.moments_uu_handover(U, G, out=mom)
             with torch.cuda.stream(self._cs):
-                self._all_reduce(mom[:nuu])          # N, sum(u - s), S_aa: all chol(C) needs
+                self._all_reduce(mom[:nuu], tag="head")          # N, sum(u - s), S_aa: all chol(C) needs
                 eng.chol_async(prm, mom)
             eng.moments_rest(U, G, mom)
         elif self.overlap_comm or self.side_gram:
@@ -135,17 +175,17 @@ class ShardedUpdate:
                 eng.moments_uu(U, G, out=mom)
             eng.moments_rest(U, G, mom)
             with torch.cuda.stream(self._cs):
-                self._all_reduce(mom[:nuu])          # N, sum(u - s), S_aa: all chol(C) needs
+                self._all_reduce(mom[:nuu], tag="head")          # N, sum(u - s), S_aa: all chol(C) needs
                 eng.chol_async(prm, mom)
         elif self.world == 1 and not self._force_collectives and hasattr(eng, "moments_uu_chol"):
             eng.moments_uu_chol(prm, U, G, out=mom)  # no collective between the two: one call, no marker packet
             eng.moments_rest(U, G, mom)
         else:
             eng.moments_uu(U, G, out=mom)
-            self._all_reduce(mom[:nuu])
+            self._all_reduce(mom[:nuu], tag="head")
             eng.chol_async(prm, mom)                 # C, then L = chol(C) on the side stream ...
             eng.moments_rest(U, G, mom)              # ... beside the rest of the Gram
-        self._all_reduce(mom[nuu:])                  # apply() joins the side stream before K2 reads the head
+        self._all_reduce(mom[nuu:], tag="tail")      # apply() joins the side stream before K2 reads the head
         self._mom = mom
         return mom
 
@@ -154,7 +194,7 @@ class ShardedUpdate:
         eng, mom = self.engine, self._mom
         if prm.update == 2:                     # aldi_constant: max|drift| over all shards
             out = eng.empty(eng.p) if out is None else out
-            absmax = self._all_reduce(eng.apply_drift(prm, mom, U, G, out), op=dist.ReduceOp.MAX)
+            absmax = self._all_reduce(eng.apply_drift(prm, mom, U, G, out), op=dist.ReduceOp.MAX, tag="absmax")
             return eng.apply_finish(prm, absmax, U, xi, out)
         return eng.apply(prm, mom, U, G, xi=xi, out=out)
 
@@ -190,9 +230,9 @@ class ShardedSampler:
     so every rank takes the same ``t_tol`` decision without a broadcast.
     """
 
-    def __init__(self, engine, p, n_obs, J, group=None):
+    def __init__(self, engine, p, n_obs, J, group=None, single_allreduce=None):
         self.engine, self.p, self.n_obs, self.J = engine, p, n_obs, J
-        self.sh = ShardedUpdate(engine, group)
+        self.sh = ShardedUpdate(engine, group, single_allreduce=single_allreduce)
         self.T = 30
         self.metrics = {k: [] for k in _METRIC_KEYS}
         self.radspec = []

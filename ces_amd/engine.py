@@ -26,7 +26,7 @@ EXPORTS = ("cesx_abi_version", "cesx_create", "cesx_destroy", "cesx_last_error",
            "cesx_forward_lineal", "cesx_debug_dense", "cesx_profile_enable", "cesx_profile_read",
            "cesx_moments_uu_len", "cesx_moments_uu", "cesx_chol_async", "cesx_moments_rest", "cesx_side_stream",
            "cesx_prefetch_noise", "cesx_forward_set_lineal", "cesx_forward_apply", "cesx_moments_uu_chol", "cesx_moments_uu_handover", "cesx_debug_gram_plan",
-           "cesx_profile_clock", "cesx_calibrate_mfma")
+           "cesx_profile_clock", "cesx_calibrate_mfma", "cesx_profile_gap")
 
 
 class Config(C.Structure):
@@ -105,6 +105,7 @@ def load_library(path=None):
     lib.cesx_profile_enable.argtypes = [vp, i32]
     lib.cesx_profile_read.argtypes = [vp, i32, dp, C.POINTER(C.c_int)]
     lib.cesx_profile_clock.argtypes = [vp, dp]
+    lib.cesx_profile_gap.argtypes = [vp, dp]
     lib.cesx_calibrate_mfma.argtypes = [vp, C.c_double, dp, dp, vp]
     if lib.cesx_abi_version() != ABI_VERSION:
         raise ImportError("libcesx.so ABI %d != binding ABI %d" % (lib.cesx_abi_version(), ABI_VERSION))
@@ -614,6 +615,13 @@ class Engine:
         ms, cnt = C.c_double(), C.c_int()
         self._check(self.lib.cesx_profile_read(self._h, int(which), C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
+
+    def profile_gap(self):
+        """ms from the end of the last profiled Gram launch to the start of the last profiled update launch
+        (cesx_profile_gap; call before profile_read); None when nothing was profiled."""
+        ms = C.c_double()
+        self._check(self.lib.cesx_profile_gap(self._h, C.byref(ms)))
+        return ms.value if ms.value >= 0 else None
 
     def profile_clock(self):
         """Shader clock (GHz) of the last profiled update launch (cesx_profile_clock)."""

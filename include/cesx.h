@@ -271,6 +271,10 @@ int cesx_forward_apply(cesx_handle h, const void* U_dev, void* G_dev, void* stre
    number of launches since the last read, and resets the counters. */
 int cesx_profile_enable(cesx_handle h, int on);
 int cesx_profile_read(cesx_handle h, int which, double* total_ms, int* launches);
+/* Milliseconds from the end of the last profiled moments launch to the start of the last profiled update launch
+   (the K2 kernels, the hand-over from the side stream and -- sharded -- the collectives sit in between): call it
+   after the profiled step and BEFORE cesx_profile_read, which recycles the events.  -1 when nothing was profiled. */
+int cesx_profile_gap(cesx_handle h, double* gap_ms);
 /* Shader clock (GHz) the last PROFILED update launch (K3) ran at: one wave of it stamps s_memtime and the 100 MHz
    s_memrealtime at its start and end (profiled launches only; the others execute no stamp).  Synchronises.
    0.0 when no profiled launch has run. */

@@ -35,7 +35,7 @@ def _problem(p, n, J, T, seed=3):
     return dict(A=A, ustar=ustar, Gamma=Gamma, sigma=sigma, mu=mu, y=y, U0=U0, xis=xis)
 
 
-def _worker(rank, world, port, update, kwargs, q, device_hook=False, dims=(5, 4, 37, 6), overlap=False):
+def _worker(rank, world, port, update, kwargs, q, device_hook=False, dims=(5, 4, 37, 6), overlap=False, single=False):
     sys.path.insert(0, ROOT)
     from ces_amd.dist import ShardedSampler, shard_range
     from ces_amd.utils import lineal
@@ -45,7 +45,7 @@ def _worker(rank, world, port, update, kwargs, q, device_hook=False, dims=(5, 4,
     d = _problem(p, n, J, T)
     lo, hi = shard_range(J, world, rank)
     eng = FakeEngine(p, n, hi - lo, J_global=J, j_offset=lo)
-    smp = ShardedSampler(eng, p, n, J)
+    smp = ShardedSampler(eng, p, n, J, single_allreduce=single)
     smp.T = T
     if overlap:                              # the N > 1 GPU branch of ShardedUpdate.begin (hand-over + side-stream collective)
         smp.sh.overlap_comm = True
@@ -65,6 +65,12 @@ def _worker(rank, world, port, update, kwargs, q, device_hook=False, dims=(5, 4,
         dist.all_gather_object(gathered, (lo, U.numpy()))
         if overlap:
             assert eng.calls.count("uu_handover") >= T, eng.calls
+        # collectives per step: the recentring of the first step apart, ONE all-reduce of the whole buffer in the
+        # north star's literal mode, two (head + tail, the same payload) by default; aldi_constant adds its max
+        steps = len(smp.metrics["t"])
+        per_step = (1 if single else 2) + (1 if update == "aldi_constant" else 0)
+        assert smp.sh.n_collectives == 1 + per_step * steps, (smp.sh.n_collectives, steps)
+        assert smp.sh.collective_doubles == (1 + p + n) + steps * (eng.moments_len() + (1 if update == "aldi_constant" else 0))
         if rank == 0:
             full = np.concatenate([g[1] for g in sorted(gathered, key=lambda g: g[0])], axis=1)
             q.put((full, {k: list(v) for k, v in smp.metrics.items()}, list(smp.radspec)))
@@ -149,6 +155,31 @@ def test_eight_ranks_ragged_shards(update, kwargs, hook):
         pr.join(timeout=60)
         assert pr.exitcode == 0
     _check_against_oracle(full, metrics, radspec, dims, update, kwargs)
+
+
+@pytest.mark.parametrize("update,kwargs,hook", [("aldi", {}, True), ("eks", {}, False), ("aldi_constant", {"switch": 0.5}, True)])
+def test_single_allreduce_mode_matches_the_split_mode(update, kwargs, hook):
+    """CESX_SINGLE_ALLREDUCE (the north star's literal form: one all-reduce of the whole moment buffer per step,
+    chol(C) in line) and the default two-piece form give the same trajectory and metrics on two gloo ranks -- and
+    both equal the single-process oracle; the per-step collective count (1 vs 2) is asserted in the worker."""
+    dims = (5, 4, 37, 6)
+    res = []
+    for single in (True, False):
+        world, port = 2, _free_port()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, update, kwargs, q, hook, dims, False, single)) for r in range(world)]
+        for pr in procs:
+            pr.start()
+        res.append(q.get(timeout=120))
+        for pr in procs:
+            pr.join(timeout=60)
+            assert pr.exitcode == 0
+    (full1, m1, _), (full2, m2, _) = res
+    assert np.array_equal(full1, full2)
+    for k in m1:
+        assert m1[k] == m2[k], k
+    _check_against_oracle(full1, m1, None, dims, update, kwargs)
 
 
 def test_resumed_run_draws_fresh_noise():

@@ -181,6 +181,52 @@ def test_c5_per_gpu_shape_fp64():
         torch.cuda.empty_cache()
 
 
+def test_c5_eight_logical_shards_of_262144():
+    """Config C5's arithmetic at its GLOBAL size on one device: J = 262 144 fp64 particles, p = n_obs = 512, as 8
+    logical shards of 32 768 (what each of the 8 GPUs holds): moments summed on the device (stand-in for the RCCL
+    all-reduce), the blocked on-device Cholesky of the 512 x 512 covariance run redundantly by every shard, apply
+    per shard == the single-engine step over the whole ensemble (on-device noise keyed by the global index)."""
+    import torch
+    from ces_amd import engine
+    p = n = 512
+    Js, nsh = 32768, 8
+    Jg = Js * nsh
+    rng = np.random.default_rng(1)
+    A = rng.standard_normal((n, p)) / np.sqrt(p)
+    ustar = rng.standard_normal((p, 1))
+    prob = dict(A=A, ustar=ustar, Gamma=0.01 * np.eye(n), y=(A @ ustar).ravel() + 0.1 * rng.standard_normal(n),
+                mu=np.zeros((p, 1)), sigma=100.0 * np.eye(p))
+    g = torch.Generator(device="cuda").manual_seed(17)
+    Ug = torch.as_tensor(ustar, device="cuda") + torch.randn((p, Jg), generator=g, device="cuda", dtype=torch.float64)
+    Gg = torch.as_tensor(A, device="cuda") @ Ug
+    whole = engine.Engine(p, n, Jg, dtype="float64")
+    whole.set_problem(prob["y"], prob["Gamma"], prob["mu"], prob["sigma"], prob["ustar"])
+    prm = engine.step_params(update="aldi", step_index=2)
+    ref = whole.step(prm, Ug, Gg, xi=None)
+    rw = whole.result()
+    shards = []
+    for k in range(nsh):
+        e = engine.Engine(p, n, Js, dtype="float64", J_global=Jg, j_offset=k * Js)
+        e.set_problem(prob["y"], prob["Gamma"], prob["mu"], prob["sigma"], prob["ustar"])
+        shards.append((e, Ug[:, k * Js:(k + 1) * Js].contiguous(), Gg[:, k * Js:(k + 1) * Js].contiguous()))
+    sums = sum(e.colsum(Us, Gs) for e, Us, Gs in shards)
+    for e, *_ in shards:
+        e.set_shift(sums)
+    mom = sum(e.moments(Us, Gs) for e, Us, Gs in shards)
+    assert float(mom[0]) == Jg
+    outs = [e.apply(prm, mom, Us, Gs, xi=None) for e, Us, Gs in shards]
+    share = [e.result() for e, *_ in shards]
+    got = torch.cat(outs, dim=1)
+    err = ((got - ref).abs().max() / ref.abs().max()).item()
+    assert err < 1e-9, err                                  # (1e-6 is the north star's fp64 bar)
+    assert all(s.hk == share[0].hk for s in share)          # every rank takes the same t_tol decision
+    assert share[0].hk == pytest.approx(rw.hk, rel=1e-10)
+    assert sum(s.bias_data for s in share) == pytest.approx(rw.bias_data, rel=1e-9)
+    assert sum(s.self_bias_data for s in share) == pytest.approx(rw.self_bias_data, rel=1e-9)
+    del whole, shards, outs, got, ref, Ug, Gg
+    torch.cuda.empty_cache()
+
+
 def test_c3_logical_shards_match_whole_ensemble(setup):
     """configs[2] arithmetic on one device: 4 column shards, moments summed on device
     (stand-in for the RCCL all-reduce), apply per shard == single-shard step."""

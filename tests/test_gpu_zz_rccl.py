@@ -47,7 +47,7 @@ def rccl_one_rank():
     dist.destroy_process_group()
 
 
-def _chain(engine, d, update, p, n, J, steps, monkeypatch, collectives, counter):
+def _chain(engine, d, update, p, n, J, steps, monkeypatch, collectives, counter, single=False):
     import torch.distributed as dist
     from ces_amd.dist import ShardedUpdate
     if collectives:
@@ -64,7 +64,7 @@ def _chain(engine, d, update, p, n, J, steps, monkeypatch, collectives, counter)
     monkeypatch.setattr(dist, "all_reduce", counted)
     eng = engine.Engine(p, n, J, dtype="float32", seed=9)
     eng.set_problem(d["y"], d["Gamma"], d["mu"], d["sigma"], d["ustar"])
-    sh = ShardedUpdate(eng)
+    sh = ShardedUpdate(eng, single_allreduce=single)
     assert sh.overlap_comm == collectives
     U = eng.to_device(d["U0"])
     t_last, chain = 0.0, []
@@ -91,6 +91,25 @@ def test_one_rank_rccl_path_is_bit_identical(rccl_one_rank, monkeypatch, update)
     nuu, nall = 1 + p + p * p, 1 + p + n + p * p + p * n + n * n + 2
     per_step = [nuu, nall - nuu] + ([1] if update == "aldi_constant" else [])
     assert calls_rccl == [1 + p + n] + per_step * steps    # centring shift once, then head + tail (+ max) per step
+    assert np.array_equal(ref[0], got[0])
+    assert ref[1] == got[1]
+
+
+@pytest.mark.parametrize("update", ["aldi", "aldi_constant"])
+def test_one_rank_rccl_single_allreduce_mode(rccl_one_rank, monkeypatch, update):
+    """CESX_SINGLE_ALLREDUCE, the north star's literal form: ONE all-reduce (the whole moment buffer) per step
+    through RCCL, chol(C) in line.  Same numbers as the default two-piece form to rounding of the in-line
+    Cholesky's position in the stream (it is the same kernel on the same matrix: bit-identical)."""
+    from ces_amd import engine
+    p, n, J, steps = 128, 96, 8192, 4
+    d = _problem(p, n, J)
+    calls_split, calls_single = [], []
+    ref = _chain(engine, d, update, p, n, J, steps, monkeypatch, True, calls_split)
+    got = _chain(engine, d, update, p, n, J, steps, monkeypatch, True, calls_single, single=True)
+    nall = 1 + p + n + p * p + p * n + n * n + 2
+    per_step = [nall] + ([1] if update == "aldi_constant" else [])
+    assert calls_single == [1 + p + n] + per_step * steps       # centring shift once, then ONE all-reduce (+ max) per step
+    assert sum(calls_single) == sum(calls_split)                # the same payload as head + tail
     assert np.array_equal(ref[0], got[0])
     assert ref[1] == got[1]
 
