@@ -29,6 +29,16 @@ __device__ __forceinline__ double dblock_sum(double v, double* red) {
     return s;   // valid on every thread
 }
 
+// One entry of C = cov(U) + 1e-8 I (ces/calibrate.py:424/:476/:512) from the shifted raw moments, with the rounding
+// sequence pinned (explicit fma): center_kernel and potrf_reg_kernel (centring fused into its load) must produce the
+// same bits.  suu = S_ij - (sa_i sa_j) / N is returned through `suu` (the trace term of the metrics).
+__device__ __forceinline__ double cov_entry(double S, double sai, double saj, double invN, double invdiv, bool diag, double* suu) {
+    const double t = sai * saj;
+    const double u = fma(-t, invN, S);
+    if (suu) *suu = u;
+    return fma(u, invdiv, diag ? 1e-8 : 0.0);
+}
+
 struct MomView {
     int p, n;
     const double* mom;
@@ -65,12 +75,17 @@ void center_kernel(MomView mv, const double* __restrict__ shift, const double* _
     }
     const int p = mv.p, n = mv.n;
     const double N = mv.N();
+    // (reciprocals: potrf_reg_kernel forms the same C_ij while it loads S_aa -- one workgroup, 64 elements per thread --
+    //  and two fp64 divisions per element cost it 18 us; both kernels use the SAME expression, so the matrix that is
+    //  factored and the matrix M is built from agree bit for bit)
+    const double invN = 1.0 / N;
     // what a deferred metric finalisation (Engine::met_deferred) needs of this buffer, copied into engine-owned
     // memory: the caller's moment buffer need not outlive cesx_apply
     if ((what & 2) && lag != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
         lag[0] = N; lag[1] = mv.mom[mv.ml().tail()]; lag[2] = mv.mom[mv.ml().tail() + 1];
     }
     const double div = unbiased ? N - 1.0 : N;
+    const double invdiv = 1.0 / div;
     const double* sa = mv.sa();
     const double* sb = mv.sb();
     // 32-bit index arithmetic (p, n < 32768): a 64-bit divide per element used to dominate this kernel
@@ -81,8 +96,8 @@ void center_kernel(MomView mv, const double* __restrict__ shift, const double* _
         const double* Saa = mv.Saa();
         for (unsigned idx = gid; idx < pp; idx += gsz) {
             const unsigned i = idx / (unsigned)p, j = idx - i * (unsigned)p;
-            const double suu = Saa[idx] - sa[i] * sa[j] / N;
-            const double c = suu / div + (i == j ? 1e-8 : 0.0);
+            double suu;
+            const double c = cov_entry(Saa[idx], sa[i], sa[j], invN, invdiv, i == j, &suu);
             C[idx] = c;
             if (sw) M[idx] = c * sw[j];              // M = C Sigma^{-1}, diagonal Sigma
             if (i == j) tr += suu;
@@ -268,7 +283,7 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
                       long long* dbg = nullptr,     // dbg: per-phase cycle counts (tools/potrf_bench only)
                       int lda = 0, int ldl = 0,     // row strides of A / Lp (0: n / np); a diagonal block of a larger matrix
                       // cen_sa != nullptr: A is the RAW second moment S_aa of the packed buffer and the covariance is
-                      // formed while it is loaded, C_ij = (S_ij - sa_i sa_j / N) / div + 1e-8 [i == j] -- the arithmetic
+                      // formed while it is loaded, C_ij = (S_ij - sa_i sa_j (1/N)) (1/div) + 1e-8 [i == j] -- the arithmetic
                       // of center_kernel, element for element (ces/calibrate.py:424/:476/:512), so the U-only centring
                       // kernel no longer sits in front of the factorisation on the side stream; the status word is
                       // reset here then
@@ -276,10 +291,11 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
                       int cen_unbiased = 0) {
     if (lda == 0) lda = n;
     if (ldl == 0) ldl = np;
-    double cN = 1.0, cdiv = 1.0;
+    double cinvN = 1.0, cinvdiv = 1.0;
     if (cen_sa != nullptr) {
-        cN = *cen_N;
-        cdiv = cen_unbiased ? cN - 1.0 : cN;
+        const double cN = *cen_N;
+        cinvN = 1.0 / cN;
+        cinvdiv = 1.0 / (cen_unbiased ? cN - 1.0 : cN);
         if (threadIdx.x == 0) *status = CESX_OK;
     }
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -331,7 +347,7 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
             if (j > i) { const int t = i; i = j; j = t; } // diagonal tiles are kept fully symmetric
             if (on && i < n) {
                 v = A[(size_t)i * lda + j];
-                if (cen_sa != nullptr) v = (v - cen_sa[i] * cen_sa[j] / cN) / cdiv + (i == j ? 1e-8 : 0.0);
+                if (cen_sa != nullptr) v = cov_entry(v, cen_sa[i], cen_sa[j], cinvN, cinvdiv, i == j, nullptr);
             }
             Pt[s][e] = v;
         }

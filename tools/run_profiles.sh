@@ -6,7 +6,7 @@ set -o pipefail
 TAG=$1; CFG=${2:-C2}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 ARGS="bench.py --config $CFG --no-cpu-baseline --no-extras --steps 12 --warmup 3"
-export CESX_BENCH_PREWARM=8
+export CESX_BENCH_PREWARM_S=${CESX_BENCH_PREWARM_S:-0.3}
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_k -- python3 $ARGS > gpurun_out/prof_${TAG}_k.log 2>&1 || exit 2
 for ctr in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
   rocprofv3 --pmc $ctr --output-format csv -d gpurun_out/prof_${TAG}_$ctr -- python3 $ARGS > gpurun_out/prof_${TAG}_$ctr.log 2>&1 || exit 3

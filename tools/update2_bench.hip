@@ -1,6 +1,7 @@
 // dev tool: update2_kernel (LDS-DMA ring) against update_kernel on the C2 shape: results + time.
 #include "../ces_amd/csrc/kernels_update.hip"
 #include "../ces_amd/csrc/kernels_update2.hip"
+#include "../ces_amd/csrc/kernels_update3.hip"
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
@@ -59,7 +60,7 @@ int main(int argc, char** argv) {
     b.src0 = a.src[0]; b.src1 = a.src[1]; b.src2 = a.src[2]; b.rows0 = p; b.rows1 = n; b.rows2 = p;
     b.kt1 = kp / 16; b.kt2 = (kp + kn) / 16; b.kind0 = 0; b.kind1 = 0; b.kind2 = a.src_kind[2];
     b.J = J; b.j_offset = a.j_offset; b.out = out2; b.rowc = rowc; b.metric_part = f_nomet ? nullptr : mpart2; b.metric_seg = 1; b.tri_seg = a.tri_seg;
-    b.seed_lo = 1; b.seed_hi = 2; b.step = 3; b.stagger_from = flag(argc, argv, "nostagger") ? 0x7fffffff : 256;
+    b.seed_lo = 1; b.seed_hi = 2; b.step = 3; b.stagger_from = flag(argc, argv, "nostagger") ? 0x7fffffff : 256; b.stagger_n = 2;
 
     using C = UpdCfg<float>;
     constexpr int RC = 4 * C::WR * 32, BN = C::WC * 32;
@@ -68,11 +69,12 @@ int main(int argc, char** argv) {
     auto kern = (J % 4 == 0) ? update_kernel<float, true, UpdCfg<float>::WC> : update_kernel<float, false, UpdCfg<float>::WC>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     const int lds2 = U2_RING * (U2_WSLOT + U2_XSLOT) + kn * 16;
-    CK(hipFuncSetAttribute((const void*)update2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+    auto kern2 = f_mem ? update2_kernel<false> : update2_kernel<true>;      // (mem: every segment from memory = the benchmark's launch)
+    CK(hipFuncSetAttribute((const void*)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
     CK(hipMemset(out, 0, (size_t)p * J * 4)); CK(hipMemset(out2, 0xff, (size_t)p * J * 4));
     hipLaunchKernelGGL(kern, grid, dim3(UPD_THREADS), lds, 0, a);
     CK(hipDeviceSynchronize());
-    hipLaunchKernelGGL(update2_kernel<true>, grid, dim3(U2_THREADS), lds2, 0, b);
+    hipLaunchKernelGGL(kern2, grid, dim3(U2_THREADS), lds2, 0, b);
     CK(hipDeviceSynchronize());
     {
         std::vector<float> h1((size_t)p * J), h2((size_t)p * J);
@@ -96,9 +98,9 @@ int main(int argc, char** argv) {
         }
     }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(update2_kernel<true>, grid, dim3(U2_THREADS), lds2, 0, b);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern2, grid, dim3(U2_THREADS), lds2, 0, b);
     hipEventRecord(e0);
-    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(update2_kernel<true>, grid, dim3(U2_THREADS), lds2, 0, b);
+    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern2, grid, dim3(U2_THREADS), lds2, 0, b);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
 #ifdef U2_CLOCKS
