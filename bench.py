@@ -41,29 +41,16 @@ MFMA_PEAK_TF = {"float32": 157.3, "float64": 78.6}   # dense matrix peaks, f32-i
 
 
 def cpu_share():
-    """Host cores this process may actually use: the cgroup CPU quota when there is one (the GPU boxes expose
-    256 logical CPUs but give a 1-GPU job a 16-core share; 128 BLAS threads on that share run several times
-    slower than 16), else the affinity mask."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
-        try:
-            txt = open(path).read().split()
-            if path.endswith("cpu.max"):
-                if txt[0] != "max":
-                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
-            else:
-                q = int(txt[0])
-                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-                if q > 0:
-                    n = min(n, max(1, q // per))
-        except (OSError, ValueError, IndexError):
-            pass
-    return n
+    """Host cores this process may actually use (ces_amd.engine.cpu_share: cgroup quota, else the affinity mask)."""
+    from ces_amd.engine import cpu_share as _share
+    return _share()
 
 
-def limit_host_threads():
-    """Size the BLAS / torch host thread pools to the CPU share (returns the thread count)."""
-    n = cpu_share()
+def limit_host_threads(reserve=0):
+    """Size the BLAS / torch host thread pools to the CPU share minus `reserve` (returns the thread count).  The
+    end-to-end host-array leg reserves the engine's copy threads: BLAS threads spin on after a GEMM, and BLAS + copy
+    threads above the cgroup quota get the whole process throttled (ces_amd.engine.default_copy_threads)."""
+    n = max(1, cpu_share() - reserve)
     try:
         from threadpoolctl import threadpool_limits
         threadpool_limits(n)
@@ -195,7 +182,7 @@ def e2e_block(engine, prob, p, n, J, dtype, update, dev_index):
     from ces_amd.dist import ShardedSampler
     from ces_amd.utils import lineal
     out = {}
-    nthreads = limit_host_threads()
+    nthreads = limit_host_threads(reserve=engine.Engine.copy_threads)
     rng = np.random.default_rng(3)
     U0 = prob["ustar"] + rng.standard_normal((p, J))
     model = lineal(prob["A"])
@@ -231,7 +218,13 @@ def e2e_block(engine, prob, p, n, J, dtype, update, dev_index):
         fwd_ms.append(1e3 * (t1 - t0))
         stamps.append((t0, t1))
         return g
-    nst = 12
+    nst = 24
+
+    def cpu_stat():
+        try:
+            return {k: int(v) for k, v in (ln.split() for ln in open("/sys/fs/cgroup/cpu.stat"))}
+        except Exception:
+            return {}
     eks = sampling(p=p, n_obs=n, J=J)
     eks.mu, eks.sigma, eks.ustar = prob["mu"], prob["sigma"], prob["ustar"]
     eks.engine_dtype, eks.noise, eks.device, eks.device_loop = np.dtype(dtype).name, "device", dev_index, False
@@ -240,20 +233,28 @@ def e2e_block(engine, prob, p, n, J, dtype, update, dev_index):
     eks.run(prob["y"], U0, host_lineal(), prob["Gamma"], None, trace=False, t_tol=1e30)      # builds engine + pinned buffers
     eks.T = nst
     del fwd_ms[:], stamps[:]
+    st0 = cpu_stat()
     t0 = time.perf_counter()
     eks.run(prob["y"], eks.Ustar, host_lineal(), prob["Gamma"], None, trace=False, t_tol=1e30)
     el = time.perf_counter() - t0
+    st1 = cpu_stat()
     fwd = sum(fwd_ms) / (nst + 1)                           # run evaluates the map once more for the final ensemble
     # one update call = from the end of one forward evaluation to the start of the next
     calls = [1e3 * (stamps[i + 1][0] - stamps[i][1]) for i in range(len(stamps) - 1)]
+    pct = lambda v: dict(p50=round(float(np.percentile(v, 50)), 3), p95=round(float(np.percentile(v, 95)), 3),
+                         max=round(float(np.max(v)), 3)) if len(v) else None
     out["host_arrays"] = dict(value=J * nst / el, unit="particle-updates/s", steps=nst, ms_per_step=1e3 * el / nst,
                               host_forward_ms=fwd, update_call_ms=1e3 * el / nst - fwd * (nst + 1) / nst,
                               host_forward_ms_median=float(np.median(fwd_ms)),
                               update_call_ms_median=float(np.median(calls)) if calls else None,
-                              host_threads=nthreads,
+                              update_call_ms_pct=pct(calls), host_forward_ms_pct=pct(fwd_ms),
+                              host_threads=nthreads, copy_threads=int(engine.Engine.copy_threads),
+                              cgroup_periods_throttled="%d of %d" % (st1.get("nr_throttled", 0) - st0.get("nr_throttled", 0),
+                                                                     st1.get("nr_periods", 0) - st0.get("nr_periods", 0)),
                               includes="sampling.run(trace=False) with a host forward map (numpy A @ U), float64 numpy "
                                        "arrays across PCIe into and out of every update; PCIe Gen5 floor for the "
-                                       "%.0f MB of engine-dtype traffic per step ~%.1f ms"
+                                       "%.0f MB of engine-dtype traffic per step ~%.1f ms; BLAS threads + the engine's "
+                                       "copy threads = the cgroup CPU share (more gets the process throttled)"
                                        % ((2 * p + n) * J * np.dtype(dtype).itemsize / 1e6,
                                           (2 * p + n) * J * np.dtype(dtype).itemsize / 56e9 * 1e3))
     return out

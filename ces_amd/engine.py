@@ -58,6 +58,36 @@ class CesxError(RuntimeError):
 _lib = None
 
 
+def cpu_share():
+    """Host cores this process may actually use: the cgroup CPU quota when there is one (a GPU box exposes 256
+    logical CPUs and gives a one-GPU job a 16-core share), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
+
+
+def default_copy_threads():
+    """Host threads for the staging casts.  They are memory-bound (4 threads already move a 256 x 65 536 block in
+    1.5 ms) and they run right after the caller's own BLAS threads, which keep spinning for a while: on a box with
+    a cgroup CPU quota the two pools TOGETHER must stay within the quota, or the kernel throttles the whole process
+    for the rest of the 100-ms period -- 40-50 ms stalls in whatever phase runs next (round 3, tools/hostloop_probe.py:
+    16 BLAS + 16 copy threads on a 16-core share: every period throttled, 30.7 ms per iteration; 12 + 4: none, 18.5).
+    A quarter of the share, at least 2, at most 8."""
+    return max(2, min(8, cpu_share() // 4))
+
+
 def load_library(path=None):
     """Load libcesx.so and declare its prototypes.  Loud failure when absent."""
     global _lib
@@ -198,7 +228,7 @@ class Engine:
     # for a 256 x 65 536 block, against 11 ms for numpy astype + a pageable upload), the way back
     # is pinned engine-dtype -> float64 on the host (3.9 ms against 32 ms).  Large blocks only.
     _PIN_MIN = 1 << 16
-    copy_threads = 16        # host threads for the staging casts: more than the process's CPU share stalls them
+    copy_threads = default_copy_threads()     # host threads for the staging casts (see default_copy_threads)
 
     class _HostThreads:
         """Bound torch's intra-op thread count for a host-side copy (a 128-thread pool on a
