@@ -187,7 +187,10 @@ def e2e_block(engine, prob, p, n, J, dtype, update, dev_index):
     U0 = prob["ustar"] + rng.standard_normal((p, J))
     model = lineal(prob["A"])
     eng = engine.Engine(p, n, J, dtype=dtype, device=dev_index, seed=77)
-    for T, timed in ((8, False), (40, True)):
+    for T, timed, fast in ((8, False, True), (40, True, True), (8, False, False), (40, True, False)):
+        # fast: the linear map lives in the engine, so the G-dependent moments follow from the U-only head
+        # (cesx_moments_rest_lineal) and the forward GEMM runs beside chol(C); not fast: forward map, then the full Gram
+        os.environ["CESX_LINEAL_FAST"] = "1" if fast else "0"
         smp = ShardedSampler(eng, p, n, J)
         smp.T = T
         torch.cuda.synchronize()
@@ -197,9 +200,14 @@ def e2e_block(engine, prob, p, n, J, dtype, update, dev_index):
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         if timed:
-            out["device_chain"] = dict(value=J * T / el, unit="particle-updates/s", ms_per_step=1e3 * el / T, steps=T,
-                                       includes="upload of U0 once, then per step: G = A U on device, update with "
-                                                "on-device noise, host read of t; U_next fed back")
+            key = "device_chain" if fast else "device_chain_full_gram"
+            out[key] = dict(value=J * T / el, unit="particle-updates/s", ms_per_step=1e3 * el / T, steps=T,
+                            lineal_fast_path=bool(fast and smp.sh.lineal_fast_ok(model)),
+                            includes="upload of U0 once, then per step: G = A U on device, update with "
+                                     "on-device noise, host read of t; U_next fed back" +
+                                     ("; the G-dependent moments from the U-only head and the installed linear map "
+                                      "(no second Gram launch)" if fast else "; full Gram over [U; G]"))
+    os.environ.pop("CESX_LINEAL_FAST", None)
     del eng
     # the reference's own calling convention: sampling.run with a host forward map and float64 numpy arrays
     # across PCIe into and out of every update (device_loop off).  G_ens evaluates the linear map for the whole

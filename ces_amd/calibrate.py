@@ -328,6 +328,7 @@ class sampling(enka):
         U = eng.to_device(U0, self.p, "U")
         G = model.forward_device(eng, U)
         sh.begin(prm0, U, G, recenter=True, noise_step=None if xis is not None else self._step_counter)
+        fast = sh.lineal_fast_ok(model)       # linear map on the device: G's moments follow from U's (no second Gram launch)
         G_next = None
         for i in range(self.T):
             if trace and (i % stride == 0):                        # :356-358 (a copy: the device buffers are reused)
@@ -344,8 +345,12 @@ class sampling(enka):
             U_new = sh.finish(prm, U, G, xi=xi)
             G_next = None
             if i + 1 < self.T:                                     # first half of the next iteration, ahead of the read
-                G_next = model.forward_device(eng, U_new)
-                sh.begin(prm0, U_new, G_next, noise_step=None if xis is not None else self._step_counter)
+                ns = None if xis is not None else self._step_counter
+                if fast:
+                    _, G_next = sh.begin_lineal(prm0, U_new, lambda u: model.forward_device(eng, u), noise_step=ns)
+                else:
+                    G_next = model.forward_device(eng, U_new)
+                    sh.begin(prm0, U_new, G_next, noise_step=ns)
             res = sh.result()
             self._append_result(rule, res, kwargs)
             U, G = U_new, G_next

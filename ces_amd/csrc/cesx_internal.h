@@ -335,6 +335,8 @@ struct Engine {
     void* d_Wfwd_f = nullptr;      // the same map in the fragment-major order of the LDS-DMA update kernels (cesx_forward_set_lineal)
     void* d_bfwd = nullptr;        // [rpad] its offset b
     bool  fwd_set = false, fwd_has_b = false;
+    double *d_A64 = nullptr, *d_b64 = nullptr;   // the installed map in fp64 (n x p, n): cesx_moments_rest_lineal
+    double *d_lvec = nullptr;                    // [2][n] c = A s_u + b - s_g and A sa
     // per-kernel profiling (cesx_profile_*)
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[2];
@@ -444,6 +446,7 @@ int gram_kt(int dtype);
 int gram_max_stage_rows();
 int launch_noise(Engine& e, uint64_t step_index, void* xi, hipStream_t s);
 int launch_stage_forward(Engine& e, const void* A, const void* b, hipStream_t s);   // A, b -> d_Wfwd, d_Wfwd_f, d_bfwd
+int launch_moments_lineal(Engine& e, double* mom, hipStream_t s);                   // G part of the moments from the head + the installed linear map
 int launch_calibrate(Engine& e, double target_ms, double* tflops, double* clock_ghz, hipStream_t s);   // kernels_calib.hip
 
 // Event pair for one profiled launch (cesx_profile_*).  bound = false: the pair is RECORDED around the launch (two

@@ -316,6 +316,7 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
     DM(e.d_absmax_part, (size_t)update_grid_blocks(e, p) * 8);
     DM(e.d_clk, 4 * 8);
     DM(e.d_lag, 3 * 8);
+    DM(e.d_A64, (size_t)n * p * 8); DM(e.d_b64, n * 8); DM(e.d_lvec, 2 * n * 8);
 #undef DM
     if (hipHostMalloc(reinterpret_cast<void**>(&e.h_scal), sizeof(Scalars), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void**>(&e.h_scal_dev), e.h_scal, 0) != hipSuccess ||
@@ -358,7 +359,7 @@ void cesx_destroy(cesx_handle h) {
                     e.gp[1].d_type_hdr, e.gp[1].d_rows, e.gp[1].d_wblk, e.gp[1].d_blk_rc, e.gp[1].d_row_own, e.gp[1].d_slabs, e.gp[1].d_rowsum_part, e.d_sums, e.d_ubar, e.d_gbar, e.d_m, e.d_dg,
                     e.d_wdel, e.d_C, e.d_L, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_Kp, e.d_M, e.d_P, e.d_PK,
                     e.d_t1, e.d_t2, e.d_t3, e.d_t4, e.d_Lp, e.d_lanczos, e.d_mv, e.d_part, e.d_scal, e.d_absmax,
-                    e.d_c0, e.d_absmax_part, e.d_clk, e.d_lag};
+                    e.d_c0, e.d_absmax_part, e.d_clk, e.d_lag, e.d_A64, e.d_b64, e.d_lvec};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     for (int w = 0; w < 2; ++w)
@@ -521,6 +522,18 @@ int cesx_moments_rest(cesx_handle h, const void* U, const void* G, double* mom, 
     // (the reduce kernel of this launch also copies this shard's data-metric sums of the PREVIOUS
     //  apply to the tail of the buffer: they ride on this step's all-reduce)
     return launch_gram(e, 1, U, G, mom, (hipStream_t)stream);
+}
+
+int cesx_moments_rest_lineal(cesx_handle h, double* mom, void* stream) {
+    if (!h) return CESX_EINVAL;
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    if (!mom) { e.err = "cesx_moments_rest_lineal: null pointer"; return CESX_EINVAL; }
+    if (!e.problem_set) { e.err = "cesx_set_problem has not been called"; return CESX_ESTATE; }
+    if (!e.shift_valid) { e.err = "no centring shift: call cesx_colsum + cesx_set_shift (or cesx_step with recenter) first"; return CESX_ESTATE; }
+    if (!e.fwd_set) { e.err = "cesx_moments_rest_lineal: cesx_forward_set_lineal has not been called"; return CESX_ESTATE; }
+    SET_DEVICE(e);
+    FLUSH(e);
+    return launch_moments_lineal(e, mom, (hipStream_t)stream);
 }
 
 int cesx_moments(cesx_handle h, const void* U, const void* G, double* mom, void* stream) {

@@ -914,7 +914,8 @@ void finish_aldi_kernel(MomView mv, cesx_step_params prm, const double* __restri
 // kernels read (wf_index / wd_index), b -> padded offset vector
 template <typename T>
 __global__ void stage_forward_kernel(int n, int p, int rpad, int kp, const T* __restrict__ A, const T* __restrict__ b,
-                                     T* __restrict__ W, T* __restrict__ Wf, T* __restrict__ bias) {
+                                     T* __restrict__ W, T* __restrict__ Wf, T* __restrict__ bias,
+                                     double* __restrict__ A64, double* __restrict__ b64) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < (long long)rpad * kp) {
         const int i = (int)(idx / kp), k = (int)(idx % kp);
@@ -922,18 +923,84 @@ __global__ void stage_forward_kernel(int n, int p, int rpad, int kp, const T* __
         W[idx] = v;
         if (sizeof(T) == 4) Wf[wf_index(i, k, kp / 16)] = v;
         else Wf[wd_index(i, k, kp / 16)] = v;
+        if (i < n && k < p) A64[(size_t)i * p + k] = (double)v;      // the SAME map in fp64 (cesx_moments_rest_lineal)
     }
     if (idx < rpad) bias[idx] = (b != nullptr && idx < n) ? b[idx] : (T)0;
+    if (idx < n) b64[idx] = b != nullptr ? (double)b[idx] : 0.0;
 }
 
 int launch_stage_forward(Engine& e, const void* A, const void* b, hipStream_t s) {
     const long long len = (long long)e.rpad * e.kp;
     if (e.cfg.dtype == CESX_F32)
         hipLaunchKernelGGL(stage_forward_kernel<float>, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s, e.n, e.p, e.rpad, e.kp,
-                           (const float*)A, (const float*)b, (float*)e.d_Wfwd, (float*)e.d_Wfwd_f, (float*)e.d_bfwd);
+                           (const float*)A, (const float*)b, (float*)e.d_Wfwd, (float*)e.d_Wfwd_f, (float*)e.d_bfwd, e.d_A64, e.d_b64);
     else
         hipLaunchKernelGGL(stage_forward_kernel<double>, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s, e.n, e.p, e.rpad, e.kp,
-                           (const double*)A, (const double*)b, (double*)e.d_Wfwd, (double*)e.d_Wfwd_f, (double*)e.d_bfwd);
+                           (const double*)A, (const double*)b, (double*)e.d_Wfwd, (double*)e.d_Wfwd_f, (double*)e.d_bfwd, e.d_A64, e.d_b64);
+    CESX_HIP(hipGetLastError());
+    return CESX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// G-dependent moments of a LINEAR forward map without a pass over G ("K1 can then fuse G = A U
+// into the moments pass").  With g_j = A u_j + b (utils.lineal, ces/utils.py:25-31), a_j = u_j - s_u and
+// c = A s_u + b - s_g:   g_j - s_g = A a_j + c, so from the U-only head (N, sa = sum a_j, S_aa = sum a_j a_j^T):
+//     sum (g_j - s_g)           = A sa + N c
+//     S_ab = sum a_j (g_j-s_g)^T = S_aa A^T + sa c^T
+//     S_bb                       = A S_aa A^T + (A sa) c^T + c (A sa)^T + N c c^T
+// -- the moments ces/calibrate.py:459-461 / :472 take from Geval, exactly (in fp64, from the fp64 head), for the G the
+// engine's own forward kernel produces from this U (cesx_forward_apply).  Two n x p x p fp64 GEMMs instead of the
+// second Gram launch (100 of the 136 blocks) and its reduce.
+// ---------------------------------------------------------------------------
+// lv[0][j] = c_j, lv[1][j] = (A sa)_j: one wave per row of A
+__global__ __launch_bounds__(DT)
+void lineal_vec_kernel(int n, int p, const double* __restrict__ A, const double* __restrict__ b,
+                       const double* __restrict__ shift, const double* __restrict__ sa, double* __restrict__ lv) {
+    const int j = blockIdx.x * (DT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= n) return;
+    double su = 0.0, as = 0.0;
+    for (int k = lane; k < p; k += 64) { const double a = A[(size_t)j * p + k]; su += a * shift[k]; as += a * sa[k]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { su += __shfl_down(su, o, 64); as += __shfl_down(as, o, 64); }
+    if (lane == 0) { lv[j] = su + b[j] - shift[p + j]; lv[n + j] = as; }
+}
+
+// tail of the moment buffer from T = S_aa A^T (p x n), B0 = A T (n x n), lv and the head
+__global__ void lineal_fix_kernel(MomLayout ml, const double* __restrict__ T, const double* __restrict__ B0,
+                                  const double* __restrict__ lv, const double* __restrict__ tail_src, double* __restrict__ mom) {
+    const int p = ml.p, n = ml.n;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const double N = mom[0];
+    const double* sa = mom + ml.sa();
+    const double* c = lv;
+    const double* As = lv + n;
+    if (idx < (long long)p * n) {
+        const int i = (int)(idx / n), j = (int)(idx % n);
+        mom[ml.Sab() + idx] = T[idx] + sa[i] * c[j];
+    }
+    if (idx < (long long)n * n) {
+        const int i = (int)(idx / n), j = (int)(idx % n);
+        mom[ml.Sbb() + idx] = B0[idx] + As[i] * c[j] + c[i] * As[j] + N * c[i] * c[j];
+    }
+    if (idx < n) mom[ml.sb() + idx] = As[idx] + N * c[idx];
+    if (idx == 0 && tail_src) { mom[ml.tail()] = tail_src[0]; mom[ml.tail() + 1] = tail_src[1]; }
+}
+
+static int gemm(Engine& e, hipStream_t s, int m, int n, int k, double alpha, const double* A, long long a0,
+                long long a1, const double* B, long long b0, long long b1, double* C);
+
+int launch_moments_lineal(Engine& e, double* mom, hipStream_t s) {
+    const int p = e.p, n = e.n;
+    int rc;
+    hipLaunchKernelGGL(lineal_vec_kernel, dim3((n + DT / 64 - 1) / (DT / 64)), dim3(DT), 0, s, n, p, e.d_A64, e.d_b64,
+                       e.d_shift64, mom + e.ml.sa(), e.d_lvec);
+    CESX_HIP(hipGetLastError());
+    // T = S_aa A^T (p x n);  B0 = A T (n x n)
+    if ((rc = gemm(e, s, p, n, p, 1.0, mom + e.ml.Saa(), p, 1, e.d_A64, 1, p, e.d_t1))) return rc;
+    if ((rc = gemm(e, s, n, n, p, 1.0, e.d_A64, p, 1, e.d_t1, n, 1, e.d_t2))) return rc;
+    const long long len = (long long)(p > n ? p : n) * n;
+    hipLaunchKernelGGL(lineal_fix_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s, e.ml, e.d_t1, e.d_t2, e.d_lvec,
+                       e.d_metric_sums, mom);
     CESX_HIP(hipGetLastError());
     return CESX_OK;
 }

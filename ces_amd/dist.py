@@ -189,6 +189,31 @@ class ShardedUpdate:
         self._mom = mom
         return mom
 
+    def lineal_fast_ok(self, model):
+        """The linear-map fast path applies: the model is ``ces_amd.utils.lineal`` with its device hook (the engine
+        evaluates G = A U + b itself), the engine has ``cesx_moments_rest_lineal``, and the ensemble is on one device
+        (CESX_LINEAL_FAST=0 switches it off)."""
+        return (getattr(model, "engine_lineal", False) and not getattr(model, "flag_noise", False)
+                and hasattr(self.engine, "moments_rest_lineal") and hasattr(self.engine, "moments_uu_chol")
+                and self.world == 1 and not self._force_collectives and not self.single_allreduce
+                and os.environ.get("CESX_LINEAL_FAST", "1") != "0")
+
+    def begin_lineal(self, prm, U, forward, noise_step=None):
+        """``begin`` for a linear forward map the engine evaluates itself: only the U x U Gram
+        runs; G = forward(U) is evaluated on the caller's stream BESIDE chol(C), and every G-dependent moment
+        follows from the U-only head (cesx_moments_rest_lineal: two small fp64 products instead of the second Gram
+        launch and its reduce -- 100 of the 136 blocks at p = n_obs = 256).  The centring shift must be valid (a
+        first step goes through ``begin`` with ``recenter``).  Returns (mom, G)."""
+        eng = self.engine
+        if noise_step is not None:
+            eng.prefetch_noise(noise_step)
+        mom = self._moment_buffer()
+        eng.moments_uu_chol(prm, U, U, out=mom)      # (the G argument is not read by the U x U launch)
+        G = forward(U)
+        eng.moments_rest_lineal(mom)
+        self._mom = mom
+        return mom, G
+
     def finish(self, prm, U, G, xi=None, out=None):
         """Second half: K2 with this step's parameters (t_last, time-step rule) and K3."""
         eng, mom = self.engine, self._mom
@@ -256,6 +281,7 @@ class ShardedSampler:
         # test, so the first half of step i+1 (forward map, moments, all-reduce, chol) is enqueued
         # before the result of step i is read; if the run stops there, that work is discarded.
         pipelined = hasattr(model, "forward_device")
+        fast = pipelined and self.sh.lineal_fast_ok(model)      # G's moments from U's (linear map on the device)
         prm0 = step_params(update=update, T=self.T)
         G = self._forward(model, U)
         draw = xis is None                     # on-device noise: drawn ahead of each update
@@ -272,8 +298,12 @@ class ShardedSampler:
             if pipelined:
                 U = self.sh.finish(prm, U, G, xi=xi)
                 if i + 1 < self.T:
-                    G = self._forward(model, U)
-                    self.sh.begin(prm0, U, G, noise_step=self._steps_done if draw else None)
+                    if fast:
+                        _, G = self.sh.begin_lineal(prm0, U, lambda u: self._forward(model, u),
+                                                    noise_step=self._steps_done if draw else None)
+                    else:
+                        G = self._forward(model, U)
+                        self.sh.begin(prm0, U, G, noise_step=self._steps_done if draw else None)
             else:
                 U = self.sh.step(prm, U, G, xi=xi, recenter=(i == 0))
             res = self.sh.result()

@@ -26,7 +26,7 @@ EXPORTS = ("cesx_abi_version", "cesx_create", "cesx_destroy", "cesx_last_error",
            "cesx_forward_lineal", "cesx_debug_dense", "cesx_profile_enable", "cesx_profile_read",
            "cesx_moments_uu_len", "cesx_moments_uu", "cesx_chol_async", "cesx_moments_rest", "cesx_side_stream",
            "cesx_prefetch_noise", "cesx_forward_set_lineal", "cesx_forward_apply", "cesx_moments_uu_chol", "cesx_moments_uu_handover", "cesx_debug_gram_plan",
-           "cesx_profile_clock", "cesx_calibrate_mfma", "cesx_profile_gap")
+           "cesx_profile_clock", "cesx_calibrate_mfma", "cesx_profile_gap", "cesx_moments_rest_lineal")
 
 
 class Config(C.Structure):
@@ -117,6 +117,7 @@ def load_library(path=None):
     lib.cesx_moments_uu_len.restype = C.c_size_t
     lib.cesx_moments_uu.argtypes = [vp, vp, vp, vp, vp]
     lib.cesx_moments_rest.argtypes = [vp, vp, vp, vp, vp]
+    lib.cesx_moments_rest_lineal.argtypes = [vp, vp, vp]
     lib.cesx_chol_async.argtypes = [vp, i32, vp, vp]
     lib.cesx_side_stream.argtypes = [vp]
     lib.cesx_side_stream.restype = vp
@@ -568,6 +569,12 @@ class Engine:
     def moments_rest(self, U, G, mom):
         with torch.cuda.device(self.device):
             self._check(self.lib.cesx_moments_rest(self._h, U.data_ptr(), G.data_ptr(), mom.data_ptr(), self._stream()))
+        return mom
+
+    def moments_rest_lineal(self, mom):
+        """The G part of the moments from the head of ``mom`` and the installed linear map (cesx_moments_rest_lineal)."""
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cesx_moments_rest_lineal(self._h, mom.data_ptr(), self._stream()))
         return mom
 
     def apply(self, prm, mom, U, G, xi=None, out=None):

@@ -14,6 +14,8 @@ class lineal(object):
     convention, one parameter vector per call as enka.G_ens uses it
     (ces/calibrate.py:123-130)."""
 
+    engine_lineal = True       # build-only: forward_device evaluates G = A U + b with the map installed in the engine
+
     def __init__(self, A, b=0, flag_noise=False):
         self.A = A
         self.b = b

@@ -205,6 +205,17 @@ int cesx_moments_uu_chol(cesx_handle h, int update, const void* U_dev, const voi
    U x U launch has the device to itself, the collective and chol(C) run beside the second launch. */
 int cesx_moments_uu_handover(cesx_handle h, const void* U_dev, const void* G_dev, double* mom_dev, void* stream);
 
+/* cesx_moments_rest for a LINEAR forward map (utils.lineal, ces/utils.py:25-31) installed with
+   cesx_forward_set_lineal, without a pass over G: with g_j = A u_j + b every G-dependent moment of
+   ces/calibrate.py:459-461 / :472 follows from the U-only head of the buffer (N, sum(u-s_u), S_aa) --
+   S_ab = S_aa A^T + sa c^T, S_bb = A S_aa A^T + (A sa) c^T + c (A sa)^T + N c c^T, sum(g-s_g) = A sa + N c with
+   c = A s_u + b - s_g -- two n x p x p fp64 products instead of the second Gram launch.  mom_dev must hold the
+   complete (summed over devices) head; the rest is written, the lagged data-metric sums included.  Valid when
+   the G_dev later passed to cesx_apply is what cesx_forward_apply produced from the same U_dev (K3 and the
+   per-particle data metrics still read that G).  The chained device-resident loops of ces_amd use it
+   (e2e only; the benchmark's timed step always runs the full Gram). */
+int cesx_moments_rest_lineal(cesx_handle h, double* mom_dev, void* stream);
+
 /* The engine's side stream (a hipStream_t).  A sharded driver issues the all-reduce of the
    leading part of the moment buffer on it (and then calls cesx_chol_async with it as
    `stream`), so that collective and chol(C) both run beside cesx_moments_rest without a third

@@ -751,3 +751,42 @@ def test_in_place_modified_ensemble_gets_a_fresh_centring_pass(eng_mod):
     ref = oc.factored_step(st, y, cast(U1), cast(A @ U1), Gamma, cast(xi1), update="aldi")
     assert rel_err(U2, ref) < TOL32
     assert eks.metrics["bias"][-1] == pytest.approx(st.metrics["bias"][-1], rel=TOL32)
+
+
+@pytest.mark.parametrize("shape,dtype,tol", [((20, 12, 1024, 6), "float64", 1e-10), ((64, 50, 4096, 6), "float64", 1e-10),
+                                             ((256, 256, 4096, 5), "float32", 2e-4), ((96, 160, 2048, 5), "float32", 2e-4)])
+def test_lineal_fast_path_matches_the_full_gram(eng_mod, monkeypatch, shape, dtype, tol):
+    """Chained device-resident loop with a linear forward map on the device: the G-dependent moments taken from the
+    U-only head and the installed map (cesx_moments_rest_lineal, no second Gram launch) against the same loop with
+    the full Gram over G (CESX_LINEAL_FAST=0), with an offset b and shapes that are not multiples of the MFMA tile;
+    the fp64 run is also held against the pinned oracle."""
+    from ces_amd.dist import ShardedSampler
+    from ces_amd.utils import lineal
+    from oracle import ces_numpy as oc
+    p, n, J, T = shape
+    rng = np.random.default_rng(21)
+    A = rng.standard_normal((n, p)) / np.sqrt(p)
+    b = 0.3 * rng.standard_normal(n)
+    ustar = rng.standard_normal((p, 1))
+    Gamma, sigma, mu = 0.01 * np.eye(n), 100.0 * np.eye(p), np.zeros((p, 1))
+    y = (A @ ustar).ravel() + b + 0.1 * rng.standard_normal(n)
+    U0 = ustar + rng.standard_normal((p, J))
+    xis = rng.standard_normal((T, p, J))
+    outs = []
+    for fast in ("1", "0"):
+        monkeypatch.setenv("CESX_LINEAL_FAST", fast)
+        eng = eng_mod.Engine(p, n, J, dtype=dtype, seed=4)
+        smp = ShardedSampler(eng, p, n, J)
+        smp.T = T
+        model = lineal(A, b)
+        assert smp.sh.lineal_fast_ok(model) == (fast == "1")
+        U = smp.run(y, U0, model, Gamma, mu, sigma, ustar, xis=xis, t_tol=1e9)
+        outs.append((U.cpu().numpy().astype(np.float64), {k: list(v) for k, v in smp.metrics.items()}))
+    assert rel_err(outs[0][0], outs[1][0]) < tol
+    for k in outs[0][1]:
+        assert np.allclose(outs[0][1][k], outs[1][1][k], rtol=max(tol, 1e-9) * 10), k
+    if dtype == "float64":
+        st = oc.OracleState(p, n, J, mu, sigma, ustar, T=T)
+        Uall, _ = oc.run_chain(st, y, U0, lambda U: A @ U + b[:, None], Gamma, xis, update="aldi", step=oc.factored_step, t_tol=1e9)
+        assert rel_err(outs[0][0], Uall[-1]) < TOL64
+        assert np.allclose(outs[0][1]["t"], st.metrics["t"], rtol=1e-8)

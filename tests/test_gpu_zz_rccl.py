@@ -123,6 +123,7 @@ def test_one_rank_rccl_sharded_sampler(rccl_one_rank, monkeypatch):
     p, n, J, T = 64, 50, 4096, 5
     d = _problem(p, n, J, seed=5)
     outs = []
+    monkeypatch.setenv("CESX_LINEAL_FAST", "0")        # (bit-identity of the collective path: both runs take the full Gram)
     for coll in (False, True):
         if coll:
             monkeypatch.setenv("CESX_FORCE_COLLECTIVES", "1")
