@@ -151,7 +151,9 @@ void gram2_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __r
         const int q = wave + G2_WAVES * i;
         const int rb = q < npieces ? q / NGROUP : 0, g = q % NGROUP;
         const int chunk = g * CP + (pch ^ ((prow / RPB) % CP));      // the swizzle (see the header)
-        gsrc[i] = rowptr[rb * TILE + prow] + t0 * KT + chunk * VEC;
+        // (G2_ABL & 16, timing only: every lane of a piece reads the block row's FIRST row -- one 128-byte line per
+        //  piece instead of 32: what the line transactions of the row-scattered pieces cost)
+        gsrc[i] = rowptr[rb * TILE + ((G2_ABL & 16) ? 0 : prow)] + t0 * KT + chunk * VEC;
         poff[i] = g * PANEL + rb * 1024;
     }
     auto issue_tile = [&](int slot) {

@@ -1,4 +1,4 @@
-"""Host forward models of the reference's model zoo.
+"""Host forward models with carried state, the Lorenz family.
 
 ``sampling.run`` drives two kinds of forward maps (ces/calibrate.py:342-353):
 ``type == 'map'`` (one call per particle, ces/utils.py:5-122) and ``type ==
@@ -7,9 +7,11 @@ observables: ces/calibrate.py:132-168 and ces/utils.py:124-455).  These are host
 code in the reference and stay host code here (BASELINE.json north_star); only
 the ensemble update runs on the GPU.  The classes keep the reference's names,
 attributes, call conventions and default arguments so that its notebooks
-(examples/notebooks/{elliptic,linear,lorenz63}.ipynb) run against
-``ces_amd.calibrate`` unchanged; the right-hand sides are written in
-vectorised numpy rather than per-variable Python loops.
+(examples/notebooks/{linear,lorenz63}.ipynb) run against ``ces_amd.calibrate``
+unchanged; the right-hand sides are written in vectorised numpy rather than
+per-variable Python loops.  ``lineal_log``, ``elliptic`` and ``banana`` of
+ces/utils.py are outside the hot-path scope and are
+not shipped.
 
 Parity: every class is checked against outputs of the reference's own
 ``ces/utils.py`` (it imports unmodified in the build container) stored in
@@ -18,79 +20,6 @@ tests/golden/models.npz by oracle/make_golden_models.py.
 import numpy as np
 
 from .utils import lineal
-
-
-class lineal_log(lineal):
-    """``A exp(phi)`` with the log-Jacobian helpers (ces/utils.py:33-51)."""
-
-    def __init__(self, A, flag_noise=False):
-        super().__init__(A, flag_noise=flag_noise)
-        self.model_name = "lineal_log"
-        self.jacobian_adjusted = True
-
-    def __call__(self, phi):
-        return super().__call__(np.exp(phi))
-
-    def grad_logjacobian(self, params):
-        return -np.exp(-params)
-
-    def logjacobian(self, params):
-        return -params.sum(axis=0) if self.jacobian_adjusted else 0.0
-
-
-class elliptic(object):
-    """Two point evaluations of the 1-D elliptic toy problem (ces/utils.py:53-89):
-    ``p(x) = u2 x + exp(-u1) (x - x^2) / 2`` at x = 1/4, 3/4; ``dG=True`` returns the
-    2 x 2 Jacobian."""
-
-    def __init__(self, flag_noise=False):
-        self.x1, self.x2 = 1.0 / 4, 3.0 / 4
-        self.flag_noise = flag_noise
-        self.sigma = np.sqrt(0.01)
-        self.model_name = "elliptic"
-        self.type = "map"
-
-    def __repr__(self):
-        return self.model_name
-
-    __str__ = __repr__
-
-    def _bump(self, x):
-        return (x - x ** 2) * 0.5
-
-    def __call__(self, theta, dG=False):
-        u1, u2 = theta
-        e = np.exp(-u1)
-        if dG:
-            return np.array([[-e * self._bump(self.x1), self.x1],
-                             [-e * self._bump(self.x2), self.x2]])
-        out = [u2 * self.x1 + e * self._bump(self.x1), u2 * self.x2 + e * self._bump(self.x2)]
-        if self.flag_noise:                       # the reference draws per component, in this order
-            out[0] = out[0] + self.sigma * np.random.normal(size=len(u1))
-            out[1] = out[1] + self.sigma * np.random.normal(size=len(u2))
-        return out
-
-
-class banana(object):
-    """Banana-shaped map ``(a u1, u2 / a - b (u1^2 + a^2))`` (ces/utils.py:91-122)."""
-
-    def __init__(self, a=1.0, b=.5, rho=.9, flag_noise=False):
-        self.flag_noise = flag_noise
-        self.sigma = np.sqrt(0.55)
-        self.model_name = "banana"
-        self.type = "map"
-        self.a, self.b = a, b
-        self.Gamma = (0.55 ** 2) * np.array([[1.0, rho], [rho, 1.0]])
-
-    def __repr__(self):
-        return self.model_name
-
-    __str__ = __repr__
-
-    def __call__(self, theta, dG=False):
-        u1, u2 = theta
-        out = np.array([u1 * self.a, u2 / self.a - self.b * (u1 ** 2 + self.a ** 2)])
-        return out + self.flag_noise * np.linalg.cholesky(self.Gamma).dot(np.random.normal(0, 1, [2, ]))
 
 
 class lorenz63(object):
