@@ -25,7 +25,12 @@ Build-only extras (not in the reference):
 build-only hook ``forward_device(engine, U_dev)`` (``ces_amd.utils.lineal`` does) and the noise does not
 have to come from numpy's global stream (``self.noise == 'device'`` or ``xis=`` given).  Per iteration
 nothing crosses PCIe but the step's scalars (and the trace, if kept).  Otherwise the reference's data flow
-is kept -- host forward map (``G_ens``), float64 numpy arrays into and out of every update.
+is kept -- host forward map (``G_ens``), float64 numpy arrays into and out of every update.  For LARGE
+ensembles with a host ``type == 'map'`` model and device noise that flow is software-pipelined over column
+blocks of the ensemble (``_run_host_pipelined``): ``G_ens`` evaluates the particles block by block (it is a
+per-particle loop in the reference, ces/calibrate.py:123-130, so the blocks give the same numbers) while the
+previous block's G crosses PCIe and the next block of the new ensemble arrives; the ensemble itself is not
+uploaded again (the device holds what it produced).  ``self.host_pipeline = False`` switches it off.
 """
 import multiprocessing
 import os
@@ -368,6 +373,161 @@ class sampling(enka):
         self.Gstar = Gfinal[:self.n_obs, :]
         self.Ustar_device, self.Gstar_device = U, G                # build-only: the final ensemble without the D2H copy
 
+    def _host_pipeline_ok(self, model, save_online, kwargs):
+        big = self.p * self.J >= (1 << 22)              # (small ensembles keep the reference's flow call for call)
+        return (big and getattr(model, "type", None) == "map" and not save_online
+                and getattr(self, "host_pipeline", True) and os.environ.get("CESX_HOST_PIPELINE", "1") != "0"
+                and (self.noise == "device" or kwargs.get("xis", None) is not None)
+                and kwargs.get("update", "aldi") in _engine.UPDATES
+                and kwargs.get("time_step", None) in _engine.TIME_STEPS and kwargs.get("time_step", None) != "adaptive")
+
+    def _run_host_pipelined(self, y_obs, U0, model, Gamma, trace, **kwargs):
+        """``run`` for a host ``type == 'map'`` model and a large ensemble (same iteration structure as
+        ces/calibrate.py:341-408), pipelined over NCH column blocks of the ensemble:
+
+            block c of U_{i+1} arrives (D2H + widening to float64)  ->  G_ens on that block (host)  ->
+            its G rows cross PCIe (cast to the engine dtype, H2D)   ...   update of the whole ensemble
+
+        A helper thread does the staging (widening the arriving blocks, casting and sending the G blocks:
+        cesx_copy2d_async, pinned buffers) while this thread evaluates the forward map, so the host forward map of
+        one block runs while the blocks around it are on the bus; the ensemble is never uploaded again -- the
+        device keeps U_{i+1} as it produced it (the host array is that tensor widened, the same numbers).
+        ``G_ens`` is the reference's per-particle loop (:123-130): evaluating it on column blocks gives what one
+        call on the whole ensemble gives."""
+        import queue
+        import threading
+        import torch
+        from .dist import ShardedUpdate
+        rule = kwargs.get("update", "aldi")
+        eng = self._get_engine()
+        eng.set_problem(y_obs, Gamma, self.mu, self.sigma, self.ustar)
+        sh = ShardedUpdate(eng)
+        self.update_rule = {"eks": "eks_update", "aldi": "eks_update_linear", "aldi_constant": "eks_update_aldi"}[rule]
+        xis = kwargs.get("xis", None)
+        p, n, J = self.p, self.n_obs, self.J
+        NCH = max(2, min(32, int(os.environ.get("CESX_HOST_PIPE_BLOCKS", getattr(self, "host_pipeline_blocks", 8)))))
+        cuts = [(J * c // NCH // 4 * 4, J * (c + 1) // NCH // 4 * 4 if c + 1 < NCH else J) for c in range(NCH)]
+        dev, tdt = eng.device, eng.torch_dtype
+        pin_g = eng._pinned("hp_g", (n, J))                                             # G blocks on their way up
+        pin_u = eng._pinned("hp_u", (p, J))                                             # U_{i+1} on its way down
+        if pin_u is None or pin_g is None:
+            raise MemoryError("no pinned host memory for the pipelined host loop (set host_pipeline = False)")
+        ev_u = [torch.cuda.Event() for _ in range(NCH)]
+        ev_g = torch.cuda.Event()
+        G_dev = [eng.empty(n), eng.empty(n)]
+        U_host = np.ascontiguousarray(np.asarray(U0, dtype=np.float64))
+        U_dev = eng.to_device(U_host, p, "U")
+        stream = torch.cuda.current_stream(dev)
+        raw_stream = int(stream.cuda_stream)
+        pool = eng._host_pool()
+
+        # the staging thread: tasks in FIFO order; an exception is handed back to this thread
+        tasks, failure = queue.Queue(), []
+
+        def stager():
+            torch.cuda.set_device(dev)
+            while True:
+                job = tasks.get()
+                if job is None:
+                    return
+                try:
+                    kind, c, arr, done, extra = job
+                    a, b = cuts[c]
+                    if kind == "down":               # block c of the new ensemble: wait for its D2H, widen it
+                        ev_u[c].synchronize()
+                        with eng._HostThreads(eng.copy_threads):
+                            torch.from_numpy(arr)[:, a:b].copy_(pin_u[:, a:b])
+                    else:                            # block c of G: cast into pinned memory, send it up
+                        with eng._HostThreads(eng.copy_threads):
+                            pin_g[:, a:b].copy_(torch.from_numpy(np.asarray(arr)))
+                        eng.copy_cols_async(extra, pin_g, a, b, True, stream=raw_stream)
+                except BaseException as ex:          # noqa: B036 -- reported by the driving thread
+                    failure.append(ex)
+                finally:
+                    done.set()
+        th = threading.Thread(target=stager, daemon=True, name="cesx-hoststage")
+        th.start()
+
+        import time as _time
+        tm = self._pipe_times = {}                   # seconds this thread spent waiting / outside the forward map (diagnostics)
+
+        def wait(evt, what="wait"):
+            t0 = _time.perf_counter()
+            evt.wait()
+            tm[what] = tm.get(what, 0.0) + _time.perf_counter() - t0
+            if failure:
+                raise failure[0]
+        try:
+            down = None                              # per-block events of the ensemble on its way down
+            for i in range(self.T):
+                Gd = G_dev[i % 2]
+                G_host = pool.get((n, J)) if trace else None
+                ups = []
+                for c, (a, b) in enumerate(cuts):
+                    if down is not None:
+                        wait(down[c], "down%d" % min(c, 1))    # block c of U_host is complete
+                    Gc = np.asarray(self.G_ens(U_host[:, a:b], model))[:n, :]
+                    if trace:
+                        G_host[:, a:b] = Gc
+                    if c == 0:
+                        ev_g.synchronize()           # (the previous iteration's H2Ds have left the pinned G buffer)
+                    done = threading.Event()
+                    tasks.put(("up", c, Gc, done, Gd))
+                    ups.append(done)
+                    del Gc
+                for d in ups:
+                    wait(d, "up")                    # every G block is cast and its H2D is enqueued on the stream
+                ev_g.record(stream)
+                down = None
+                if trace:                                                  # :356-358
+                    self.Uall.append(U_host)
+                    self.Gall.append(G_host)
+                t = self.metrics["t"]
+                prm = _engine.step_params(update=rule, time_step=kwargs.get("time_step", None),
+                                          first_step=self._is_first_step(), t_len=len(t), t_last=t[-1] if t else 0.0,
+                                          delta_t=kwargs.get("delta_t", None), spinup=kwargs.get("spinup", 4.0),
+                                          switch=kwargs.get("switch", 1.0), step_index=self._step_counter, T=self.T)
+                self._step_counter += 1
+                xi = None if xis is None else eng.to_device(xis[i], p, "xi")
+                U_new = sh.step(prm, U_dev, Gd, xi=xi, recenter=(i == 0))
+                # the new ensemble starts its way down block by block behind the update kernel; the staging thread
+                # widens the blocks as they land, the next iteration's forward map picks them up in order
+                U_prev_host = U_host
+                U_host = pool.get((p, J))
+                down = []
+                for c, (a, b) in enumerate(cuts):
+                    eng.copy_cols_async(pin_u, U_new, a, b, False, stream=raw_stream)
+                    ev_u[c].record(stream)
+                    done = threading.Event()
+                    tasks.put(("down", c, U_host, done, None))
+                    down.append(done)
+                t0 = _time.perf_counter()
+                res = sh.result()
+                tm["result"] = tm.get("result", 0.0) + _time.perf_counter() - t0
+                self._append_result(rule, res, kwargs)
+                U_dev = U_new
+                if not trace and i > 0:
+                    eng.discard_host(U_prev_host)    # (iteration 0's array is the caller's U0)
+                del U_prev_host
+                if self.metrics["t"][-1] > kwargs.get("t_tol", 2.0):       # :387-388
+                    break
+            if down is not None:
+                for d in down:
+                    wait(d)
+        finally:
+            tasks.put(None)
+            th.join(timeout=30.0)
+            torch.cuda.current_stream(dev).synchronize()
+        Geval = self.G_ens(U_host, model)                              # :390-398 the final ensemble, one call
+        if trace:                                                      # :400-405
+            self.Uall.append(U_host)
+            self.Gall.append(Geval)
+            self.Uall = np.asarray(self.Uall)
+            self.Gall = np.array(self.Gall)
+        self.Ustar = U_host
+        self.Gstar = Geval[:self.n_obs, :]
+        self._last_Uk, self._last_engine, self._last_sample = U_host, eng, self._sample(U_host)
+
     def run(self, y_obs, U0, model, Gamma, Jnoise, save_online=False, trace=True, **kwargs):
         """Driver loop, ces/calibrate.py:270-416."""
         getattr(model, "type")                                     # :294-297
@@ -394,6 +554,12 @@ class sampling(enka):
         if self._device_loop_ok(model, save_online, kwargs):
             self._get_engine()                                     # (creates self._step_counter)
             self._run_device(y_obs, U0, model, Gamma, trace, **kwargs)
+            tail = "-" + str(self.nexp).zfill(2) if hasattr(self, "nexp") else ""
+            self.online_path = self.directory + "/ensembles/" + model.model_name + "-" + str(self.J).zfill(4) + tail + "/"
+            return
+        if self._host_pipeline_ok(model, save_online, kwargs) and isinstance(U0, np.ndarray):
+            self._get_engine()
+            self._run_host_pipelined(y_obs, U0, model, Gamma, trace, **kwargs)
             tail = "-" + str(self.nexp).zfill(2) if hasattr(self, "nexp") else ""
             self.online_path = self.directory + "/ensembles/" + model.model_name + "-" + str(self.J).zfill(4) + tail + "/"
             return

@@ -26,7 +26,7 @@ EXPORTS = ("cesx_abi_version", "cesx_create", "cesx_destroy", "cesx_last_error",
            "cesx_forward_lineal", "cesx_debug_dense", "cesx_profile_enable", "cesx_profile_read",
            "cesx_moments_uu_len", "cesx_moments_uu", "cesx_chol_async", "cesx_moments_rest", "cesx_side_stream",
            "cesx_prefetch_noise", "cesx_forward_set_lineal", "cesx_forward_apply", "cesx_moments_uu_chol", "cesx_moments_uu_handover", "cesx_debug_gram_plan",
-           "cesx_profile_clock", "cesx_calibrate_mfma", "cesx_profile_gap", "cesx_moments_rest_lineal")
+           "cesx_profile_clock", "cesx_calibrate_mfma", "cesx_profile_gap", "cesx_moments_rest_lineal", "cesx_copy2d_async")
 
 
 class Config(C.Structure):
@@ -84,7 +84,10 @@ def default_copy_threads():
     a cgroup CPU quota the two pools TOGETHER must stay within the quota, or the kernel throttles the whole process
     for the rest of the 100-ms period -- 40-50 ms stalls in whatever phase runs next (round 3, tools/hostloop_probe.py:
     16 BLAS + 16 copy threads on a 16-core share: every period throttled, 30.7 ms per iteration; 12 + 4: none, 18.5).
-    A quarter of the share, at least 2, at most 8."""
+    A quarter of the share, at least 2, at most 8 (CESX_COPY_THREADS overrides)."""
+    env = os.environ.get("CESX_COPY_THREADS")
+    if env:
+        return max(1, int(env))
     return max(2, min(8, cpu_share() // 4))
 
 
@@ -137,6 +140,7 @@ def load_library(path=None):
     lib.cesx_profile_read.argtypes = [vp, i32, dp, C.POINTER(C.c_int)]
     lib.cesx_profile_clock.argtypes = [vp, dp]
     lib.cesx_profile_gap.argtypes = [vp, dp]
+    lib.cesx_copy2d_async.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_size_t, i32, vp]
     lib.cesx_calibrate_mfma.argtypes = [vp, C.c_double, dp, dp, vp]
     if lib.cesx_abi_version() != ABI_VERSION:
         raise ImportError("libcesx.so ABI %d != binding ABI %d" % (lib.cesx_abi_version(), ABI_VERSION))
@@ -471,6 +475,17 @@ class Engine:
     def discard_host(self, *arrays):
         """Hand large host arrays the caller no longer needs to the helper thread for release."""
         self._host_pool().discard([a for a in arrays if isinstance(a, np.ndarray) and a.nbytes >= (1 << 22)])
+
+    def copy_cols_async(self, dst, src, a, b, to_device, stream=None):
+        """Columns [a, b) of a row-major 2-D tensor between a PINNED host tensor and a device tensor of the same shape,
+        asynchronously on ``stream`` (cesx_copy2d_async; torch's own non_blocking copy of a strided block blocks the
+        host for the whole transfer)."""
+        esz = dst.element_size()
+        rows = int(dst.shape[0])
+        st = self._stream() if stream is None else C.c_void_p(stream)
+        self._check(self.lib.cesx_copy2d_async(self._h, dst.data_ptr() + a * esz, int(dst.stride(0)) * esz,
+                                               src.data_ptr() + a * esz, int(src.stride(0)) * esz,
+                                               (b - a) * esz, rows, int(bool(to_device)), st))
 
     def empty(self, rows):
         return torch.empty((rows, self.J), dtype=self.torch_dtype, device=self.device)

@@ -790,3 +790,46 @@ def test_lineal_fast_path_matches_the_full_gram(eng_mod, monkeypatch, shape, dty
         Uall, _ = oc.run_chain(st, y, U0, lambda U: A @ U + b[:, None], Gamma, xis, update="aldi", step=oc.factored_step, t_tol=1e9)
         assert rel_err(outs[0][0], Uall[-1]) < TOL64
         assert np.allclose(outs[0][1]["t"], st.metrics["t"], rtol=1e-8)
+
+
+@pytest.mark.parametrize("update,dtype,trace", [("aldi", "float32", False), ("aldi", "float64", True), ("eks", "float32", True),
+                                                ("aldi_constant", "float32", False)])
+def test_pipelined_host_loop_equals_the_plain_host_loop(eng_mod, update, dtype, trace):
+    """``sampling.run`` with a HOST forward map on a large ensemble: the loop pipelined over column blocks
+    (G_ens block by block, G up while the next block is evaluated, the ensemble never uploaded again) gives the
+    same bits as the reference's flow (one G_ens call, float64 arrays into and out of every update)."""
+    from ces_amd.calibrate import sampling
+    p, n, J, T = 256, 200, 16388, 4                      # p J >= 2^22 (the pipelined loop's threshold), ragged blocks
+    rng = np.random.default_rng(8)
+    A = rng.standard_normal((n, p)) / np.sqrt(p)
+    ustar = rng.standard_normal((p, 1))
+    Gamma, sigma, mu = 0.01 * np.eye(n), 100.0 * np.eye(p), np.zeros((p, 1))
+    y = (A @ ustar).ravel() + 0.1 * rng.standard_normal(n)
+    U0 = ustar + rng.standard_normal((p, J))
+
+    class host_model:
+        type, model_name, n_obs = "map", "lineal", n
+
+        def __call__(self, theta):
+            return A @ theta + 0.05 * np.tanh(theta[:n])          # mildly nonlinear, per particle
+    outs = []
+    for pipe in (True, False):
+        eks = sampling(p=p, n_obs=n, J=J)
+        eks.mu, eks.sigma, eks.ustar = mu, sigma, ustar
+        eks.engine_dtype, eks.noise, eks.T, eks.seed = dtype, "device", T, 5
+        eks.host_pipeline = pipe
+        calls = []
+        g_ens = eks.G_ens
+
+        def counted(theta, m, g_ens=g_ens, calls=calls):
+            calls.append(theta.shape[1])
+            return A @ theta + 0.05 * np.tanh(theta[:n])        # (= m(theta[:, j]) for every particle j)
+        eks.G_ens = counted
+        eks.run(y, U0.copy(), host_model(), Gamma, None, trace=trace, update=update, t_tol=1e30)
+        assert (len(calls) == 8 * T + 1) == pipe and sum(calls) == (T + 1) * J
+        outs.append((eks.Ustar.copy(), eks.Gstar.copy(), {k: list(v) for k, v in eks.metrics.items()},
+                     np.array(eks.Uall) if trace else None, np.array(eks.Gall) if trace else None))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert outs[0][2] == outs[1][2]
+    if trace:
+        assert np.array_equal(outs[0][3], outs[1][3]) and np.array_equal(outs[0][4], outs[1][4])
