@@ -389,7 +389,7 @@ class sampling(enka):
             its G rows cross PCIe (cast to the engine dtype, H2D)   ...   update of the whole ensemble
 
         A helper thread does the staging (widening the arriving blocks, casting and sending the G blocks:
-        cesx_copy2d_async, pinned buffers) while this thread evaluates the forward map, so the host forward map of
+        cesx_copy_cols_async, pinned buffers) while this thread evaluates the forward map, so the host forward map of
         one block runs while the blocks around it are on the bus; the ensemble is never uploaded again -- the
         device keeps U_{i+1} as it produced it (the host array is that tensor widened, the same numbers).
         ``G_ens`` is the reference's per-particle loop (:123-130): evaluating it on column blocks gives what one

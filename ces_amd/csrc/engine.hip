@@ -781,12 +781,12 @@ int cesx_profile_read(cesx_handle h, int which, double* total_ms, int* launches)
     return CESX_OK;
 }
 
-int cesx_copy2d_async(cesx_handle h, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes,
+int cesx_copy_cols_async(cesx_handle h, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes,
                       size_t height, int to_device, void* stream) {
     if (!h) return CESX_EINVAL;
     Engine& e = *reinterpret_cast<Engine*>(h);
     if (!dst || !src || width_bytes == 0 || height == 0 || dpitch < width_bytes || spitch < width_bytes) {
-        e.err = "cesx_copy2d_async: bad argument";
+        e.err = "cesx_copy_cols_async: bad argument";
         return CESX_EINVAL;
     }
     SET_DEVICE(e);

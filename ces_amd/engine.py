@@ -26,7 +26,7 @@ EXPORTS = ("cesx_abi_version", "cesx_create", "cesx_destroy", "cesx_last_error",
            "cesx_forward_lineal", "cesx_debug_dense", "cesx_profile_enable", "cesx_profile_read",
            "cesx_moments_uu_len", "cesx_moments_uu", "cesx_chol_async", "cesx_moments_rest", "cesx_side_stream",
            "cesx_prefetch_noise", "cesx_forward_set_lineal", "cesx_forward_apply", "cesx_moments_uu_chol", "cesx_moments_uu_handover", "cesx_debug_gram_plan",
-           "cesx_profile_clock", "cesx_calibrate_mfma", "cesx_profile_gap", "cesx_moments_rest_lineal", "cesx_copy2d_async")
+           "cesx_profile_clock", "cesx_calibrate_mfma", "cesx_profile_gap", "cesx_moments_rest_lineal", "cesx_copy_cols_async")
 
 
 class Config(C.Structure):
@@ -140,7 +140,7 @@ def load_library(path=None):
     lib.cesx_profile_read.argtypes = [vp, i32, dp, C.POINTER(C.c_int)]
     lib.cesx_profile_clock.argtypes = [vp, dp]
     lib.cesx_profile_gap.argtypes = [vp, dp]
-    lib.cesx_copy2d_async.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_size_t, i32, vp]
+    lib.cesx_copy_cols_async.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_size_t, i32, vp]
     lib.cesx_calibrate_mfma.argtypes = [vp, C.c_double, dp, dp, vp]
     if lib.cesx_abi_version() != ABI_VERSION:
         raise ImportError("libcesx.so ABI %d != binding ABI %d" % (lib.cesx_abi_version(), ABI_VERSION))
@@ -478,12 +478,12 @@ class Engine:
 
     def copy_cols_async(self, dst, src, a, b, to_device, stream=None):
         """Columns [a, b) of a row-major 2-D tensor between a PINNED host tensor and a device tensor of the same shape,
-        asynchronously on ``stream`` (cesx_copy2d_async; torch's own non_blocking copy of a strided block blocks the
+        asynchronously on ``stream`` (cesx_copy_cols_async; torch's own non_blocking copy of a strided block blocks the
         host for the whole transfer)."""
         esz = dst.element_size()
         rows = int(dst.shape[0])
         st = self._stream() if stream is None else C.c_void_p(stream)
-        self._check(self.lib.cesx_copy2d_async(self._h, dst.data_ptr() + a * esz, int(dst.stride(0)) * esz,
+        self._check(self.lib.cesx_copy_cols_async(self._h, dst.data_ptr() + a * esz, int(dst.stride(0)) * esz,
                                                src.data_ptr() + a * esz, int(src.stride(0)) * esz,
                                                (b - a) * esz, rows, int(bool(to_device)), st))
 

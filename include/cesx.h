@@ -280,7 +280,7 @@ int cesx_forward_apply(cesx_handle h, const void* U_dev, void* G_dev, void* stre
    `stream` (hipMemcpy2DAsync; pitches and width in bytes, `height` rows, to_device != 0: host -> device).  The
    drop-in class pipelines the reference's host data flow (ces/calibrate.py:341-369: G_ens on the host, arrays into
    and out of every update) over such blocks: particles are independent in G_ens (:123-130), rows are not. */
-int cesx_copy2d_async(cesx_handle h, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes,
+int cesx_copy_cols_async(cesx_handle h, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes,
                       size_t height, int to_device, void* stream);
 
 /* ---- introspection ---------------------------------------------------- */
