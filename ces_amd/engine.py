@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcesx.so")
+LIB_PATH = os.environ.get("CESX_LIB") or os.path.join(_HERE, "libcesx.so")      # (CESX_LIB: a dev build of the same ABI)
 
 OK, EINVAL, ENOTPD, EHIP, ESTATE, EUNSUPPORTED, ENOCONV = 0, 1, 2, 3, 4, 5, 6
 F32, F64 = 0, 1
