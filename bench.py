@@ -517,19 +517,22 @@ def main():
     # longer (0.56 against 0.45 ms; the event records serialise the side stream's Cholesky behind the Gram launch).
     # The sampled step is inside the timed region, so exactly ONE step of the region -- the middle one -- is
     # sampled; `roofline.profiled_steps` says so, the rocprofv3 kernel stats under profiles/ are the cross-check.
-    prof = dict(on=False, steps=0, at=-1)
+    prof = dict(on=False, steps=0, at=-1, gap_at=-2)
+
+    def prof_mode(i):           # the sampled step: start + stop events on K1 / K3; a second one: the gap's two events only
+        return True if i == prof["at"] else 2 if i == prof["gap_at"] else False
 
     def begin(i):
         U, G = batches[i % NB]
         if prof["on"]:
-            eng.profile_enable(i == prof["at"])
+            eng.profile_enable(prof_mode(i))
             sh.sample_collectives = i == prof["at"]      # (sharded runs: event pairs around the step's all-reduces)
         sh.begin(prm0, U, G, recenter=(i == 0), noise_step=i)
 
     def finish(i):
         U, G = batches[i % NB]
         if prof["on"]:
-            eng.profile_enable(i == prof["at"])
+            eng.profile_enable(prof_mode(i))
             sh.sample_collectives = i == prof["at"]
             prof["steps"] += int(i == prof["at"])
         prm = engine.step_params(update=args.update, first_step=(i == 0), t_len=min(i, 1), t_last=t_hist[0],
@@ -573,6 +576,7 @@ def main():
         # the first window carries one HIP-event-sampled step (thrown away): whatever the runtime sets up on the
         # first time-stamped launch of a queue happens here
         prof["at"] = 8 if (prewarm == 0 and prof["on"]) else -1
+        prof["gap_at"] = 12 if (prewarm == 0 and prof["on"]) else -2
         tb = time.perf_counter()
         run_steps(0, WIN)
         torch.cuda.synchronize()
@@ -594,7 +598,7 @@ def main():
     prewarm_s = time.perf_counter() - t_pre
     sclk_before = sysfs_sclk()
     t_hist[0] = 0.0
-    prof["at"] = -1
+    prof["at"], prof["gap_at"] = -1, -2
     run_steps(0, 64)                            # (the reads above idled the GPU for a moment: back to work first)
     if args.warmup:
         run_steps(0, args.warmup)
@@ -604,6 +608,7 @@ def main():
     # exactly ONE step of the timed region -- the middle one -- is HIP-event sampled (`roofline.profiled_steps`)
     prof["steps"] = 0
     prof["at"] = args.warmup + args.steps // 2
+    prof["gap_at"] = prof["at"] + 3 if args.steps >= 8 else -2      # (its events come last: cesx_profile_gap reads the newest)
     del stamps[:]
     t0 = time.perf_counter()
     res = run_steps(args.warmup, args.steps)
@@ -745,7 +750,8 @@ def main():
                                                   "single" if sh.single_allreduce else "head+tail"),
                                  collectives_per_step=(0 if world == 1 and not rehearse else 1 if sh.single_allreduce else 2),
                                  collective_ms={k: dict(doubles=v[0], ms=round(v[1], 4)) for k, v in coll_ms.items()},
-                                 how="HIP events: kernel-bound stop of the second Gram launch -> kernel-bound start of K3; "
+                                 how="HIP events of a step of their own (3 after the sampled one, nothing else time-stamped in "
+                                     "it): kernel-bound stop of the second Gram launch -> kernel-bound start of K3; "
                                      "a recorded event pair around each all-reduce on the stream that issues it (the pair "
                                      "itself adds a few us to the sampled step)"))
     if world == 1 and not rehearse and not args.no_extras:

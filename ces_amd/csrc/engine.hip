@@ -363,7 +363,7 @@ void cesx_destroy(cesx_handle h) {
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     for (int w = 0; w < 2; ++w)
-        for (auto& pr : e.prof_ev[w]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+        for (auto& pr : e.prof_ev[w]) { if (pr.first) (void)hipEventDestroy(pr.first); if (pr.second) (void)hipEventDestroy(pr.second); }
     for (auto ev : e.prof_pool) (void)hipEventDestroy(ev);
     if (e.h_scal) (void)hipHostFree(e.h_scal);
     if (e.ev_a) (void)hipEventDestroy(e.ev_a);
@@ -748,6 +748,7 @@ int cesx_profile_enable(cesx_handle h, int on) {
     if (!h) return CESX_EINVAL;
     Engine& e = *reinterpret_cast<Engine*>(h);
     e.profile = on != 0;
+    e.profile_gap_only = on == 2;
     if (e.profile) {
         SET_DEVICE(e);
         while (e.prof_pool.size() < 512) {        // created up front: no event creation in a timed region
@@ -767,13 +768,15 @@ int cesx_profile_read(cesx_handle h, int which, double* total_ms, int* launches)
     double tot = 0.0;
     int cnt = 0;
     for (auto& pr : e.prof_ev[which]) {
-        CESX_HIP(hipEventSynchronize(pr.second));
         float ms = 0.f;
-        CESX_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
-        tot += ms;
-        ++cnt;
-        e.prof_pool.push_back(pr.first);
-        e.prof_pool.push_back(pr.second);
+        if (pr.first && pr.second) {               // (a pair of a gap-only step has one event only: recycled, not counted)
+            CESX_HIP(hipEventSynchronize(pr.second));
+            CESX_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+            tot += ms;
+            ++cnt;
+        }
+        if (pr.first) e.prof_pool.push_back(pr.first);
+        if (pr.second) e.prof_pool.push_back(pr.second);
     }
     e.prof_ev[which].clear();
     *total_ms = tot;
@@ -803,7 +806,8 @@ int cesx_profile_gap(cesx_handle h, double* gap_ms) {
     if (e.prof_ev[0].empty() || e.prof_ev[1].empty()) return CESX_OK;
     SET_DEVICE(e);
     hipEvent_t gram_end = e.prof_ev[0].back().second, upd_start = e.prof_ev[1].back().first;
-    CESX_HIP(hipEventSynchronize(e.prof_ev[1].back().second));
+    if (!gram_end || !upd_start) return CESX_OK;
+    CESX_HIP(hipEventSynchronize(upd_start));
     float ms = 0.f;
     CESX_HIP(hipEventElapsedTime(&ms, gram_end, upd_start));
     *gap_ms = ms;

@@ -351,8 +351,8 @@ static int launch_gram2_t(Engine& e, int part, const void* U, const void* G, hip
     auto kern = gram2_kernel<T>;
     CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     {
-        ProfScope prof(e, 0, s, true);
-        if (prof.a)
+        ProfScope prof(e, (e.profile_gap_only && part == 0) ? -1 : 0, s, true);      // (gap-only: the second launch's stop, nothing else)
+        if (prof.on())
             hipExtLaunchKernelGGL(kern, dim3(pl.total_wgs), dim3(G2_THREADS), (unsigned)lds, s, prof.a, prof.b, 0,
                                   (const T*)U, (const T*)G, (const T*)e.d_shiftT, e.p, e.n, (long long)e.J,
                                   (const int*)gp.d_type_hdr, pl.ntypes, (const int*)gp.d_rows, (const int*)gp.d_wblk,

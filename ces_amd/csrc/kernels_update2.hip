@@ -540,8 +540,8 @@ int launch_update2(Engine& e, int out_rows, const void* Wf, int ktot, const void
     e.last_update_grid = (int)(grid.x * grid.y);
     {
         ProfScope prof(e, opt.prof, s, true);
-        a.clk = prof.a ? e.d_clk : nullptr;
-        if (prof.a) hipExtLaunchKernelGGL(kern, grid, dim3(U2_THREADS), (unsigned)lds, s, prof.a, prof.b, 0, a);
+        a.clk = (prof.a && prof.b) ? e.d_clk : nullptr;
+        if (prof.on()) hipExtLaunchKernelGGL(kern, grid, dim3(U2_THREADS), (unsigned)lds, s, prof.a, prof.b, 0, a);
         else hipLaunchKernelGGL(kern, grid, dim3(U2_THREADS), lds, s, a);
     }
     CESX_HIP(hipGetLastError());

@@ -302,8 +302,8 @@ int launch_update3(Engine& e, int out_rows, const void* Wd, int ktot, const void
     e.last_update_grid = (int)(grid.x * grid.y);
     {
         ProfScope prof(e, opt.prof, s, true);
-        a.clk = prof.a ? e.d_clk : nullptr;
-        if (prof.a) hipExtLaunchKernelGGL(update3_kernel, grid, dim3(U3_THREADS), (unsigned)lds, s, prof.a, prof.b, 0, a);
+        a.clk = (prof.a && prof.b) ? e.d_clk : nullptr;
+        if (prof.on()) hipExtLaunchKernelGGL(update3_kernel, grid, dim3(U3_THREADS), (unsigned)lds, s, prof.a, prof.b, 0, a);
         else hipLaunchKernelGGL(update3_kernel, grid, dim3(U3_THREADS), lds, s, a);
     }
     CESX_HIP(hipGetLastError());

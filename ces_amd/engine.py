@@ -660,7 +660,8 @@ class Engine:
         return out
 
     def profile_enable(self, on=True):
-        self._check(self.lib.cesx_profile_enable(self._h, int(bool(on))))
+        """on: False / True, or 2 = bind only the events cesx_profile_gap needs."""
+        self._check(self.lib.cesx_profile_enable(self._h, 2 if on == 2 and on is not True else int(bool(on))))
 
     def profile_read(self, which):
         """(total ms, launches) of kernel 0 = Gram (K1) or 1 = update (K3) since the last read."""
