@@ -435,16 +435,19 @@ class sampling(enka):
                     a, b = cuts[c]
                     if kind == "down":               # block c of the new ensemble: wait for its D2H, widen it
                         ev_u[c].synchronize()
-                        with eng._HostThreads(eng.copy_threads):
-                            torch.from_numpy(arr)[:, a:b].copy_(pin_u[:, a:b])
+                        torch.from_numpy(arr)[:, a:b].copy_(pin_u[:, a:b])
                     else:                            # block c of G: cast into pinned memory, send it up
-                        with eng._HostThreads(eng.copy_threads):
-                            pin_g[:, a:b].copy_(torch.from_numpy(np.asarray(arr)))
+                        pin_g[:, a:b].copy_(torch.from_numpy(np.asarray(arr)))
                         eng.copy_cols_async(extra, pin_g, a, b, True, stream=raw_stream)
                 except BaseException as ex:          # noqa: B036 -- reported by the driving thread
                     failure.append(ex)
                 finally:
                     done.set()
+        # torch's intra-op pool serves the staging casts only while this loop runs: sized ONCE to the copy threads
+        # (resizing it around every block costs more than the casts)
+        old_threads = torch.get_num_threads()
+        if old_threads > eng.copy_threads:
+            torch.set_num_threads(eng.copy_threads)
         th = threading.Thread(target=stager, daemon=True, name="cesx-hoststage")
         th.start()
 
@@ -518,6 +521,8 @@ class sampling(enka):
             tasks.put(None)
             th.join(timeout=30.0)
             torch.cuda.current_stream(dev).synchronize()
+            if torch.get_num_threads() != old_threads:
+                torch.set_num_threads(old_threads)
         Geval = self.G_ens(U_host, model)                              # :390-398 the final ensemble, one call
         if trace:                                                      # :400-405
             self.Uall.append(U_host)
