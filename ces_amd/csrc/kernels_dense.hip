@@ -345,10 +345,7 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
             int i = R * 16 + lr + 4 * e, j = Cc * 16 + lc;
             double v = (i == j) ? 1.0 : 0.0;              // identity padding
             if (j > i) { const int t = i; i = j; j = t; } // diagonal tiles are kept fully symmetric
-            if (on && i < n) {
-                v = A[(size_t)i * lda + j];
-                if (cen_sa != nullptr) v = cov_entry(v, cen_sa[i], cen_sa[j], cinvN, cinvdiv, i == j, nullptr);
-            }
+            if (on && i < n) v = A[(size_t)i * lda + j];      // (cen_sa: the RAW second moment; centred below, from LDS)
             Pt[s][e] = v;
         }
     }
@@ -369,7 +366,26 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
             buf[off] = Pt[s][e];
         }
     };
-    __syncthreads();                                      // (the zero fill above)
+    // centring fused into the load: the row sums go through LDS (one global load per matrix entry instead of
+    // three: the dependent sa_i / sa_j loads made this one workgroup's load phase 20 us longer), the raw entries are
+    // already on their way into the tile registers
+    double* s_sa = PnT + 3 * QNB * LDT;                   // [np] (launched with NPMAX doubles more when cen_sa is set)
+    if (cen_sa != nullptr)
+        for (int i = threadIdx.x; i < n; i += PRT) s_sa[i] = cen_sa[i];
+    __syncthreads();                                      // (the zero fill above, the row sums)
+    if (cen_sa != nullptr) {
+#pragma clang loop unroll(full)
+        for (int s = 0; s < SLOTS; ++s) {
+            if (s < non) {
+#pragma clang loop unroll(full)
+                for (int e = 0; e < 4; ++e) {
+                    int i = TROW(s) * 16 + lr + 4 * e, j = TCOL(s) * 16 + lc;
+                    if (j > i) { const int t = i; i = j; j = t; }
+                    if (i < n) Pt[s][e] = cov_entry(Pt[s][e], s_sa[i], s_sa[j], cinvN, cinvdiv, i == j, nullptr);
+                }
+            }
+        }
+    }
 #pragma clang loop unroll(full)
     for (int s = 0; s < SLOTS; ++s)
         if (s < non && TCOL(s) == 0) publish(s, 0, PnT);
@@ -1032,7 +1048,7 @@ static int potrf_reg_launch(Engine& e, hipStream_t s, int n, int np, const doubl
                             hipEvent_t stop = nullptr,        // stop: event bound to this kernel's own completion signal
                             PotrfCen cen = PotrfCen()) {
     constexpr int NPMAX = SLOTS <= 2 ? 64 : SLOTS <= 5 ? 128 : SLOTS <= 10 ? 192 : 256;
-    const size_t lds = (size_t)3 * QNB * (2 * NPMAX + 4) * 8;      // panel x 2, its negative (each k-row behind NPMAX zeros)
+    const size_t lds = (size_t)3 * QNB * (2 * NPMAX + 4) * 8 + (cen.sa ? (size_t)NPMAX * 8 : 0);      // panel x 2, its negative (each k-row behind NPMAX zeros), the row sums of a fused centring
     CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_reg_kernel<SLOTS>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (stop)
