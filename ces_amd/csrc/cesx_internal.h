@@ -216,6 +216,10 @@ __device__ __forceinline__ void metric_final_body(const MetricFin& f) {
     __shared__ double mf_red[2][4];
     __shared__ double mf_out[4];
     constexpr int ND = offsetof(Scalars, seq) / 8;
+    // 256 threads do the work whatever the launch's block size is (the summation order is part of the result);
+    // the other waves of a larger block leave (a finished wave does not hold up the barriers below)
+    constexpr unsigned MF_THREADS = 256;
+    if (threadIdx.x >= MF_THREADS) return;
     // the scalars earlier kernels of the step wrote (hk, t, bias ...): read FIRST, beside the partial sums -- the
     // chain of dependent round trips of this one workgroup is what a launch that carries it waits for
     double mine = 0.0;
@@ -227,14 +231,14 @@ __device__ __forceinline__ void metric_final_body(const MetricFin& f) {
         if (!(Nm > 0.0)) Nm = f.mom[0];
     }
     double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < f.nparts; i += blockDim.x) { a += f.part[(size_t)i * 2]; b += f.part[(size_t)i * 2 + 1]; }
+    for (int i = threadIdx.x; i < f.nparts; i += MF_THREADS) { a += f.part[(size_t)i * 2]; b += f.part[(size_t)i * 2 + 1]; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b += __shfl_down(b, o, 64); }
     if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 4) { mf_red[0][threadIdx.x >> 6] = a; mf_red[1][threadIdx.x >> 6] = b; }
     __syncthreads();
     if (threadIdx.x == 0) {
         a = 0.0; b = 0.0;
-        for (int i = 0; i < (int)(blockDim.x >> 6) && i < 4; ++i) { a += mf_red[0][i]; b += mf_red[1][i]; }
+        for (int i = 0; i < (int)(MF_THREADS >> 6); ++i) { a += mf_red[0][i]; b += mf_red[1][i]; }
         const double N = Nm;
         f.sums[0] = a; f.sums[1] = b;
         mf_out[0] = f.sc->bias_data = a / N;

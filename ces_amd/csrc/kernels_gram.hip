@@ -267,9 +267,9 @@ void gram_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __re
 // handles RED_G 16-byte groups (4 f32 / 2 f64 along a block row) x RED_S slice
 // parts (each lane sums nslices / RED_S slices with up to 8 loads in flight);
 // the parts are combined through LDS in a fixed order.
-constexpr int RED_G = 32, RED_S = 8;
+constexpr int RED_G = 32, RED_S = 8;       // (16 / 32 slice parts, i.e. 512 / 1024 threads: +4 / +10 us per step at C2, round 3)
 template <typename T>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(RED_G * RED_S)
 void gram_reduce_kernel(const T* __restrict__ slabs, const int* __restrict__ blk_rc, const int* __restrict__ row_own,
                         int nblocks, int tile, MomLayout ml, long long J, int row_lo, int row_hi,
                         int write_N, const double* __restrict__ rowsum_part, const double* __restrict__ tail_src,
@@ -666,12 +666,12 @@ static int launch_gram_reduce_t(Engine& e, int part, double* mom, hipStream_t s,
     const long long wgs = (ngroups + RED_G - 1) / RED_G + std::max(1, (row_hi - row_lo + RED_G - 1) / RED_G) + (fin ? 1 : 0);
     const MetricFin f = fin ? *fin : MetricFin{};
     if (stop)
-        hipExtLaunchKernelGGL(gram_reduce_kernel<T>, dim3((unsigned)wgs), dim3(256), 0, s, nullptr, stop, 0,
+        hipExtLaunchKernelGGL(gram_reduce_kernel<T>, dim3((unsigned)wgs), dim3(RED_G * RED_S), 0, s, nullptr, stop, 0,
                               (const T*)gp.d_slabs, (const int*)gp.d_blk_rc, (const int*)gp.d_row_own, pl.nblocks, pl.tile, e.ml,
                               (long long)e.J, row_lo, row_hi, part == 0 ? 1 : 0, (const double*)gp.d_rowsum_part,
                               part == 1 ? (const double*)e.d_metric_sums : (const double*)nullptr, mom, f);
     else
-    hipLaunchKernelGGL(gram_reduce_kernel<T>, dim3((unsigned)wgs), dim3(256), 0, s,
+    hipLaunchKernelGGL(gram_reduce_kernel<T>, dim3((unsigned)wgs), dim3(RED_G * RED_S), 0, s,
                        (const T*)gp.d_slabs, gp.d_blk_rc, gp.d_row_own, pl.nblocks, pl.tile, e.ml,
                        (long long)e.J, row_lo, row_hi, part == 0 ? 1 : 0, gp.d_rowsum_part,
                        part == 1 ? e.d_metric_sums : (const double*)nullptr, mom, f);
