@@ -393,6 +393,9 @@ void update2_kernel(const Upd2Args a) {
     // the last iteration's barrier had nothing in flight; one more so that the ring can be reused
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
+#ifdef U2_CLOCKS
+    const long long clk_ep0 = clock64();
+#endif
     // epilogue: lane holds, for row (e&3) + 8 (e>>2) + 4 lh of each of its blocks, particles 4 li .. 4 li + 3
     const double c1 = a.add1 ? (a.c1p ? *a.c1p * a.c1i : a.c1i) : 0.0;
     const double c2 = a.add2 ? (a.c2p ? *a.c2p * a.c2i : a.c2i) : 0.0;
@@ -423,6 +426,11 @@ void update2_kernel(const Upd2Args a) {
             }
         }
     }
+#ifdef U2_CLOCKS
+    const long long clk_ep1 = clock64();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long clk_ep2 = clock64();
+#endif
     if (do_metrics) {
         // combine the 8 row groups of every particle through LDS (the ring is idle now)
         float* comb = reinterpret_cast<float*>(smem);            // [2][8][128]
@@ -479,6 +487,8 @@ void update2_kernel(const Upd2Args a) {
         a.metric_part[16384 + blockIdx.x * 2 + 1] = (double)(wclk0 % 100000);
         a.metric_part[24576 + blockIdx.x * 2 + 0] = (double)(clk_s1 - clk_loop0);
         a.metric_part[24576 + blockIdx.x * 2 + 1] = (double)(clk_s2 - clk_s1);
+        a.metric_part[32768 + blockIdx.x * 2 + 0] = (double)(clk_ep1 - clk_ep0);      // store issue
+        a.metric_part[32768 + blockIdx.x * 2 + 1] = (double)(clk_ep2 - clk_ep1);      // ... until the stores are acknowledged
     }
 #endif
 #undef U2_PIECE

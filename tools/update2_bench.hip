@@ -23,7 +23,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&U, (size_t)p * J * 4)); CK(hipMalloc(&G, (size_t)n * J * 4)); CK(hipMalloc(&X, (size_t)p * J * 4));
     CK(hipMalloc(&out, (size_t)p * J * 4)); CK(hipMalloc(&out2, (size_t)p * J * 4));
     CK(hipMalloc(&W, (size_t)rpad * ktot * 4)); CK(hipMalloc(&Wf, (size_t)rpad * ktot * 4)); CK(hipMalloc(&bias, rpad * 4));
-    CK(hipMalloc(&rowc, kn * 16)); CK(hipMalloc(&mpart, 8192 * 16)); CK(hipMalloc(&mpart2, 4 * 8192 * 16));
+    CK(hipMalloc(&rowc, kn * 16)); CK(hipMalloc(&mpart, 8192 * 16)); CK(hipMalloc(&mpart2, 6 * 8192 * 16));
     {
         std::vector<float> h((size_t)(p > n ? p : n) * J);
         for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) % 2001) / 1000.f - 1.f;
@@ -124,6 +124,10 @@ int main(int argc, char** argv) {
         printf("segments: U %.0f cycles, G %.0f cycles (the rest is xi)\n", g1 / grid.x, g2 / grid.x);
         CK(hipMemcpy(m3.data(), mpart2 + 8192, m3.size() * 8, hipMemcpyDeviceToHost));
         printf("wave 0: K loop %.0f cycles, of which waiting at the barrier %.0f (%.1f per tile)\n", lp / grid.x, bw / grid.x, bw / grid.x / nkt);
+        CK(hipMemcpy(m3.data(), mpart2 + 32768, m3.size() * 8, hipMemcpyDeviceToHost));
+        double e1 = 0, e2 = 0;
+        for (unsigned i = 0; i < grid.x; ++i) { e1 += m3[2 * i]; e2 += m3[2 * i + 1]; }
+        printf("wave 0 epilogue: store issue %.0f cycles, + %.0f until acknowledged\n", e1 / grid.x, e2 / grid.x);
     }
 #endif
     printf("update2: %.1f us/launch (%.1f TF algorithmic)\n", ms * 100.0, 2.0 * p * ktot * J / (ms * 1e-4) / 1e12);
