@@ -10,6 +10,7 @@
 // p, n are a few hundred: these kernels are latency bound, not roofline bound.
 #include "cesx_internal.h"
 #include <hip/hip_ext.h>
+#include <type_traits>
 
 namespace cesx {
 
@@ -150,6 +151,20 @@ void center_kernel(MomView mv, const double* __restrict__ shift, const double* _
             if (what & 1) { part[b * 4 + 0] = 0.0; part[b * 4 + 1] = 0.0; }
             if (what & 2) part[b * 4 + 2] = 0.0;
         }
+    // the U-only part runs on the side stream in front of chol(C), whose completion the caller's stream may take from a
+    // polled word instead of a queue-level wait (FrArgs::join): its results are written back at agent scope here
+    // (ONE write-back of the XCD's L2 per workgroup, behind its waves' acknowledged stores: 1024 threads each fencing
+    //  took the kernel from 13 to 23 us)
+    if (what & 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __threadfence();
+    }
+}
+
+// agent-scope (sc1) load of a double another stream's kernel wrote: coherent whatever the per-XCD L2 holds
+__device__ __forceinline__ double ld_agent(const double* ptr) {
+    return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // part[blk*4 + 2] = sum A .* B   (dense-Gamma Frobenius term)
@@ -288,7 +303,10 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
                       // kernel no longer sits in front of the factorisation on the side stream; the status word is
                       // reset here then
                       const double* __restrict__ cen_sa = nullptr, const double* __restrict__ cen_N = nullptr,
-                      int cen_unbiased = 0) {
+                      int cen_unbiased = 0,
+                      // done != nullptr: the factor (and the status word) written back at agent scope, then *done =
+                      // done_val with release semantics -- what the caller's stream polls instead of waiting for an event
+                      unsigned long long* done = nullptr, unsigned long long done_val = 0) {
     if (lda == 0) lda = n;
     if (ldl == 0) ldl = np;
     double cinvN = 1.0, cinvdiv = 1.0;
@@ -495,6 +513,11 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
     if (dbg && tid == 0)
         for (int i = 0; i < 5; ++i) dbg[i] = tph[i];
 #undef PH
+    if (done != nullptr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave's stores of L acknowledged, then one release (L2 write-back)
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(done, done_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // X = a * A + B with a = (*ap) / (*divp)  (both on device; divp may be null)
@@ -849,41 +872,74 @@ __global__ void assemble_kernel(int mode, int p, int n, int kp, int kn, int rpad
 // M_i . ubar -> bias_i and the next centring shift.  Same arithmetic, in the same order, as scalar_kernel +
 // assemble_kernel<T>(mode 0).
 // ---------------------------------------------------------------------------
-template <typename T>
+// ---------------------------------------------------------------------------
+// FAST (one device, diagonal Gamma and Sigma, default time step; round 3): the launch follows the second Gram launch's
+// reduce DIRECTLY -- no G-part centring launch in between, no barrier packet for the side stream:
+//   * the Frobenius term arrives as that reduce's per-workgroup partials (FinFast::frpart), summed here in a fixed order;
+//   * K = C_ug Gamma^{-1} and gbar are formed on the fly from the moment buffer (center_kernel's expressions, entry by
+//     entry) by the threads that need them, and written out once for the debug / moments entry points;
+//   * what the side stream produced (trace / bias partials, ubar, M, L) is read with agent-scope loads: the reduce
+//     launch ended only after chol(C) had signalled (FrArgs::join), but no queue-level acquire stands between that
+//     stream's kernels and this one.
+struct FinFast {
+    const double* frpart; int nfr;
+    const double* shift;            // centring shift of THIS step's moments [p + n]
+    double* Kout; double* gbar_out; double* lag;
+};
+
+template <typename T, bool FAST>
 __global__ __launch_bounds__(DT)
-void finish_aldi_kernel(MomView mv, cesx_step_params prm, const double* __restrict__ part, Scalars* __restrict__ sc,
-                        int nwb, int kp, int kn, int rpad, int ktot, const double* __restrict__ M,
-                        const double* __restrict__ K, const double* __restrict__ L, int ldl,
-                        const double* __restrict__ y, const double* __restrict__ gbar, const double* __restrict__ mu,
-                        const double* __restrict__ ubar, const double* __restrict__ gw, int mx, double* __restrict__ mvs,
+void finish_aldi_kernel(MomView mv, cesx_step_params prm, const double* part, Scalars* __restrict__ sc,
+                        int nwb, int kp, int kn, int rpad, int ktot, const double* M,
+                        const double* K, const double* L, int ldl,
+                        const double* __restrict__ y, const double* gbar, const double* __restrict__ mu,
+                        const double* ubar, const double* __restrict__ gw, int mx, double* __restrict__ mvs,
                         T* __restrict__ W, T* __restrict__ bias, T* __restrict__ shiftT, double* __restrict__ shift64,
-                        T* __restrict__ rowc, T* __restrict__ gbarT, float* __restrict__ Wf) {
+                        T* __restrict__ rowc, T* __restrict__ gbarT, float* __restrict__ Wf, const FinFast ff) {
     static_assert(DT == NPB, "one partial per thread");
     __shared__ double red[DT / 64];
     const int p = mv.p, n = mv.n, tid = threadIdx.x;
     const double N = mv.N();
-    const double tr = dblock_sum(part[tid * 4], red);
-    const double b2 = dblock_sum(part[tid * 4 + 1], red);
-    const double fr = dblock_sum(part[tid * 4 + 2], red);
+    const double* sa = mv.sa();
+    const double* sb = mv.sb();
+    const double* Sab = mv.Sab();
+    // (FAST) one entry of K / gbar, as center_kernel forms them
+    const double invN = 1.0 / N;      // (FAST: reciprocals instead of center_kernel's quotients -- an ulp apart)
+    auto Kat = [&](int i, int c) -> double {
+        if (!FAST) return K[(size_t)i * n + c];
+        const double cug = (Sab[(size_t)i * n + c] - sa[i] * sb[c] * invN) * invN;
+        return cug * gw[c];
+    };
+    auto gbar_at = [&](int k) -> double { return FAST ? ff.shift[p + k] + sb[k] * invN : gbar[k]; };
+    auto side = [&](const double* q) -> double { return FAST ? ld_agent(q) : *q; };
+    const double tr = dblock_sum(side(part + tid * 4), red);
+    const double b2 = dblock_sum(side(part + tid * 4 + 1), red);
+    double frp = 0.0;
+    if (FAST) { for (int i = tid; i < ff.nfr; i += DT) frp += ff.frpart[i]; }
+    else frp = part[tid * 4 + 2];
+    const double fr = dblock_sum(frp, red);
     const double hk = step_hk(prm, N, fr, sc->radspec), s2 = sqrt(2.0 * hk), al = (p + 1.0) / N;
-    if (blockIdx.x == 0 && tid == 0) write_scalars(prm, p, N, tr, b2, fr, sc);
+    if (blockIdx.x == 0 && tid == 0) {
+        write_scalars(prm, p, N, tr, b2, fr, sc);
+        if (FAST) { ff.lag[0] = N; ff.lag[1] = mv.mom[mv.ml().tail()]; ff.lag[2] = mv.mom[mv.ml().tail() + 1]; }
+    }
     if ((int)blockIdx.x >= nwb) {
         const int i = ((int)blockIdx.x - nwb) * (DT / 64) + (tid >> 6), lane = tid & 63;
         if (i >= p) return;
         double ky = 0.0, kg = 0.0, mm = 0.0, mu_ = 0.0;
-        const double* Ki = K + (size_t)i * n;
         const double* Mi = M + (size_t)i * p;
-        for (int c = lane; c < n; c += 64) { ky += Ki[c] * y[c]; kg += Ki[c] * gbar[c]; }
-        for (int c = lane; c < p; c += 64) { mm += Mi[c] * mu[c]; mu_ += Mi[c] * ubar[c]; }
+        for (int c = lane; c < n; c += 64) { const double k_ = Kat(i, c); ky += k_ * y[c]; kg += k_ * gbar_at(c); }
+        for (int c = lane; c < p; c += 64) { const double m_ = side(Mi + c); mm += m_ * mu[c]; mu_ += m_ * side(ubar + c); }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             ky += __shfl_down(ky, o, 64); kg += __shfl_down(kg, o, 64);
             mm += __shfl_down(mm, o, 64); mu_ += __shfl_down(mu_, o, 64);
         }
         if (lane == 0) {
+            const double ub = side(ubar + i);
             mvs[i] = ky; mvs[(size_t)mx + i] = kg; mvs[(size_t)2 * mx + i] = mm; mvs[(size_t)3 * mx + i] = mu_;
-            bias[i] = (T)(hk * (ky + mm - al * ubar[i]));
-            const T st = (T)(ubar[i] + (-hk * (mu_ - mm) - hk * (kg - ky)));
+            bias[i] = (T)(hk * (ky + mm - al * ub));
+            const T st = (T)(ub + (-hk * (mu_ - mm) - hk * (kg - ky)));
             shiftT[i] = st;
             shift64[i] = (double)st;
         }
@@ -895,13 +951,17 @@ void finish_aldi_kernel(MomView mv, cesx_step_params prm, const double* __restri
         double v = 0.0;
         if (i < p) {
             if (k < kp) {
-                if (k < p) v = (i == k ? 1.0 + hk * al : 0.0) - hk * M[(size_t)i * p + k];
+                if (k < p) v = (i == k ? 1.0 + hk * al : 0.0) - hk * side(M + (size_t)i * p + k);
             } else if (k < kp + kn) {
                 const int c = k - kp;
-                if (c < n) v = -hk * K[(size_t)i * n + c];
+                if (c < n) {
+                    const double k_ = Kat(i, c);
+                    if (FAST) ff.Kout[(size_t)i * n + c] = k_;
+                    v = -hk * k_;
+                }
             } else {
                 const int c = k - kp - kn;
-                if (c < p && c <= i) v = s2 * L[(size_t)i * ldl + c];
+                if (c < p && c <= i) v = s2 * side(L + (size_t)i * ldl + c);
             }
         }
         W[idx] = (T)v;
@@ -913,14 +973,18 @@ void finish_aldi_kernel(MomView mv, cesx_step_params prm, const double* __restri
     if (idx >= p && idx < rpad) bias[idx] = (T)0;
     if (idx < kn) {
         const int i = (int)idx;
-        rowc[i * 4 + 0] = (T)(i < n ? gbar[i] : 0.0);
+        const double gb = i < n ? gbar_at(i) : 0.0;
+        rowc[i * 4 + 0] = (T)gb;
         rowc[i * 4 + 1] = (T)(i < n ? y[i] : 0.0);
         rowc[i * 4 + 2] = (T)((i < n && gw != nullptr) ? gw[i] : 0.0);
         rowc[i * 4 + 3] = (T)0;
-        if (i < n) gbarT[i] = (T)gbar[i];
+        if (i < n) {
+            gbarT[i] = (T)gb;
+            if (FAST) ff.gbar_out[i] = gb;
+        }
     }
     if (idx >= p && idx < p + n) {
-        const T st = (T)gbar[idx - p];
+        const T st = (T)gbar_at((int)(idx - p));
         shiftT[idx] = st;
         shift64[idx] = (double)st;
     }
@@ -1008,6 +1072,7 @@ static int gemm(Engine& e, hipStream_t s, int m, int n, int k, double alpha, con
 int launch_moments_lineal(Engine& e, double* mom, hipStream_t s) {
     const int p = e.p, n = e.n;
     int rc;
+    e.fr_mom = nullptr;          // (no reduce launch on this path: K2 takes the Frobenius term from its own pass over S_bb)
     hipLaunchKernelGGL(lineal_vec_kernel, dim3((n + DT / 64 - 1) / (DT / 64)), dim3(DT), 0, s, n, p, e.d_A64, e.d_b64,
                        e.d_shift64, mom + e.ml.sa(), e.d_lvec);
     CESX_HIP(hipGetLastError());
@@ -1046,17 +1111,18 @@ struct PotrfCen { const double* sa = nullptr; const double* N = nullptr; int unb
 template <int SLOTS>
 static int potrf_reg_launch(Engine& e, hipStream_t s, int n, int np, const double* A, double* Lp, int lda = 0, int ldl = 0,
                             hipEvent_t stop = nullptr,        // stop: event bound to this kernel's own completion signal
-                            PotrfCen cen = PotrfCen()) {
+                            PotrfCen cen = PotrfCen(),
+                            unsigned long long* done = nullptr, unsigned long long done_val = 0) {
     constexpr int NPMAX = SLOTS <= 2 ? 64 : SLOTS <= 5 ? 128 : SLOTS <= 10 ? 192 : 256;
     const size_t lds = (size_t)3 * QNB * (2 * NPMAX + 4) * 8 + (cen.sa ? (size_t)NPMAX * 8 : 0);      // panel x 2, its negative (each k-row behind NPMAX zeros), the row sums of a fused centring
     CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_reg_kernel<SLOTS>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (stop)
         hipExtLaunchKernelGGL(potrf_reg_kernel<SLOTS>, dim3(1), dim3(PRT), (unsigned)lds, s, nullptr, stop, 0, n, np, A, Lp,
-                              &e.d_scal->status, (long long*)nullptr, lda, ldl, cen.sa, cen.N, cen.unbiased);
+                              &e.d_scal->status, (long long*)nullptr, lda, ldl, cen.sa, cen.N, cen.unbiased, done, done_val);
     else
     hipLaunchKernelGGL(potrf_reg_kernel<SLOTS>, dim3(1), dim3(PRT), lds, s, n, np, A, Lp, &e.d_scal->status, (long long*)nullptr,
-                       lda, ldl, cen.sa, cen.N, cen.unbiased);
+                       lda, ldl, cen.sa, cen.N, cen.unbiased, done, done_val);
     CESX_HIP(hipGetLastError());
     return CESX_OK;
 }
@@ -1186,12 +1252,13 @@ __global__ void pad_copy_kernel(int n, int np, const double* __restrict__ A, dou
 int potrf_ld(int n) { return (n + PNB - 1) / PNB * PNB; }
 
 static int potrf_reg_any(Engine& e, hipStream_t s, int n, int np, const double* A, double* Lp, int lda, int ldl,
-                         hipEvent_t stop = nullptr, PotrfCen cen = PotrfCen()) {
+                         hipEvent_t stop = nullptr, PotrfCen cen = PotrfCen(),
+                         unsigned long long* done = nullptr, unsigned long long done_val = 0) {
     const int T = np / 16, ntile = T * (T + 1) / 2, slots = (ntile + 7) / 8;
-    if (slots <= 2) return potrf_reg_launch<2>(e, s, n, np, A, Lp, lda, ldl, stop, cen);       // np <= 64
-    if (slots <= 5) return potrf_reg_launch<5>(e, s, n, np, A, Lp, lda, ldl, stop, cen);       // np <= 128
-    if (slots <= 10) return potrf_reg_launch<10>(e, s, n, np, A, Lp, lda, ldl, stop, cen);     // np <= 192
-    if (slots <= 17) return potrf_reg_launch<17>(e, s, n, np, A, Lp, lda, ldl, stop, cen);     // np <= 256
+    if (slots <= 2) return potrf_reg_launch<2>(e, s, n, np, A, Lp, lda, ldl, stop, cen, done, done_val);       // np <= 64
+    if (slots <= 5) return potrf_reg_launch<5>(e, s, n, np, A, Lp, lda, ldl, stop, cen, done, done_val);       // np <= 128
+    if (slots <= 10) return potrf_reg_launch<10>(e, s, n, np, A, Lp, lda, ldl, stop, cen, done, done_val);     // np <= 192
+    if (slots <= 17) return potrf_reg_launch<17>(e, s, n, np, A, Lp, lda, ldl, stop, cen, done, done_val);     // np <= 256
     e.err = "potrf: diagonal block too large for the register kernel";
     return CESX_EINVAL;
 }
@@ -1211,16 +1278,17 @@ static int trsm_reg(Engine& e, hipStream_t s, int nr, int nc, const double* A, i
 // stop (optional): an event to complete with the factorisation.  One-kernel factorisations bind it to the kernel's own
 // completion signal (hipExtLaunchKernel: no separate marker packet on the stream -- a marker costs ~6 us before the
 // next kernel of the stream starts); the blocked path records it behind its last kernel.
-static int potrf(Engine& e, hipStream_t s, int n, const double* A, double* Lp, hipEvent_t stop = nullptr) {
+static int potrf(Engine& e, hipStream_t s, int n, const double* A, double* Lp, hipEvent_t stop = nullptr,
+                 unsigned long long* done = nullptr, unsigned long long done_val = 0) {      // done: one-kernel factorisations only (np <= 256)
     const int np = potrf_ld(n);
     if (np <= 256) {
         if (stop && !e.ext_events) {
-            int rc0 = potrf_reg_any(e, s, n, np, A, Lp, 0, 0);
+            int rc0 = potrf_reg_any(e, s, n, np, A, Lp, 0, 0, nullptr, PotrfCen(), done, done_val);
             if (rc0) return rc0;
             CESX_HIP(hipEventRecord(stop, s));
             return CESX_OK;
         }
-        return potrf_reg_any(e, s, n, np, A, Lp, 0, 0, stop);
+        return potrf_reg_any(e, s, n, np, A, Lp, 0, 0, stop, PotrfCen(), done, done_val);
     }
     // Blocked right-looking factorisation with 256-wide diagonal blocks (p > 256): register
     // Cholesky of the diagonal block, register TRSM of the rows below it (64 rows per
@@ -1326,18 +1394,30 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
     // read what the side stream wrote (trace / bias partials, later L).  One event each way per step -- every
     // record / wait pair costs ~6 us of idle GPU.
     const bool early = e.chol_inflight;
+    const bool fused_finish = phase == 0 && prm.update == CESX_UPDATE_ALDI && e.k2_fused &&
+        (prm.time_step == CESX_TS_DEFAULT || prm.time_step == CESX_TS_SPECTRAL);
+    // ALDI fast path (FinFast): the reduce of the second Gram launch left the Frobenius partials of THESE moments
+    // (fr_mom), chol(C) is in flight on the side stream with its U-only centring in front -- then the assembly launch
+    // follows that reduce directly
+    const bool fast = fused_finish && prm.time_step == CESX_TS_DEFAULT && early && !e.chol_fused_center && e.k2_fast_ok &&
+        e.fr_mom == mom && mom != nullptr && e.diag_gamma && e.diag_sigma && e.J == e.Jg;
     // (early, centring fused into the Cholesky's load: the U part is done HERE, with the G part, and leaves the
     //  status word alone -- the side stream carried nothing but the factorisation)
     const int what = !early ? 3 : e.chol_fused_center ? (3 | 4) : 2;
-    hipLaunchKernelGGL(center_kernel, dim3(NPB), dim3(DT), 0, s, mv, e.d_shift64, e.d_y, e.d_ustar,
-                       e.diag_gamma ? e.d_gw : (const double*)nullptr,
-                       e.diag_sigma ? e.d_sw : (const double*)nullptr, unbiased, what, e.d_ubar, e.d_gbar,
-                       e.d_m, e.d_dg, e.d_C, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_M, e.d_part, e.d_scal, e.d_lag);
-    CESX_HIP(hipGetLastError());
+    if (!fast) {
+        hipLaunchKernelGGL(center_kernel, dim3(NPB), dim3(DT), 0, s, mv, e.d_shift64, e.d_y, e.d_ustar,
+                           e.diag_gamma ? e.d_gw : (const double*)nullptr,
+                           e.diag_sigma ? e.d_sw : (const double*)nullptr, unbiased, what, e.d_ubar, e.d_gbar,
+                           e.d_m, e.d_dg, e.d_C, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_M, e.d_part, e.d_scal, e.d_lag);
+        CESX_HIP(hipGetLastError());
+    }
     if (!early)
         if ((rc = potrf(e, s, p, e.d_C, e.d_L))) return rc;
     if (early) {
-        CESX_HIP(hipStreamWaitEvent(s, e.ev_b, 0));
+        // the reduce launch in front already waited for this factorisation's signal (its first workgroup polled it) and
+        // the assembly launch reads the side stream's results with agent-scope loads: no barrier packet
+        const bool joined = fast && e.join_polled_seq == e.chol_seq;
+        if (!joined) CESX_HIP(hipStreamWaitEvent(s, e.ev_b, 0));
         e.evb_waited_seq = e.chol_seq;
         e.evb_waited_stream = s;
         e.chol_inflight = false;
@@ -1367,17 +1447,21 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
                            lz, lz + msteps, lz + 2 * msteps, e.d_scal);
         CESX_HIP(hipGetLastError());
     }
-    if (phase == 0 && prm.update == CESX_UPDATE_ALDI && e.k2_fused &&
-        (prm.time_step == CESX_TS_DEFAULT || prm.time_step == CESX_TS_SPECTRAL)) {
+    if (fused_finish) {
         const int nwb = (int)(((long long)e.rpad * e.ktot + DT - 1) / DT), nvb = (p + DT / 64 - 1) / (DT / 64);
-        auto go = [&](auto tag) {
+        // (FAST reads the shift of THESE moments while it writes the next one: d_shift_cur is the copy the reduce launch made)
+        const FinFast ff{e.d_frpart, e.fr_n, e.d_shift_cur, e.d_K, e.d_gbar, e.d_lag};
+        auto go = [&](auto tag, auto fast_tag) {
             using T = decltype(tag);
-            hipLaunchKernelGGL(finish_aldi_kernel<T>, dim3(nwb + nvb), dim3(DT), 0, s, mv, prm, e.d_part, e.d_scal, nwb,
-                               e.kp, e.kn, e.rpad, e.ktot, e.d_M, e.d_K, e.d_L, potrf_ld(p), e.d_y, e.d_gbar, e.d_mu,
-                               e.d_ubar, e.diag_gamma ? e.d_gw : (const double*)nullptr, mx, e.d_mv, (T*)e.d_W,
-                               (T*)e.d_bias, (T*)e.d_shiftT, e.d_shift64, (T*)e.d_rowc, (T*)e.d_gbarT, (float*)e.d_Wf);
+            constexpr bool FAST = decltype(fast_tag)::value;
+            hipLaunchKernelGGL((finish_aldi_kernel<T, FAST>), dim3(nwb + nvb), dim3(DT), 0, s, mv, prm, (const double*)e.d_part, e.d_scal, nwb,
+                               e.kp, e.kn, e.rpad, e.ktot, (const double*)e.d_M, (const double*)e.d_K, (const double*)e.d_L, potrf_ld(p),
+                               (const double*)e.d_y, (const double*)e.d_gbar, (const double*)e.d_mu,
+                               (const double*)e.d_ubar, e.diag_gamma ? (const double*)e.d_gw : (const double*)nullptr, mx, e.d_mv, (T*)e.d_W,
+                               (T*)e.d_bias, (T*)e.d_shiftT, e.d_shift64, (T*)e.d_rowc, (T*)e.d_gbarT, (float*)e.d_Wf, ff);
         };
-        if (f32) go(float{}); else go(double{});
+        if (fast) { if (f32) go(float{}, std::true_type{}); else go(double{}, std::true_type{}); }
+        else      { if (f32) go(float{}, std::false_type{}); else go(double{}, std::false_type{}); }
         CESX_HIP(hipGetLastError());
         return CESX_OK;
     }
@@ -1445,9 +1529,9 @@ int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s, b
         const int np = potrf_ld(p);
         PotrfCen cen{mv.mom + e.ml.sa(), mv.mom, unbiased};
         if (e.ext_events) {
-            if ((rc = potrf_reg_any(e, e.side, p, np, mv.mom + e.ml.Saa(), e.d_L, p, 0, e.ev_b, cen))) return rc;
+            if ((rc = potrf_reg_any(e, e.side, p, np, mv.mom + e.ml.Saa(), e.d_L, p, 0, e.ev_b, cen, e.d_cholflag, e.chol_seq + 1))) return rc;
         } else {
-            if ((rc = potrf_reg_any(e, e.side, p, np, mv.mom + e.ml.Saa(), e.d_L, p, 0, nullptr, cen))) return rc;
+            if ((rc = potrf_reg_any(e, e.side, p, np, mv.mom + e.ml.Saa(), e.d_L, p, 0, nullptr, cen, e.d_cholflag, e.chol_seq + 1))) return rc;
             CESX_HIP(hipEventRecord(e.ev_b, e.side));
         }
     } else {
@@ -1457,8 +1541,9 @@ int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s, b
                        e.diag_sigma ? e.d_sw : (const double*)nullptr, unbiased, 1, e.d_ubar, e.d_gbar,
                        e.d_m, e.d_dg, e.d_C, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_M, e.d_part, e.d_scal, (double*)nullptr);
     CESX_HIP(hipGetLastError());
-    if ((rc = potrf(e, e.side, p, e.d_C, e.d_L, e.ev_b))) return rc;      // ev_b: C, M, ubar, L -- what K2's scalar and assemble kernels read
+    if ((rc = potrf(e, e.side, p, e.d_C, e.d_L, e.ev_b, e.d_cholflag, e.chol_seq + 1))) return rc;      // ev_b: C, M, ubar, L -- what K2's scalar and assemble kernels read
     }
+    e.chol_signals = potrf_ld(p) <= 256;      // (the blocked factorisation ends in a GEMM launch: the event is its only hand-over)
     ++e.chol_seq;
     if (e.xi_want >= 0 && e.d_xi[0]) {
         // noise blocks asked for by cesx_prefetch_noise (cesx_internal.h): this step's, unless the lookahead of an
