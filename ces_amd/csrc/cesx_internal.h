@@ -262,20 +262,6 @@ __device__ __forceinline__ void metric_final_body(const MetricFin& f) {
     if (threadIdx.x == 0) __hip_atomic_store(&f.host->seq, f.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// What the second Gram launch's reduce adds on one device with diagonal Gamma (FrArgs, gram_reduce_kernel): the partial
-// sums of the time step's Frobenius term, taken while the S_bb entries are at hand, and the join of the side stream.
-struct FrArgs {
-    double* part = nullptr;                 // [main workgroups] partial sums of sum_ij see_ij srr_ij gw_i gw_j (nullptr: none)
-    const double* shift = nullptr;          // centring shift [p + n] (fp64 image)
-    double* shift_copy = nullptr;           // ... copied here by workgroup 0: the assembly launch reads THIS step's shift while it writes the next
-    const double* y = nullptr;
-    const double* gw = nullptr;             // diag(Gamma^{-1})
-    int pb0 = 0;                            // first block row that lies in G entirely (p a multiple of the tile) or -1
-    const unsigned long long* join = nullptr;   // != nullptr: workgroup 0 ends only when *join >= join_want (chol(C) has signalled)
-    unsigned long long join_want = 0;
-    int* status = nullptr;                  // where a join that timed out is reported
-};
-
 struct Engine {
     cesx_config cfg{};
     std::string err;
@@ -382,16 +368,10 @@ struct Engine {
     long long xi_want = -1;          // step index asked for by cesx_prefetch_noise, drawn behind the next chol(C)
     bool xi_lookahead = true;        // CESX_NOISE_LOOKAHEAD=0 switches the second draw off
     unsigned long long chol_seq = 0;              // cesx_chol_async calls so far
-    // ---- ALDI fast path on one device (round 3): no G-part centring launch, no barrier packet for the side stream ----
-    bool k2_fast_ok = true;                       // CESX_K2_FAST=0 switches it off
-    double* d_frpart = nullptr;                   // partial sums of the Frobenius term written by the second Gram launch's reduce
-    double* d_shift_cur = nullptr;                // [p + n] the centring shift of the moments those partials belong to
-    int frparts = 0, fr_n = 0;                    // ... capacity, and how many the last such launch wrote
-    const double* fr_mom = nullptr;               // the moment buffer they belong to (nullptr: none valid)
+    // ---- the side stream joined through a polled word instead of a barrier packet (round 3, launch_dense) ----
     bool poll_join_ok = true;                     // CESX_POLL_JOIN=0: always join the side stream with the event
     unsigned long long* d_cholflag = nullptr;     // chol_seq of the last factorisation that completed on the side stream, stored by the kernel itself
     bool chol_signals = false;                    // the factorisation in flight stores that word (one-kernel path, p <= 256)
-    unsigned long long join_polled_seq = 0;       // chol_seq whose completion the last reduce launch waited for in its workgroup 0
     unsigned long long evb_waited_seq = 0;        // ... the last one whose ev_b a stream has waited for,
     hipStream_t evb_waited_stream = nullptr;      // and that stream
     int last_update_grid_x = 0, last_update_grid = 0, last_metric_parts = 0;

@@ -211,7 +211,6 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
     if (const char* xv = std::getenv("CESX_EXT_EVENTS")) e.ext_events = xv[0] != '0';
     if (const char* dv = std::getenv("CESX_DEFER_PUBLISH")) e.met_defer_ok = dv[0] != '0';
     if (const char* fv = std::getenv("CESX_FUSE_CENTER")) e.fuse_center_ok = fv[0] != '0';
-    if (const char* kv = std::getenv("CESX_K2_FAST")) e.k2_fast_ok = kv[0] != '0';
     if (const char* pv = std::getenv("CESX_POLL_JOIN")) e.poll_join_ok = pv[0] != '0';
     auto fail = [&](int rc) { g_create_err = e.err; cesx_destroy(reinterpret_cast<cesx_handle>(ep)); return rc; };
     int rc;
@@ -318,13 +317,6 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
     DM(e.d_absmax_part, (size_t)update_grid_blocks(e, p) * 8);
     DM(e.d_clk, 4 * 8);
     DM(e.d_cholflag, 128);
-    DM(e.d_shift_cur, P * 8);
-    {
-        // one Frobenius partial per main workgroup of the second launch's reduce (32 16-byte groups each)
-        const GramPlan& pl1 = e.gp[1].plan;
-        e.frparts = (int)(((long long)pl1.nblocks * pl1.tile * pl1.tile / (cfg->dtype == CESX_F32 ? 4 : 2) + 31) / 32) + 1;
-        DM(e.d_frpart, (size_t)e.frparts * 8);
-    }
     DM(e.d_lag, 3 * 8);
     DM(e.d_A64, (size_t)n * p * 8); DM(e.d_b64, n * 8); DM(e.d_lvec, 2 * n * 8);
 #undef DM
@@ -369,7 +361,7 @@ void cesx_destroy(cesx_handle h) {
                     e.gp[1].d_type_hdr, e.gp[1].d_rows, e.gp[1].d_wblk, e.gp[1].d_blk_rc, e.gp[1].d_row_own, e.gp[1].d_slabs, e.gp[1].d_rowsum_part, e.d_sums, e.d_ubar, e.d_gbar, e.d_m, e.d_dg,
                     e.d_wdel, e.d_C, e.d_L, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_Kp, e.d_M, e.d_P, e.d_PK,
                     e.d_t1, e.d_t2, e.d_t3, e.d_t4, e.d_Lp, e.d_lanczos, e.d_mv, e.d_part, e.d_scal, e.d_absmax,
-                    e.d_c0, e.d_absmax_part, e.d_clk, e.d_cholflag, e.d_shift_cur, e.d_frpart, e.d_lag, e.d_A64, e.d_b64, e.d_lvec};
+                    e.d_c0, e.d_absmax_part, e.d_clk, e.d_cholflag, e.d_lag, e.d_A64, e.d_b64, e.d_lvec};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     for (int w = 0; w < 2; ++w)

@@ -61,7 +61,10 @@ void center_kernel(MomView mv, const double* __restrict__ shift, const double* _
                    double* __restrict__ dg, double* __restrict__ C, double* __restrict__ Cug,
                    double* __restrict__ See, double* __restrict__ Srr, double* __restrict__ K,
                    double* __restrict__ M, double* __restrict__ part, Scalars* __restrict__ sc,
-                   double* __restrict__ lag) {
+                   double* __restrict__ lag,
+                   // join != nullptr (the G part on the caller's stream): workgroup 0 ends only when *join >= join_want --
+                   // chol(C) has signalled on the side stream -- so that the assembly launch behind needs no barrier packet
+                   const unsigned long long* join = nullptr, unsigned long long join_want = 0) {
     __shared__ double red[1024 / 64];      // (launched with 256 or, for the U-only part beside a Gram launch, 1024 threads)
     // what & 1: the part that depends on U alone (C, M = C Sigma^{-1}, ubar, tr S_uu, |ubar - u*|^2):
     //           everything chol(C) needs, available before the rest of the Gram is finished
@@ -152,13 +155,20 @@ void center_kernel(MomView mv, const double* __restrict__ shift, const double* _
             if (what & 2) part[b * 4 + 2] = 0.0;
         }
     // the U-only part runs on the side stream in front of chol(C), whose completion the caller's stream may take from a
-    // polled word instead of a queue-level wait (FrArgs::join): its results are written back at agent scope here
+    // polled word instead of a queue-level wait (launch_dense): its results are written back at agent scope here
     // (ONE write-back of the XCD's L2 per workgroup, behind its waves' acknowledged stores: 1024 threads each fencing
     //  took the kernel from 13 to 23 us)
     if (what & 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) __threadfence();
+    }
+    if (join != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {      // (one small workgroup waits: chol(C) needs a CU of its own)
+        unsigned spins = 0;
+        while (__hip_atomic_load(join, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < join_want) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++spins > (1u << 21)) { sc->status = CESX_EHIP; break; }
+        }
     }
 }
 
@@ -873,21 +883,7 @@ __global__ void assemble_kernel(int mode, int p, int n, int kp, int kn, int rpad
 // assemble_kernel<T>(mode 0).
 // ---------------------------------------------------------------------------
 // ---------------------------------------------------------------------------
-// FAST (one device, diagonal Gamma and Sigma, default time step; round 3): the launch follows the second Gram launch's
-// reduce DIRECTLY -- no G-part centring launch in between, no barrier packet for the side stream:
-//   * the Frobenius term arrives as that reduce's per-workgroup partials (FinFast::frpart), summed here in a fixed order;
-//   * K = C_ug Gamma^{-1} and gbar are formed on the fly from the moment buffer (center_kernel's expressions, entry by
-//     entry) by the threads that need them, and written out once for the debug / moments entry points;
-//   * what the side stream produced (trace / bias partials, ubar, M, L) is read with agent-scope loads: the reduce
-//     launch ended only after chol(C) had signalled (FrArgs::join), but no queue-level acquire stands between that
-//     stream's kernels and this one.
-struct FinFast {
-    const double* frpart; int nfr;
-    const double* shift;            // centring shift of THIS step's moments [p + n]
-    double* Kout; double* gbar_out; double* lag;
-};
-
-template <typename T, bool FAST>
+template <typename T, bool POLLED>
 __global__ __launch_bounds__(DT)
 void finish_aldi_kernel(MomView mv, cesx_step_params prm, const double* part, Scalars* __restrict__ sc,
                         int nwb, int kp, int kn, int rpad, int ktot, const double* M,
@@ -895,40 +891,26 @@ void finish_aldi_kernel(MomView mv, cesx_step_params prm, const double* part, Sc
                         const double* __restrict__ y, const double* gbar, const double* __restrict__ mu,
                         const double* ubar, const double* __restrict__ gw, int mx, double* __restrict__ mvs,
                         T* __restrict__ W, T* __restrict__ bias, T* __restrict__ shiftT, double* __restrict__ shift64,
-                        T* __restrict__ rowc, T* __restrict__ gbarT, float* __restrict__ Wf, const FinFast ff) {
+                        T* __restrict__ rowc, T* __restrict__ gbarT, float* __restrict__ Wf) {
     static_assert(DT == NPB, "one partial per thread");
     __shared__ double red[DT / 64];
     const int p = mv.p, n = mv.n, tid = threadIdx.x;
     const double N = mv.N();
-    const double* sa = mv.sa();
-    const double* sb = mv.sb();
-    const double* Sab = mv.Sab();
-    // (FAST) one entry of K / gbar, as center_kernel forms them
-    const double invN = 1.0 / N;      // (FAST: reciprocals instead of center_kernel's quotients -- an ulp apart)
-    auto Kat = [&](int i, int c) -> double {
-        if (!FAST) return K[(size_t)i * n + c];
-        const double cug = (Sab[(size_t)i * n + c] - sa[i] * sb[c] * invN) * invN;
-        return cug * gw[c];
-    };
-    auto gbar_at = [&](int k) -> double { return FAST ? ff.shift[p + k] + sb[k] * invN : gbar[k]; };
-    auto side = [&](const double* q) -> double { return FAST ? ld_agent(q) : *q; };
+    // POLLED: the side stream was joined through chol(C)'s signal word (a workgroup of the launch in front waited for
+    // it), not through a barrier packet: what that stream wrote is read with agent-scope loads
+    auto side = [&](const double* q) -> double { return POLLED ? ld_agent(q) : *q; };
     const double tr = dblock_sum(side(part + tid * 4), red);
     const double b2 = dblock_sum(side(part + tid * 4 + 1), red);
-    double frp = 0.0;
-    if (FAST) { for (int i = tid; i < ff.nfr; i += DT) frp += ff.frpart[i]; }
-    else frp = part[tid * 4 + 2];
-    const double fr = dblock_sum(frp, red);
+    const double fr = dblock_sum(part[tid * 4 + 2], red);
     const double hk = step_hk(prm, N, fr, sc->radspec), s2 = sqrt(2.0 * hk), al = (p + 1.0) / N;
-    if (blockIdx.x == 0 && tid == 0) {
-        write_scalars(prm, p, N, tr, b2, fr, sc);
-        if (FAST) { ff.lag[0] = N; ff.lag[1] = mv.mom[mv.ml().tail()]; ff.lag[2] = mv.mom[mv.ml().tail() + 1]; }
-    }
+    if (blockIdx.x == 0 && tid == 0) write_scalars(prm, p, N, tr, b2, fr, sc);
     if ((int)blockIdx.x >= nwb) {
         const int i = ((int)blockIdx.x - nwb) * (DT / 64) + (tid >> 6), lane = tid & 63;
         if (i >= p) return;
         double ky = 0.0, kg = 0.0, mm = 0.0, mu_ = 0.0;
         const double* Mi = M + (size_t)i * p;
-        for (int c = lane; c < n; c += 64) { const double k_ = Kat(i, c); ky += k_ * y[c]; kg += k_ * gbar_at(c); }
+        const double* Ki = K + (size_t)i * n;
+        for (int c = lane; c < n; c += 64) { ky += Ki[c] * y[c]; kg += Ki[c] * gbar[c]; }
         for (int c = lane; c < p; c += 64) { const double m_ = side(Mi + c); mm += m_ * mu[c]; mu_ += m_ * side(ubar + c); }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -954,11 +936,7 @@ void finish_aldi_kernel(MomView mv, cesx_step_params prm, const double* part, Sc
                 if (k < p) v = (i == k ? 1.0 + hk * al : 0.0) - hk * side(M + (size_t)i * p + k);
             } else if (k < kp + kn) {
                 const int c = k - kp;
-                if (c < n) {
-                    const double k_ = Kat(i, c);
-                    if (FAST) ff.Kout[(size_t)i * n + c] = k_;
-                    v = -hk * k_;
-                }
+                if (c < n) v = -hk * K[(size_t)i * n + c];
             } else {
                 const int c = k - kp - kn;
                 if (c < p && c <= i) v = s2 * side(L + (size_t)i * ldl + c);
@@ -973,18 +951,15 @@ void finish_aldi_kernel(MomView mv, cesx_step_params prm, const double* part, Sc
     if (idx >= p && idx < rpad) bias[idx] = (T)0;
     if (idx < kn) {
         const int i = (int)idx;
-        const double gb = i < n ? gbar_at(i) : 0.0;
+        const double gb = i < n ? gbar[i] : 0.0;
         rowc[i * 4 + 0] = (T)gb;
         rowc[i * 4 + 1] = (T)(i < n ? y[i] : 0.0);
         rowc[i * 4 + 2] = (T)((i < n && gw != nullptr) ? gw[i] : 0.0);
         rowc[i * 4 + 3] = (T)0;
-        if (i < n) {
-            gbarT[i] = (T)gb;
-            if (FAST) ff.gbar_out[i] = gb;
-        }
+        if (i < n) gbarT[i] = (T)gb;
     }
     if (idx >= p && idx < p + n) {
-        const T st = (T)gbar_at((int)(idx - p));
+        const T st = (T)gbar[idx - p];
         shiftT[idx] = st;
         shift64[idx] = (double)st;
     }
@@ -1072,7 +1047,6 @@ static int gemm(Engine& e, hipStream_t s, int m, int n, int k, double alpha, con
 int launch_moments_lineal(Engine& e, double* mom, hipStream_t s) {
     const int p = e.p, n = e.n;
     int rc;
-    e.fr_mom = nullptr;          // (no reduce launch on this path: K2 takes the Frobenius term from its own pass over S_bb)
     hipLaunchKernelGGL(lineal_vec_kernel, dim3((n + DT / 64 - 1) / (DT / 64)), dim3(DT), 0, s, n, p, e.d_A64, e.d_b64,
                        e.d_shift64, mom + e.ml.sa(), e.d_lvec);
     CESX_HIP(hipGetLastError());
@@ -1396,28 +1370,28 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
     const bool early = e.chol_inflight;
     const bool fused_finish = phase == 0 && prm.update == CESX_UPDATE_ALDI && e.k2_fused &&
         (prm.time_step == CESX_TS_DEFAULT || prm.time_step == CESX_TS_SPECTRAL);
-    // ALDI fast path (FinFast): the reduce of the second Gram launch left the Frobenius partials of THESE moments
-    // (fr_mom), chol(C) is in flight on the side stream with its U-only centring in front -- then the assembly launch
-    // follows that reduce directly
-    const bool fast = fused_finish && prm.time_step == CESX_TS_DEFAULT && early && !e.chol_fused_center && e.k2_fast_ok &&
-        e.fr_mom == mom && mom != nullptr && e.diag_gamma && e.diag_sigma && e.J == e.Jg;
     // (early, centring fused into the Cholesky's load: the U part is done HERE, with the G part, and leaves the
     //  status word alone -- the side stream carried nothing but the factorisation)
     const int what = !early ? 3 : e.chol_fused_center ? (3 | 4) : 2;
-    if (!fast) {
-        hipLaunchKernelGGL(center_kernel, dim3(NPB), dim3(DT), 0, s, mv, e.d_shift64, e.d_y, e.d_ustar,
-                           e.diag_gamma ? e.d_gw : (const double*)nullptr,
-                           e.diag_sigma ? e.d_sw : (const double*)nullptr, unbiased, what, e.d_ubar, e.d_gbar,
-                           e.d_m, e.d_dg, e.d_C, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_M, e.d_part, e.d_scal, e.d_lag);
-        CESX_HIP(hipGetLastError());
-    }
+    // The side stream joined WITHOUT a barrier packet (6-8 us of the caller's stream even when the event completed long
+    // before): workgroup 0 of the G-part centring launch -- the launch in front of the assembly launch -- ends only when
+    // chol(C) has stored its sequence number, and the assembly launch reads what that stream wrote with agent-scope
+    // loads (no queue-level acquire stands between that stream's kernels and it).  Only where nothing else sits between the two and reads those results (ALDI, default time
+    // step, diagonal Gamma / Sigma, one device), and only for the one-kernel factorisation that signals.
+    const bool can_poll = fused_finish && prm.time_step == CESX_TS_DEFAULT && early && !e.chol_fused_center && e.poll_join_ok &&
+        e.chol_signals && e.diag_gamma && e.diag_sigma && e.J == e.Jg && s != e.side;
+    const bool polled = can_poll;
+    hipLaunchKernelGGL(center_kernel, dim3(NPB), dim3(DT), 0, s, mv, e.d_shift64, e.d_y, e.d_ustar,
+                       e.diag_gamma ? e.d_gw : (const double*)nullptr,
+                       e.diag_sigma ? e.d_sw : (const double*)nullptr, unbiased, what, e.d_ubar, e.d_gbar,
+                       e.d_m, e.d_dg, e.d_C, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_M, e.d_part, e.d_scal, e.d_lag,
+                       polled ? (const unsigned long long*)e.d_cholflag : (const unsigned long long*)nullptr,
+                       (unsigned long long)e.chol_seq);
+    CESX_HIP(hipGetLastError());
     if (!early)
         if ((rc = potrf(e, s, p, e.d_C, e.d_L))) return rc;
     if (early) {
-        // the reduce launch in front already waited for this factorisation's signal (its first workgroup polled it) and
-        // the assembly launch reads the side stream's results with agent-scope loads: no barrier packet
-        const bool joined = fast && e.join_polled_seq == e.chol_seq;
-        if (!joined) CESX_HIP(hipStreamWaitEvent(s, e.ev_b, 0));
+        if (!polled) CESX_HIP(hipStreamWaitEvent(s, e.ev_b, 0));
         e.evb_waited_seq = e.chol_seq;
         e.evb_waited_stream = s;
         e.chol_inflight = false;
@@ -1449,19 +1423,20 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
     }
     if (fused_finish) {
         const int nwb = (int)(((long long)e.rpad * e.ktot + DT - 1) / DT), nvb = (p + DT / 64 - 1) / (DT / 64);
-        // (FAST reads the shift of THESE moments while it writes the next one: d_shift_cur is the copy the reduce launch made)
-        const FinFast ff{e.d_frpart, e.fr_n, e.d_shift_cur, e.d_K, e.d_gbar, e.d_lag};
-        auto go = [&](auto tag, auto fast_tag) {
+        auto go = [&](auto tag, auto poll_tag) {
             using T = decltype(tag);
-            constexpr bool FAST = decltype(fast_tag)::value;
-            hipLaunchKernelGGL((finish_aldi_kernel<T, FAST>), dim3(nwb + nvb), dim3(DT), 0, s, mv, prm, (const double*)e.d_part, e.d_scal, nwb,
+            constexpr bool POLLED = decltype(poll_tag)::value;
+            hipLaunchKernelGGL((finish_aldi_kernel<T, POLLED>), dim3(nwb + nvb), dim3(DT), 0, s, mv, prm, (const double*)e.d_part, e.d_scal, nwb,
                                e.kp, e.kn, e.rpad, e.ktot, (const double*)e.d_M, (const double*)e.d_K, (const double*)e.d_L, potrf_ld(p),
                                (const double*)e.d_y, (const double*)e.d_gbar, (const double*)e.d_mu,
                                (const double*)e.d_ubar, e.diag_gamma ? (const double*)e.d_gw : (const double*)nullptr, mx, e.d_mv, (T*)e.d_W,
-                               (T*)e.d_bias, (T*)e.d_shiftT, e.d_shift64, (T*)e.d_rowc, (T*)e.d_gbarT, (float*)e.d_Wf, ff);
+                               (T*)e.d_bias, (T*)e.d_shiftT, e.d_shift64, (T*)e.d_rowc, (T*)e.d_gbarT, (float*)e.d_Wf);
         };
-        if (fast) { if (f32) go(float{}, std::true_type{}); else go(double{}, std::true_type{}); }
-        else      { if (f32) go(float{}, std::false_type{}); else go(double{}, std::false_type{}); }
+        auto pick = [&](auto tag) {
+            if (polled) go(tag, std::true_type{});
+            else go(tag, std::false_type{});
+        };
+        if (f32) pick(float{}); else pick(double{});
         CESX_HIP(hipGetLastError());
         return CESX_OK;
     }

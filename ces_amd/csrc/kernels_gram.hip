@@ -273,9 +273,9 @@ __global__ __launch_bounds__(RED_G * RED_S)
 void gram_reduce_kernel(const T* __restrict__ slabs, const int* __restrict__ blk_rc, const int* __restrict__ row_own,
                         int nblocks, int tile, MomLayout ml, long long J, int row_lo, int row_hi,
                         int write_N, const double* __restrict__ rowsum_part, const double* __restrict__ tail_src,
-                        double* mom, const MetricFin fin, const FrArgs fr) {
+                        double* __restrict__ mom, const MetricFin fin) {
     using vec_t = typename Mfma<T>::vec_t;
-    constexpr int VEC = Mfma<T>::VEC, TILE = Mfma<T>::TILE;
+    constexpr int VEC = Mfma<T>::VEC;
     // the previous update's metric finalisation + publication, riding on this launch as one extra workgroup -- the
     // FIRST one: its chain of dependent loads, fences and the write to host memory (~8 us) starts with the launch and
     // ends inside it
@@ -317,56 +317,6 @@ void gram_reduce_kernel(const T* __restrict__ slabs, const int* __restrict__ blk
     }
     const bool on = idx < ngroups;
     const int blk = on ? (int)(idx / (tt / VEC)) : 0, e0 = on ? (int)(idx % (tt / VEC)) * VEC : 0;
-    // One device, diagonal Gamma (fr.part): the entries of S_bb this workgroup completes also yield its share of the
-    // time step's Frobenius term  sum_ij see_ij srr_ij gw_i gw_j  (ces/calibrate.py:243-267 through SURVEY.md 3.3; the
-    // arithmetic per entry is center_kernel's) -- K2 then needs no pass over S_bb of its own between this launch and
-    // the assembly of W.  The first moments sb_i it needs are summed here from the same row-sum partials, in the same
-    // order, as the tail workgroups sum them into the buffer (block rows another launch owns: read from the buffer).
-    __shared__ double sbp[RED_S][2][TILE];
-    __shared__ double sbt[2][TILE];
-    bool gg = false;
-    int R0 = 0, C0 = 0;
-    if (fr.part != nullptr) {
-        const long long g0 = (long long)bid * RED_G;                                       // (all groups of a workgroup lie in one block)
-        const int* info0 = blk_rc + (int)(g0 / (tt / VEC)) * 5;
-        R0 = info0[0]; C0 = info0[1];
-        gg = (R0 + 1) * TILE > p && (C0 + 1) * TILE > p;
-        if (gg) {
-            const int P_ = p + n;
-            // the rows of block row R0 this workgroup's entries lie in: its RED_G groups cover rows rlo .. rhi of the block
-            // (slab_group_rc: 4 rows in f32, 8 in f64) and, between them, every column -- only those row sums are formed
-            int ra, ca, rb_, cb_, rs_;
-            slab_group_rc<T>((int)(g0 % (tt / VEC)), ra, ca, rs_);
-            slab_group_rc<T>((int)(g0 % (tt / VEC)) + RED_G - 1, rb_, cb_, rs_);
-            const int rlo = ra < rb_ ? ra : rb_, rhi = (ra < rb_ ? rb_ : ra) + (VEC - 1) * rs_;
-            for (int it = threadIdx.x; it < 2 * TILE * RED_S; it += RED_G * RED_S) {
-                const int q = it / (2 * TILE), wr = it % (2 * TILE), which = wr / TILE, r = wr % TILE;
-                const int gr = (which ? C0 : R0) * TILE + r;
-                double sum = 0.0;
-                if (gr >= p && gr < P_ && (which == 1 || (r >= rlo && r <= rhi))) {
-                    const int rs0 = row_own[(gr / TILE) * 2], nsl = row_own[(gr / TILE) * 2 + 1];
-                    if (nsl == 0) {
-                        if (q == 0) sum = mom[ml.sb() + (gr - p)];
-                    } else {
-                        const int per_ = (nsl + RED_S - 1) / RED_S;
-                        const int kb = min(nsl, (q + 1) * per_);
-#pragma unroll 8
-                        for (int k = q * per_; k < kb; ++k) sum += rowsum_part[(size_t)(rs0 + k) * P_ + gr];
-                    }
-                }
-                sbp[q][which][r] = sum;
-            }
-            __syncthreads();
-            if (threadIdx.x < 2 * TILE) {
-                const int which = threadIdx.x / TILE, r = threadIdx.x % TILE;
-                double t = 0.0;
-#pragma unroll
-                for (int q = 0; q < RED_S; ++q) t += sbp[q][which][r];
-                sbt[which][r] = t;
-            }
-            __syncthreads();
-        }
-    }
     double acc[VEC];
 #pragma unroll
     for (int c = 0; c < VEC; ++c) acc[c] = 0.0;
@@ -396,64 +346,30 @@ void gram_reduce_kernel(const T* __restrict__ slabs, const int* __restrict__ blk
 #pragma unroll
     for (int c = 0; c < VEC; ++c) part[gq][gl][c] = acc[c];
     __syncthreads();
-    if (gq != 0) return;
-    double frl = 0.0;
-    if (on) {
-        const int R = info[0], C = info[1];
-        const int P = p + n;
-        double* Saa = mom + ml.Saa();
-        double* Sab = mom + ml.Sab();
-        double* Sbb = mom + ml.Sbb();
-        // (reciprocal: five fp64 divisions per entry sat on the launch's critical path -- see / mi differ from
-        //  center_kernel's quotients by an ulp, the term by ~1e-16 relative)
-        const double N = gg ? mom[0] : 1.0, invN = 1.0 / N;
-        int row0, col, rstep;
-        slab_group_rc<T>(e0 / VEC, row0, col, rstep);
+    if (gq != 0 || !on) return;
+    const int R = info[0], C = info[1];
+    const int P = p + n;
+    double* Saa = mom + ml.Saa();
+    double* Sab = mom + ml.Sab();
+    double* Sbb = mom + ml.Sbb();
+    int row0, col, rstep;
+    slab_group_rc<T>(e0 / VEC, row0, col, rstep);
 #pragma unroll
-        for (int c = 0; c < VEC; ++c) {
-            const int gr = R * tile + row0 + c * rstep, gc = C * tile + col;
-            if (gr >= P || gc >= P) continue;
-            if (R == C && gc > gr) continue;          // diagonal block: lower half, mirrored below
-            double s = 0.0;
+    for (int c = 0; c < VEC; ++c) {
+        const int gr = R * tile + row0 + c * rstep, gc = C * tile + col;
+        if (gr >= P || gc >= P) continue;
+        if (R == C && gc > gr) continue;          // diagonal block: lower half, mirrored below
+        double s = 0.0;
 #pragma unroll
-            for (int q = 0; q < RED_S; ++q) s += part[q][gl][c];
-            if (gr < p) {                              // both in U (gr >= gc)
-                Saa[(size_t)gr * p + gc] = s;
-                Saa[(size_t)gc * p + gr] = s;
-            } else if (gc < p) {                       // gr in G, gc in U
-                Sab[(size_t)gc * n + (gr - p)] = s;
-            } else {
-                Sbb[(size_t)(gr - p) * n + (gc - p)] = s;
-                Sbb[(size_t)(gc - p) * n + (gr - p)] = s;
-                if (gg) {
-                    const int i = gr - p, j = gc - p;
-                    const double sbi = sbt[0][gr - R0 * TILE], sbj = sbt[1][gc - C0 * TILE];
-                    const double see = s - sbi * sbj * invN;
-                    const double mi = fr.shift[p + i] + sbi * invN - fr.y[i], mj = fr.shift[p + j] + sbj * invN - fr.y[j];
-                    const double srr = see + N * mi * mj;
-                    const double term = see * srr * fr.gw[i] * fr.gw[j];
-                    frl += gr != gc ? 2.0 * term : term;      // (the mirrored entry)
-                }
-            }
-        }
-    }
-    if (fr.part != nullptr) {
-        if (bid == 0)
-            for (int i = threadIdx.x; i < p + n; i += RED_G) fr.shift_copy[i] = fr.shift[i];      // (the RED_G finishing threads)
-        // the RED_G finishing threads are the first lanes of wave 0: fixed-order sum, one slot per workgroup
-#pragma unroll
-        for (int o = RED_G / 2; o > 0; o >>= 1) frl += __shfl_down(frl, o, 64);
-        if (threadIdx.x == 0) fr.part[bid] = frl;
-    }
-    // The side stream's factorisation is joined HERE when the engine asks for it: the launch completes only after
-    // chol(C) has stored its sequence number, so the next kernel of the caller's stream needs no barrier packet (6-8 us
-    // of that stream even when the event completed long before).  One small workgroup waits -- the factorisation needs
-    // a CU of its own and must always find one.  Bounded (~2 s): a factorisation that never signals fails the step.
-    if (fr.join != nullptr && bid == 0 && threadIdx.x == 0) {
-        unsigned spins = 0;
-        while (__hip_atomic_load(fr.join, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < fr.join_want) {
-            __builtin_amdgcn_s_sleep(16);
-            if (++spins > (1u << 21)) { *fr.status = CESX_EHIP; break; }
+        for (int q = 0; q < RED_S; ++q) s += part[q][gl][c];
+        if (gr < p) {                              // both in U (gr >= gc)
+            Saa[(size_t)gr * p + gc] = s;
+            Saa[(size_t)gc * p + gr] = s;
+        } else if (gc < p) {                       // gr in G, gc in U
+            Sab[(size_t)gc * n + (gr - p)] = s;
+        } else {
+            Sbb[(size_t)(gr - p) * n + (gc - p)] = s;
+            Sbb[(size_t)(gc - p) * n + (gr - p)] = s;
         }
     }
 }
@@ -747,36 +663,18 @@ static int launch_gram_reduce_t(Engine& e, int part, double* mom, hipStream_t s,
     const GramPlan& pl = gp.plan;
     const long long ngroups = (long long)pl.nblocks * pl.tile * pl.tile / Mfma<T>::VEC;
     const int row_lo = std::min(pl.own_lo * pl.tile, e.p + e.n), row_hi = std::min(pl.own_hi * pl.tile, e.p + e.n);
-    const long long main_wgs = (ngroups + RED_G - 1) / RED_G;
-    const long long wgs = main_wgs + std::max(1, (row_hi - row_lo + RED_G - 1) / RED_G) + (fin ? 1 : 0);
+    const long long wgs = (ngroups + RED_G - 1) / RED_G + std::max(1, (row_hi - row_lo + RED_G - 1) / RED_G) + (fin ? 1 : 0);
     const MetricFin f = fin ? *fin : MetricFin{};
-    // second launch, whole ensemble on this device, diagonal Gamma: the Frobenius term's partial sums come out of this
-    // launch and (a factorisation in flight that signals) its first workgroup joins the side stream -- launch_dense then
-    // skips the G-part centring launch and the wait for ev_b (ALDI, default time step)
-    FrArgs fr;
-    if (part == 1) e.fr_mom = nullptr;
-    // (p a multiple of the tile: every S_bb entry then belongs to THIS launch -- a block row across U and G is the first
-    //  launch's, and its share of the term would be missing)
-    if (part == 1 && fin == nullptr && e.k2_fast_ok && e.J == e.Jg && e.diag_gamma && main_wgs > 0 && main_wgs <= e.frparts &&
-        e.p % pl.tile == 0 && (pl.tile * pl.tile / Mfma<T>::VEC) % RED_G == 0) {
-        fr.part = e.d_frpart; fr.shift = e.d_shift64; fr.shift_copy = e.d_shift_cur; fr.y = e.d_y; fr.gw = e.d_gw; fr.status = &e.d_scal->status;
-        e.fr_mom = mom;
-        e.fr_n = (int)main_wgs;
-        if (e.poll_join_ok && e.chol_inflight && e.chol_signals && s != e.side) {
-            fr.join = e.d_cholflag; fr.join_want = e.chol_seq;
-            e.join_polled_seq = e.chol_seq;
-        }
-    }
     if (stop)
         hipExtLaunchKernelGGL(gram_reduce_kernel<T>, dim3((unsigned)wgs), dim3(RED_G * RED_S), 0, s, nullptr, stop, 0,
                               (const T*)gp.d_slabs, (const int*)gp.d_blk_rc, (const int*)gp.d_row_own, pl.nblocks, pl.tile, e.ml,
                               (long long)e.J, row_lo, row_hi, part == 0 ? 1 : 0, (const double*)gp.d_rowsum_part,
-                              part == 1 ? (const double*)e.d_metric_sums : (const double*)nullptr, mom, f, fr);
+                              part == 1 ? (const double*)e.d_metric_sums : (const double*)nullptr, mom, f);
     else
     hipLaunchKernelGGL(gram_reduce_kernel<T>, dim3((unsigned)wgs), dim3(RED_G * RED_S), 0, s,
                        (const T*)gp.d_slabs, gp.d_blk_rc, gp.d_row_own, pl.nblocks, pl.tile, e.ml,
                        (long long)e.J, row_lo, row_hi, part == 0 ? 1 : 0, gp.d_rowsum_part,
-                       part == 1 ? e.d_metric_sums : (const double*)nullptr, mom, f, fr);
+                       part == 1 ? e.d_metric_sums : (const double*)nullptr, mom, f);
     CESX_HIP(hipGetLastError());
     return CESX_OK;
 }
@@ -787,7 +685,6 @@ int launch_gram_reduce(Engine& e, int part, double* mom, hipStream_t s, hipEvent
 }
 
 int launch_gram(Engine& e, int part, const void* U, const void* G, double* mom, hipStream_t s, bool no_reduce) {
-    if (part == 0) e.fr_mom = nullptr;       // (a new step's moments: the Frobenius partials of the last second launch are stale)
     int rc = e.cfg.dtype == CESX_F32 ? launch_gram_t<float>(e, part, U, G, s) : launch_gram_t<double>(e, part, U, G, s);
     if (rc != CESX_OK || no_reduce) return rc;
     return launch_gram_reduce(e, part, mom, s);
