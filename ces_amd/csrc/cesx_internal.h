@@ -339,7 +339,6 @@ struct Engine {
     void* d_Wfwd_f = nullptr;      // the same map in the fragment-major order of the LDS-DMA update kernels (cesx_forward_set_lineal)
     void* d_bfwd = nullptr;        // [rpad] its offset b
     bool  fwd_set = false, fwd_has_b = false;
-    bool  fwd_split_ok = true;     // cesx_forward_apply beside a pending factorisation leaves it a CU (CESX_FWD_SPLIT=0: one launch)
     double *d_A64 = nullptr, *d_b64 = nullptr;   // the installed map in fp64 (n x p, n): cesx_moments_rest_lineal
     double *d_lvec = nullptr;                    // [2][n] c = A s_u + b - s_g and A sa
     // per-kernel profiling (cesx_profile_*)
@@ -409,7 +408,6 @@ struct UpdateOpt {
     int metric_seg = 1;   // K-segment that holds G (data metrics)
     const void* wf = nullptr;  // fragment-major copy of the WHOLE W (fp32): enables the LDS-DMA kernel
     int prof = -1;        // profiling slot (1 = K3) or -1
-    int blk0 = 0, nblk = 0;    // fp32 LDS-DMA kernel only: particle blocks [blk0, blk0 + nblk) of 128 columns (nblk 0: all)
 };
 int launch_update(Engine& e, int out_rows, const void* W, int ktot, const void* bias,
                   const UpdateSrc* src, int nsrc,

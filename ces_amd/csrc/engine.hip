@@ -212,7 +212,6 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
     if (const char* dv = std::getenv("CESX_DEFER_PUBLISH")) e.met_defer_ok = dv[0] != '0';
     if (const char* fv = std::getenv("CESX_FUSE_CENTER")) e.fuse_center_ok = fv[0] != '0';
     if (const char* pv = std::getenv("CESX_POLL_JOIN")) e.poll_join_ok = pv[0] != '0';
-    if (const char* sv = std::getenv("CESX_FWD_SPLIT")) e.fwd_split_ok = sv[0] != '0';
     auto fail = [&](int rc) { g_create_err = e.err; cesx_destroy(reinterpret_cast<cesx_handle>(ep)); return rc; };
     int rc;
     DeviceGuard dg(cfg->device);
@@ -747,32 +746,8 @@ int cesx_forward_apply(cesx_handle h, const void* U, void* G, void* stream) {
     UpdateSrc src[1] = {{U, e.p, 0, 0}};
     UpdateOpt opt;
     opt.wf = e.d_Wfwd_f;
-    auto go = [&](const UpdateOpt& o) {
-        return launch_update(e, e.n, e.d_Wfwd, e.kp, e.fwd_has_b ? e.d_bfwd : nullptr, src, 1, nullptr, nullptr, 0.0, nullptr,
-                             nullptr, 0.0, G, nullptr, 0, false, o, (hipStream_t)stream);
-    };
-    // A factorisation is waiting on the side stream (the chained loops evaluate the map right behind the U x U reduce):
-    // it needs a CU to itself (8 waves x 256 registers), and 512 workgroups, two on every CU, leave it none -- it starts
-    // when the GEMM has drained, and 100 us of Cholesky sit on the critical path.  Cut where the second Gram launch is
-    // cut -- two workgroups on all but 1 CU in 32 (1 in 8 when the side stream carries more than the one-workgroup
-    // chain), the few blocks left over in a short launch of their own behind -- the factorisation starts when the
-    // first launch drains and runs beside the second one and the moment kernels that follow: 0.460 against 0.476
-    // ms/step in the chained loop at C2.  Measured and dropped: the small launch FIRST (so that the side stream is
-    // resident before the large one fills the chip): 0.50; one workgroup per CU in three launches (8 CUs empty from
-    // the first instant, but a workgroup alone on its CU is slow): 0.472.
-    const int nblk = (int)((e.J + 127) / 128), rows_y = (e.n + 255) / 256;
-    const bool slim_side = e.J == e.Jg && potrf_ld(e.p) <= 256;
-    const int cap = 2 * (e.num_cus - (slim_side ? e.num_cus / 32 : e.num_cus / 8)) / std::max(rows_y, 1);
-    if (e.chol_inflight && e.fwd_split_ok && e.cfg.dtype == CESX_F32 && e.update_v2 && cap >= 16 && nblk > cap && nblk <= 2 * cap) {
-        UpdateOpt a = opt, b = opt;
-        a.blk0 = 0; a.nblk = cap;
-        b.blk0 = cap; b.nblk = nblk - cap;
-        int rc = go(a);
-        if (rc == CESX_OK) return go(b);
-        if (rc != -1) return rc;
-        // (-1: the LDS-DMA kernel does not take ranges here, nothing was launched -- the whole launch below)
-    }
-    return go(opt);
+    return launch_update(e, e.n, e.d_Wfwd, e.kp, e.fwd_has_b ? e.d_bfwd : nullptr, src, 1, nullptr, nullptr, 0.0, nullptr,
+                         nullptr, 0.0, G, nullptr, 0, false, opt, (hipStream_t)stream);
 }
 
 int cesx_profile_enable(cesx_handle h, int on) {

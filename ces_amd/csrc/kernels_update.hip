@@ -472,7 +472,6 @@ int launch_update(Engine& e, int out_rows, const void* W, int ktot, const void* 
                              absmax_part, metrics, opt, s);
         if (rc != -1) return rc;
     }
-    if (opt.nblk > 0) return -1;          // (a column range is the fp32 LDS-DMA kernel's alone: the caller launches the whole ensemble instead)
     return e.cfg.dtype == CESX_F32
         ? update_t<float>(e, out_rows, W, ktot, bias, src, nsrc, add1, c1, c1_imm, add2, c2, c2_imm, out, absmax_part, step_index, metrics, opt, s)
         : update_t<double>(e, out_rows, W, ktot, bias, src, nsrc, add1, c1, c1_imm, add2, c2, c2_imm, out, absmax_part, step_index, metrics, opt, s);

@@ -47,7 +47,6 @@ struct Upd2Args {
     unsigned int seed_lo, seed_hi, step;
     const float* rowc; double* metric_part; int metric_seg;
     int tri_seg;
-    int blk0;             // first particle block of this launch (a launch may cover a column range of the ensemble: launch_update2)
     int stagger_from;     // workgroups with a linear index >= this start late (see the kernel)
     int stagger_n;        // ... by this many s_sleep(100) = 6.4k cycles each
     long long* clk;       // profiled launches only: wave 0 of workgroup (0, 0) writes its {s_memtime, s_memrealtime} ticks
@@ -135,7 +134,7 @@ void update2_kernel(const Upd2Args a) {
         if (lane == 0) { a.clk[0] = c0; a.clk[1] = r0; }
     }
     const int li = lane & 31, lh = lane >> 5;
-    const long long jt0 = (long long)(blockIdx.x + a.blk0) * U2_BN;
+    const long long jt0 = (long long)blockIdx.x * U2_BN;
     const int rc0 = blockIdx.y * U2_RC;
     const int nkt = a.nkt;
     // mirrored pair of row blocks (w, 7 - w): equal work for every wave in the triangular segment
@@ -539,11 +538,6 @@ int launch_update2(Engine& e, int out_rows, const void* Wf, int ktot, const void
     a.metric_part = metrics ? e.d_metric_part : nullptr;
     a.metric_seg = opt.metric_seg;
     dim3 grid((unsigned)((e.J + U2_BN - 1) / U2_BN), (unsigned)((out_rows + U2_RC - 1) / U2_RC));
-    if (opt.nblk > 0) {       // a range of particle blocks (no per-workgroup partial results: their slots are indexed from 0)
-        if (metrics || absmax_part || opt.blk0 < 0 || opt.blk0 + opt.nblk > (int)grid.x) return -1;
-        a.blk0 = opt.blk0;
-        grid.x = (unsigned)opt.nblk;
-    }
     // the dispatcher gives every CU one workgroup before any CU gets its second: from there on start late
     a.stagger_from = (long long)grid.x * grid.y > e.num_cus ? e.num_cus : 0x7fffffff;
     a.stagger_n = 2;

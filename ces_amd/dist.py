@@ -209,8 +209,12 @@ class ShardedUpdate:
             eng.prefetch_noise(noise_step)
         mom = self._moment_buffer()
         eng.moments_uu_chol(prm, U, U, out=mom)      # (the G argument is not read by the U x U launch)
-        G = forward(U)
+        # the moment kernels FIRST (they need A and the head, not G): they are small, so the side stream's centring and
+        # chol(C) find their CUs while they run, and the forward GEMM behind fills what is left.  With the GEMM first --
+        # 512 workgroups, two on every CU -- the factorisation (8 waves x 256 registers: a CU to itself) started when the
+        # GEMM had drained: 0.477 against 0.457 ms/step at C2
         eng.moments_rest_lineal(mom)
+        G = forward(U)
         self._mom = mom
         return mom, G
 

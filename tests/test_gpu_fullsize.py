@@ -307,27 +307,6 @@ def test_sharded_sampler_single_rank_chain(setup):
     assert len(smp.metrics["t"]) == T
 
 
-def test_forward_map_launch_split_beside_the_factorisation(setup, monkeypatch):
-    """The chained device loop evaluates G = A U right behind the U x U reduce, while chol(C) waits on the side stream
-    for a CU of its own: cesx_forward_apply then launches the particle blocks in two ranges (two workgroups on all
-    but 8 CUs, the rest behind).  Same tiles, same arithmetic: bit-identical to the single launch (CESX_FWD_SPLIT=0)."""
-    import torch
-    from ces_amd.dist import ShardedSampler
-    from ces_amd.utils import lineal
-    engine, prob, U, G, xi = setup
-    outs = []
-    for split in ("1", "0"):
-        monkeypatch.setenv("CESX_FWD_SPLIT", split)
-        eng = engine.Engine(P, N, J, dtype="float32", seed=3)
-        smp = ShardedSampler(eng, P, N, J)
-        smp.T = 3
-        Uf = smp.run(prob["y"], U, lineal(prob["A"]), prob["Gamma"], prob["mu"], prob["sigma"], prob["ustar"],
-                     update="aldi", t_tol=1e9)
-        outs.append((Uf.cpu().numpy().copy(), list(smp.metrics["t"]), list(smp.metrics["bias-data"])))
-    assert np.isfinite(outs[0][0]).all()
-    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2]
-
-
 @pytest.mark.parametrize("dtype,tol", [("float64", 1e-6), ("float32", 1e-3)])
 def test_c5_dimensions_p512(dtype, tol):
     """BASELINE.json configs[4] dimensions (d = 512, n_obs = 512; ALDI, on-device Cholesky
