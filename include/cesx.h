@@ -113,7 +113,10 @@ typedef struct cesx_step_result {
        collective is needed.  On one device the values above are already complete. */
     double  lag_bias_data;
     double  lag_self_bias_data;
-    int32_t status;          /* CESX_OK, CESX_ENOTPD or CESX_ENOCONV for this step   */
+    int32_t status;          /* CESX_OK, CESX_ENOTPD or CESX_ENOCONV for this step; CESX_EHIP:
+                                the side stream's factorisation never signalled (one device:
+                                its completion is a polled word, bounded; CESX_POLL_JOIN=0 joins
+                                with an event instead)                                */
     int32_t reserved;
 } cesx_step_result;
 
