@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """dev tool: A/B of engine build-time switches (environment variables read by cesx_create) in ONE process.
 
-    python tools/ab_env.py "CESX_POLL_JOIN=0" "" "CESX_NOISE_WGS=1024,CESX_NOISE_LDS=40960" [--rounds 3 --steps 400]
+    python tools/ab_env.py "CESX_POLL_JOIN=0" "" "CESX_NOISE_LOOKAHEAD=0,CESX_K2_SPLIT=1" [--rounds 3 --steps 400]
 
 One engine per configuration (the variables are set only while that engine is created), the C2 step driven as in
 bench.py (pipelined begin / finish / result over a ring of 4 resident batches), the configurations interleaved
 round by round so that clock drift hits all of them alike.  Prints per configuration: ms/step of every round and
-the Gram-end -> K3-start gap of gap-only sampled steps.
+the Gram-end -> K3-start gap of gap-only sampled steps, K1 / K3 by kernel-bound events.  At most four configurations:
+HIP multiplexes the streams of a priority level onto four hardware queues, a fifth engine's side stream shares one.
 """
 import argparse
 import json
