@@ -513,14 +513,16 @@ def main():
     # ShardedSampler.run is: begin(i+1) is enqueued before result(i) is read, so the host's read
     # overlaps the next Gram instead of idling the GPU.  Every timed step still does all of its
     # work inside the timed region, and every result is read.
-    # HIP events around K1 / K3 are barrier packets: a step whose launches are bracketed by them runs ~110 us
-    # longer (0.56 against 0.45 ms; the event records serialise the side stream's Cholesky behind the Gram launch).
-    # The sampled step is inside the timed region, so exactly ONE step of the region -- the middle one -- is
-    # sampled; `roofline.profiled_steps` says so, the rocprofv3 kernel stats under profiles/ are the cross-check.
-    prof = dict(on=False, steps=0, at=-1, gap_at=-2)
+    # A launch that carries kernel-bound start / stop events costs its step 20-30 us (time-stamped dispatch), and the
+    # sampled steps are inside the timed region: so exactly ONE step of the region -- the middle one -- is sampled, and
+    # in it only the DOMINANT kernel's launches carry events (`roofline`, `roofline.profiled_steps`).  The other MFMA
+    # kernel and the Gram-end -> K3-start interval are sampled the same way in an untimed step right before the
+    # warm-up steps (same process, same warmed-up device, 64 + W steps earlier; `roofline.kernels[*].sampled` says
+    # which is which); the rocprofv3 kernel stats under profiles/ are the cross-check for both.
+    prof = dict(on=False, steps=0, at=-1, gap_at=-2, mode=True)
 
-    def prof_mode(i):           # the sampled step: start + stop events on K1 / K3; a second one: the gap's two events only
-        return True if i == prof["at"] else 2 if i == prof["gap_at"] else False
+    def prof_mode(i):           # the sampled step: start + stop events on K1 and / or K3; another one: the gap's two events only
+        return prof["mode"] if i == prof["at"] else 2 if i == prof["gap_at"] else False
 
     def begin(i):
         U, G = batches[i % NB]
@@ -540,6 +542,7 @@ def main():
         sh.finish(prm, U, G, xi=None, out=out)
 
     stamps = []
+    sclk_probe = dict(at=-1, val=None)          # read sysfs sclk at this step of an UNTIMED run: the GPU is busy then
 
     def run_steps(first, count):
         begin(first)
@@ -548,6 +551,8 @@ def main():
             finish(i)
             if i + 1 < first + count:
                 begin(i + 1)
+            if i == sclk_probe["at"]:
+                sclk_probe["val"] = sysfs_sclk()
             res = eng.result()
             stamps.append(time.perf_counter())     # host time at which the result of step i was in hand
             t_hist[0] = res.t_new
@@ -596,19 +601,31 @@ def main():
         if done:
             break
     prewarm_s = time.perf_counter() - t_pre
-    sclk_before = sysfs_sclk()
     t_hist[0] = 0.0
+    # the untimed samples: both MFMA kernels in one step, the gap's two events in another
+    pre_k1 = pre_k3 = (0.0, 0)
+    pre_gap = None
+    if prof["on"]:
+        prof["at"], prof["gap_at"], prof["mode"], prof["steps"] = 24, 28, True, 0
+        run_steps(0, 48)
+        torch.cuda.synchronize()
+        pre_gap = eng.profile_gap()
+        pre_k1, pre_k3 = eng.profile_read(0), eng.profile_read(1)
+        sh.read_collective_ms()
     prof["at"], prof["gap_at"] = -1, -2
+    sclk_probe["at"] = 32
     run_steps(0, 64)                            # (the reads above idled the GPU for a moment: back to work first)
+    sclk_before, sclk_probe["at"] = sclk_probe["val"], -1
     if args.warmup:
         run_steps(0, args.warmup)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    # exactly ONE step of the timed region -- the middle one -- is HIP-event sampled (`roofline.profiled_steps`)
+    # exactly ONE step of the timed region -- the middle one -- is HIP-event sampled, its dominant kernel alone
+    dom_is_k3 = pre_k3[0] >= pre_k1[0]
     prof["steps"] = 0
+    prof["mode"] = 3 if dom_is_k3 else 4
     prof["at"] = args.warmup + args.steps // 2
-    prof["gap_at"] = prof["at"] + 3 if args.steps >= 8 else -2      # (its events come last: cesx_profile_gap reads the newest)
     del stamps[:]
     t0 = time.perf_counter()
     res = run_steps(args.warmup, args.steps)
@@ -624,10 +641,13 @@ def main():
     # device right behind the timed region, and the sysfs sclk samples around it
     sh.sample_collectives = False
     coll_ms = sh.read_collective_ms()
-    gap_ms = eng.profile_gap() if prof["steps"] else None      # end of the second Gram launch -> start of K3, sampled step
+    gap_ms = pre_gap                                            # end of the second Gram launch -> start of K3 (untimed sample)
     k3_clock = eng.profile_clock() if prof["steps"] else None
     calib_tf, calib_ghz = eng.calibrate_mfma(5.0)
-    sclk_after = sysfs_sclk()
+    sclk_probe["at"] = args.warmup + args.steps + 16
+    run_steps(args.warmup + args.steps, 32)     # (untimed: the same steps again, the sysfs clock read while they run)
+    torch.cuda.synchronize()
+    sclk_after, sclk_probe["at"] = sclk_probe["val"], -1
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -637,6 +657,14 @@ def main():
 
     gram_ms, gram_cnt = eng.profile_read(0)
     upd_ms, upd_cnt = eng.profile_read(1)
+    where = {"gram_kernel(K1)": "timed region", "update_kernel(K3)": "timed region"}
+    if prof["steps"]:                           # the kernel that was not sampled inside the timed region: its untimed sample
+        if dom_is_k3:
+            gram_ms, gram_cnt = pre_k1[0] * prof["steps"], pre_k1[1] * prof["steps"]
+            where["gram_kernel(K1)"] = "untimed step right before the warm-up steps"
+        else:
+            upd_ms, upd_cnt = pre_k3[0] * prof["steps"], pre_k3[1] * prof["steps"]
+            where["update_kernel(K3)"] = "untimed step right before the warm-up steps"
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -696,6 +724,7 @@ def main():
                     avg_launch_ms=round(kern[dom]["ms"], 4), profiled_steps=prof["steps"],
                     kernels={k: dict(avg_launch_ms=round(v["ms"], 4), launches_per_step=v["launches"],
                                      tflops=round(v["tflops"], 2), frac=round(v["tflops"] / peak, 4),
+                                     sampled=where[k],
                                      traffic=traffic_tab.get(tkey[k]),
                                      hbm_gbs=(round(traffic_tab[tkey[k]] / (v["ms"] * 1e-3) / 1e9, 1)
                                               if traffic_tab.get(tkey[k]) and v["ms"] > 0 else None))
@@ -727,11 +756,12 @@ def main():
                prewarm_steps=prewarm, prewarm_s=round(prewarm_s, 3), prewarm_window_ms=[round(w, 4) for w in win_ms],
                rccl_nranks=rccl_nranks,
                clock=dict(k3_ghz=round(k3_clock, 4) if k3_clock else None,
-                          k3_how="s_memtime / s_memrealtime of one wave of the HIP-event-sampled update launch inside "
-                                 "the timed region",
+                          k3_how="s_memtime / s_memrealtime of one wave of the last HIP-event-sampled update launch (%s)"
+                                 % where["update_kernel(K3)"],
                           calibration_ghz=round(calib_ghz, 4), sclk_before=sclk_before, sclk_after=sclk_after,
-                          sclk_how="sysfs pp_dpm_sclk level marked current, sampled before the warm-up steps and "
-                                   "after the calibration loop (an instantaneous reading)"),
+                          sclk_how="sysfs pp_dpm_sclk level marked current, read by the host WHILE an untimed run of the "
+                                   "same steps is in flight (an idle GPU reads 100-700 MHz): 32 steps before the warm-up "
+                                   "steps, and 16 steps into a 32-step run behind the timed region and the calibration loop"),
                higher_is_better=True, scaling="weak", vs_baseline=None,
                dtype={"float32": "f32", "float64": "f64"}[dname], data="synthetic",
                config=dict(workload="%s per GPU: synthetic linear-Gaussian forward map, J=%d particles/GPU "
@@ -750,10 +780,11 @@ def main():
                                                   "single" if sh.single_allreduce else "head+tail"),
                                  collectives_per_step=(0 if world == 1 and not rehearse else 1 if sh.single_allreduce else 2),
                                  collective_ms={k: dict(doubles=v[0], ms=round(v[1], 4)) for k, v in coll_ms.items()},
-                                 how="HIP events of a step of their own (3 after the sampled one, nothing else time-stamped in "
-                                     "it): kernel-bound stop of the second Gram launch -> kernel-bound start of K3; "
-                                     "a recorded event pair around each all-reduce on the stream that issues it (the pair "
-                                     "itself adds a few us to the sampled step)"))
+                                 how="the interval: HIP events of an UNTIMED step of their own right before the warm-up steps "
+                                     "(nothing else time-stamped in it): kernel-bound stop of the second Gram launch -> "
+                                     "kernel-bound start of K3; the collectives: a recorded event pair around each all-reduce of "
+                                     "the timed region's sampled step, on the stream that issues it (the pair itself adds a few "
+                                     "us to that step)"))
     if world == 1 and not rehearse and not args.no_extras:
         del batches, out, sh, eng
         torch.cuda.empty_cache()

@@ -343,6 +343,7 @@ struct Engine {
     double *d_lvec = nullptr;                    // [2][n] c = A s_u + b - s_g and A sa
     // per-kernel profiling (cesx_profile_*)
     bool profile = false;
+    int  profile_only = -1;            // cesx_profile_enable(h, 3 / 4): only the update (1) / the moments (0) launches carry events
     bool profile_gap_only = false;     // cesx_profile_enable(h, 2): bind ONLY the stop of the second moments launch and the start of the
                                        // update launch (the gap between them, cesx_profile_gap): a step whose launches carry start AND stop
                                        // events runs ~70 us longer and its gap reads anywhere between 40 and 150 us
@@ -468,6 +469,7 @@ struct ProfScope {
     Engine& e; int which; hipStream_t s; hipEvent_t a = nullptr, b = nullptr; bool bound;
     ProfScope(Engine& e_, int which_, hipStream_t s_, bool bound_ = false) : e(e_), which(which_), s(s_), bound(bound_) {
         if (!e.profile || which < 0) return;
+        if (e.profile_only >= 0 && which != e.profile_only) return;
         if (e.profile_gap_only && !bound) return;         // (recorded pairs are markers on the stream: not in a gap-only step)
         auto get = [&]() { hipEvent_t ev = nullptr; if (!e.prof_pool.empty()) { ev = e.prof_pool.back(); e.prof_pool.pop_back(); } else (void)hipEventCreate(&ev); return ev; };
         // gap-only: the moments launch binds its stop alone, the update launch its start alone (the other stays null)

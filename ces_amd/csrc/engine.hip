@@ -753,8 +753,10 @@ int cesx_forward_apply(cesx_handle h, const void* U, void* G, void* stream) {
 int cesx_profile_enable(cesx_handle h, int on) {
     if (!h) return CESX_EINVAL;
     Engine& e = *reinterpret_cast<Engine*>(h);
+    if (on < 0 || on > 4) { e.err = "cesx_profile_enable: bad mode"; return CESX_EINVAL; }
     e.profile = on != 0;
     e.profile_gap_only = on == 2;
+    e.profile_only = on == 3 ? 1 : on == 4 ? 0 : -1;      // 3: the update launches alone, 4: the moments launches alone
     if (e.profile) {
         SET_DEVICE(e);
         while (e.prof_pool.size() < 512) {        // created up front: no event creation in a timed region

@@ -660,8 +660,10 @@ class Engine:
         return out
 
     def profile_enable(self, on=True):
-        """on: False / True, or 2 = bind only the events cesx_profile_gap needs."""
-        self._check(self.lib.cesx_profile_enable(self._h, 2 if on == 2 and on is not True else int(bool(on))))
+        """on: False / True, 2 = bind only the events cesx_profile_gap needs, 3 / 4 = the update / the moments
+        launches alone."""
+        mode = int(on) if (on is not True and on is not False and on in (2, 3, 4)) else int(bool(on))
+        self._check(self.lib.cesx_profile_enable(self._h, mode))
 
     def profile_read(self, which):
         """(total ms, launches) of kernel 0 = Gram (K1) or 1 = update (K3) since the last read."""

@@ -293,7 +293,9 @@ int cesx_copy_cols_async(cesx_handle h, void* dst, size_t dpitch, const void* sr
    cesx_profile_read synchronises, returns the summed milliseconds and the
    number of launches since the last read, and resets the counters. */
 /* on = 2: "gap-only" -- only the stop of the second moments launch and the start of the update launch are bound
-   (for cesx_profile_gap); such a step contributes nothing to cesx_profile_read. */
+   (for cesx_profile_gap); such a step contributes nothing to cesx_profile_read.
+   on = 3 / 4: only the update / only the moments launches carry events (a time-stamped dispatch costs the step
+   20-30 us: a timed region samples its dominant kernel alone). */
 int cesx_profile_enable(cesx_handle h, int on);
 int cesx_profile_read(cesx_handle h, int which, double* total_ms, int* launches);
 /* Milliseconds from the end of the last profiled moments launch to the start of the last profiled update launch
