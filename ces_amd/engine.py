@@ -189,6 +189,7 @@ class Engine:
             raise ValueError("dtype must be float32 or float64")
         self.torch_dtype = torch.float32 if self.np_dtype == np.dtype("float32") else torch.float64
         self.device = torch.device("cuda", int(device))
+        self._dev_index = int(device)
         cfg = Config()
         cfg.struct_bytes = C.sizeof(Config)
         cfg.p, cfg.n_obs = self.p, self.n_obs
@@ -226,6 +227,11 @@ class Engine:
         raise CesxError(rc, msg)
 
     def _stream(self):
+        # (the raw handle of torch's current stream: ~0.3 us through the C binding, 2 us through the Stream object --
+        #  a step of a small problem is bound by the driving thread, tools/host_call_cost.py)
+        raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        if raw is not None:
+            return C.c_void_p(raw(self._dev_index))
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     # Host arrays cross PCIe through persistent pinned staging buffers in the ENGINE dtype: the
@@ -543,8 +549,7 @@ class Engine:
 
     def moments(self, U, G, out=None):
         mom = torch.empty(self.moments_len(), dtype=torch.float64, device=self.device) if out is None else out
-        with torch.cuda.device(self.device):
-            self._check(self.lib.cesx_moments(self._h, U.data_ptr(), G.data_ptr(), mom.data_ptr(), self._stream()))
+        self._check(self.lib.cesx_moments(self._h, U.data_ptr(), G.data_ptr(), mom.data_ptr(), self._stream()))
         return mom
 
     def moments_uu_len(self):
@@ -557,61 +562,52 @@ class Engine:
     def moments_uu(self, U, G, out=None):
         """U x U part of the moments into the leading moments_uu_len() entries of the buffer."""
         mom = torch.empty(self.moments_len(), dtype=torch.float64, device=self.device) if out is None else out
-        with torch.cuda.device(self.device):
-            self._check(self.lib.cesx_moments_uu(self._h, U.data_ptr(), G.data_ptr(), mom.data_ptr(), self._stream()))
+        self._check(self.lib.cesx_moments_uu(self._h, U.data_ptr(), G.data_ptr(), mom.data_ptr(), self._stream()))
         return mom
 
     def chol_async(self, prm, mom):
         """C = cov(U) and L = chol(C) on the engine's side stream (joined by apply)."""
-        with torch.cuda.device(self.device):
-            self._check(self.lib.cesx_chol_async(self._h, int(prm.update), mom.data_ptr(), self._stream()))
+        self._check(self.lib.cesx_chol_async(self._h, int(prm.update), mom.data_ptr(), self._stream()))
 
     def moments_uu_chol(self, prm, U, G, out=None):
         """moments_uu + chol_async in one call (one device, nothing between the two: cesx_moments_uu_chol)."""
         mom = torch.empty(self.moments_len(), dtype=torch.float64, device=self.device) if out is None else out
-        with torch.cuda.device(self.device):
-            self._check(self.lib.cesx_moments_uu_chol(self._h, int(prm.update), U.data_ptr(), G.data_ptr(),
-                                                      mom.data_ptr(), self._stream()))
+        self._check(self.lib.cesx_moments_uu_chol(self._h, int(prm.update), U.data_ptr(), G.data_ptr(),
+                                                  mom.data_ptr(), self._stream()))
         return mom
 
     def moments_uu_handover(self, U, G, out=None):
         """moments_uu on the current stream, then the engine's side stream waits for it (cesx_moments_uu_handover)."""
         mom = torch.empty(self.moments_len(), dtype=torch.float64, device=self.device) if out is None else out
-        with torch.cuda.device(self.device):
-            self._check(self.lib.cesx_moments_uu_handover(self._h, U.data_ptr(), G.data_ptr(), mom.data_ptr(), self._stream()))
+        self._check(self.lib.cesx_moments_uu_handover(self._h, U.data_ptr(), G.data_ptr(), mom.data_ptr(), self._stream()))
         return mom
 
     def moments_rest(self, U, G, mom):
-        with torch.cuda.device(self.device):
-            self._check(self.lib.cesx_moments_rest(self._h, U.data_ptr(), G.data_ptr(), mom.data_ptr(), self._stream()))
+        self._check(self.lib.cesx_moments_rest(self._h, U.data_ptr(), G.data_ptr(), mom.data_ptr(), self._stream()))
         return mom
 
     def moments_rest_lineal(self, mom):
         """The G part of the moments from the head of ``mom`` and the installed linear map (cesx_moments_rest_lineal)."""
-        with torch.cuda.device(self.device):
-            self._check(self.lib.cesx_moments_rest_lineal(self._h, mom.data_ptr(), self._stream()))
+        self._check(self.lib.cesx_moments_rest_lineal(self._h, mom.data_ptr(), self._stream()))
         return mom
 
     def apply(self, prm, mom, U, G, xi=None, out=None):
         out = self.empty(self.p) if out is None else out
-        with torch.cuda.device(self.device):
-            self._check(self.lib.cesx_apply(self._h, C.byref(prm), mom.data_ptr(), U.data_ptr(), G.data_ptr(),
-                                            None if xi is None else xi.data_ptr(), out.data_ptr(), self._stream()))
+        self._check(self.lib.cesx_apply(self._h, C.byref(prm), mom.data_ptr(), U.data_ptr(), G.data_ptr(),
+                                        None if xi is None else xi.data_ptr(), out.data_ptr(), self._stream()))
         self._keep = (mom, U, G, xi, out)
         return out
 
     def apply_drift(self, prm, mom, U, G, out):
         absmax = torch.empty(1, dtype=torch.float64, device=self.device)
-        with torch.cuda.device(self.device):
-            self._check(self.lib.cesx_apply_drift(self._h, C.byref(prm), mom.data_ptr(), U.data_ptr(),
-                                                  G.data_ptr(), out.data_ptr(), absmax.data_ptr(), self._stream()))
+        self._check(self.lib.cesx_apply_drift(self._h, C.byref(prm), mom.data_ptr(), U.data_ptr(),
+                                              G.data_ptr(), out.data_ptr(), absmax.data_ptr(), self._stream()))
         return absmax
 
     def apply_finish(self, prm, absmax, U, xi, out):
-        with torch.cuda.device(self.device):
-            self._check(self.lib.cesx_apply_finish(self._h, C.byref(prm), absmax.data_ptr(), U.data_ptr(),
-                                                   None if xi is None else xi.data_ptr(), out.data_ptr(),
-                                                   self._stream()))
+        self._check(self.lib.cesx_apply_finish(self._h, C.byref(prm), absmax.data_ptr(), U.data_ptr(),
+                                               None if xi is None else xi.data_ptr(), out.data_ptr(),
+                                               self._stream()))
         self._keep = (absmax, U, xi, out)
         return out
 
@@ -623,8 +619,7 @@ class Engine:
 
     def prefetch_noise(self, step_index):
         """Draw the noise block of ``step_index`` ahead of its update (cesx_prefetch_noise)."""
-        with torch.cuda.device(self.device):
-            self._check(self.lib.cesx_prefetch_noise(self._h, int(step_index), self._stream()))
+        self._check(self.lib.cesx_prefetch_noise(self._h, int(step_index), self._stream()))
 
     def forward_lineal(self, A, U, b=None, out=None):
         A = torch.as_tensor(A).to(device=self.device, dtype=self.torch_dtype).contiguous()
