@@ -251,6 +251,63 @@ void gemm_kernel(int m, int n, int k, double alpha, const double* __restrict__ A
     }
 }
 
+// The same product with K split over the four waves of a workgroup (one 16 x 16 block of C per workgroup): a block's
+// chain of dependent operand loads is k / 32 round trips to L2 (8 at k = 256: the 20 us a 256^3 product took were
+// latency, not arithmetic), a quarter of it per wave here; the four partial blocks are summed through LDS in a fixed
+// order.  For the small n x p x p products of K2 (moments of a linear map, EKS gain, dense Gamma / Sigma).
+__global__ __launch_bounds__(DT)
+void gemm_splitk_kernel(int m, int n, int k, double alpha, const double* __restrict__ A, long long a0, long long a1,
+                        const double* __restrict__ B, long long b0, long long b1, double* Cm, int ldc) {
+    __shared__ double part[3][4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16;
+    const int i = r0 + (lane & 15), j = c0 + (lane & 15), kk = lane >> 4;
+    const bool iok = i < m, jok = j < n;
+    const double* pa = A + (long long)(iok ? i : 0) * a0;
+    const double* pb = B + (long long)(jok ? j : 0) * b1;
+    const int kper = ((k + 3) / 4 + 3) / 4 * 4;          // k-range of a wave, a multiple of the MFMA's 4
+    const int kbeg = wave * kper, kend = kbeg + kper < k ? kbeg + kper : k;
+    constexpr int UN = 8;
+    gemm_d4_t acc = {0.0, 0.0, 0.0, 0.0};
+    double av[2][UN], bv[2][UN];
+    auto load = [&](int buf, int k0) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int kc = k0 + 4 * u + kk;
+            const bool kok = kc < kend;
+            av[buf][u] = (iok && kok) ? pa[(long long)kc * a1] : 0.0;
+            bv[buf][u] = (jok && kok) ? pb[(long long)kc * b0] : 0.0;
+        }
+    };
+    if (kbeg < kend) load(0, kbeg);
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += 4 * UN) {
+        if (k0 + 4 * UN < kend) {
+            if (buf == 0) load(1, k0 + 4 * UN); else load(0, k0 + 4 * UN);
+        }
+        if (buf == 0) {
+#pragma unroll
+            for (int u = 0; u < UN; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0][u], bv[0][u], acc, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int u = 0; u < UN; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1][u], bv[1][u], acc, 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    // C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = r0 + kk + 4 * r;
+        if (row < m && jok) Cm[(size_t)row * ldc + j] = alpha * (((acc[r] + part[0][r][lane]) + part[1][r][lane]) + part[2][r][lane]);
+    }
+}
+
 // out[r] = sum_c A[r][c] x[c]   (one wave per row)
 __global__ __launch_bounds__(DT)
 void matvec_kernel(int rows, int cols, const double* __restrict__ A, const double* __restrict__ x,
@@ -1074,6 +1131,11 @@ static inline dim3 g1(long long len, int bs = 256) { return dim3((unsigned)((len
 
 static int gemm(Engine& e, hipStream_t s, int m, int n, int k, double alpha, const double* A, long long a0,
                 long long a1, const double* B, long long b0, long long b1, double* C) {
+    // (small output, long k: K split over the waves of a workgroup -- a 256^3 product 20 -> see DESIGN.md; else 2 x 2 blocks per workgroup)
+    if (k >= 64 && (long long)((m + 15) / 16) * ((n + 15) / 16) <= 4096)
+        hipLaunchKernelGGL(gemm_splitk_kernel, dim3((n + 15) / 16, (m + 15) / 16), dim3(DT), 0, s, m, n, k, alpha, A, a0,
+                           a1, B, b0, b1, C, n);
+    else
     hipLaunchKernelGGL(gemm_kernel, dim3((n + 31) / 32, (m + 31) / 32), dim3(DT), 0, s, m, n, k, alpha, A, a0,
                        a1, B, b0, b1, C, n, (const double*)nullptr);
     CESX_HIP(hipGetLastError());
