@@ -30,7 +30,39 @@ def short(name):
     return name.split("<")[0].split("(")[0]
 
 
+def traffic_per_step(summary):
+    """HBM bytes per step and kernel from the per-counter summaries.  Every --pmc pass is a run of its own and the
+    benchmark's pre-warm is time-based, so the passes hold DIFFERENT numbers of steps: each counter is normalised by
+    the steps of ITS pass (= the launches of the one-per-step update kernel in that pass)."""
+    steps = {}
+    for k3 in ("update2_kernel", "update3_kernel", "metric_final_kernel"):      # one launch per step
+        if k3 in summary and "FETCH_SIZE" in summary[k3] and "WRITE_SIZE" in summary[k3]:
+            steps = {c: summary[k3][c]["launches"] for c in ("FETCH_SIZE", "WRITE_SIZE")}
+            break
+    per_step = {}
+    for kern, c in summary.items():
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c and steps:
+            f = c["FETCH_SIZE"]["mean_per_launch"] * c["FETCH_SIZE"]["launches"] / steps["FETCH_SIZE"]
+            w = c["WRITE_SIZE"]["mean_per_launch"] * c["WRITE_SIZE"]["launches"] / steps["WRITE_SIZE"]
+            per_step[kern] = int((2 * f + w) * 1024)
+    return per_step
+
+
 def main():
+    if sys.argv[1] == "--retraffic":          # python tools/prof_summary.py --retraffic TAG[:CONFIG]  (from profiles/TAG_pmc_summary.json)
+        tag, _, config = sys.argv[2].partition(":")
+        config = config or "C2"
+        out = os.path.join(ROOT, "profiles")
+        summary = json.load(open(os.path.join(out, tag + "_pmc_summary.json")))
+        tpath = os.path.join(out, "traffic.json")
+        traffic = json.load(open(tpath))
+        per_step = traffic_per_step(summary)
+        per_step["gram_kernel"] = per_step.get("gram2_kernel", 0) + per_step.get("gram_kernel", 0)
+        per_step["_source"] = tag + "_pmc_summary.json"
+        traffic[config] = per_step
+        json.dump(traffic, open(tpath, "w"), indent=1, sort_keys=True)
+        print({k: v for k, v in per_step.items() if isinstance(v, int) and v > 1e6})
+        return
     tag, kdir, pmc_dirs = sys.argv[1], sys.argv[2], sys.argv[3:]
     tag, _, config = tag.partition(":")
     config = config or "C2"
@@ -83,17 +115,7 @@ def main():
                             "of a step, from separate rocprofv3 --pmc passes (gfx950 FETCH_SIZE tallies the 128-B requests of "
                             "wide streaming reads as 64 B, MI355X_MICROARCH.md section HBM); keyed by bench.py --config; "
                             "gram_kernel = both Gram launches of a step (gram2_kernel = the LDS-DMA form)")
-        per_step = {}
-        steps = None
-        for k3 in ("update2_kernel", "update3_kernel", "metric_final_kernel"):      # one launch per step
-            if k3 in summary and "FETCH_SIZE" in summary[k3]:
-                steps = summary[k3]["FETCH_SIZE"]["launches"]
-                break
-        for kern, c in summary.items():
-            if "FETCH_SIZE" in c and "WRITE_SIZE" in c and steps:
-                tot = (2 * c["FETCH_SIZE"]["mean_per_launch"] * c["FETCH_SIZE"]["launches"]
-                       + c["WRITE_SIZE"]["mean_per_launch"] * c["WRITE_SIZE"]["launches"]) * 1024
-                per_step[kern] = int(tot / steps)
+        per_step = traffic_per_step(summary)
         if per_step:
             per_step["gram_kernel"] = per_step.get("gram2_kernel", 0) + per_step.get("gram_kernel", 0)
             # (update_kernel also counts the forward-map launches of the bench set-up: the step's K3 is
