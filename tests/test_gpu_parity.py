@@ -694,6 +694,33 @@ def test_polled_side_stream_join_is_bit_identical(eng_mod, monkeypatch, dtype, p
     assert np.array_equal(outs[4][0], outs[3][0]) and outs[4][1] == outs[3][1]
 
 
+def test_profile_modes_select_the_sampled_kernel(eng_mod):
+    """cesx_profile_enable(h, 3 / 4): only the update / only the moments launches of a step carry kernel-bound events
+    (bench.py samples the dominant kernel alone inside its timed region); 1: both; 2: the gap's two events, which
+    cesx_profile_read does not count."""
+    p, n, J = 128, 96, 8192
+    d = _synthetic(p, n, J, seed=5)
+    eng = eng_mod.Engine(p, n, J, dtype="float32", seed=2)
+    eng.set_problem(d["y"], d["Gamma"], d["mu"], d["sigma"], d["ustar"])
+    U, G = eng.to_device(d["U0"]), eng.to_device(d["G"])
+    ref = None
+    for mode, want in ((1, (2, 1)), (3, (0, 1)), (4, (2, 0)), (2, (0, 0)), (False, (0, 0))):
+        eng.profile_enable(mode)
+        out = eng.step(eng_mod.step_params(update="aldi", step_index=3), U, G, xi=None, recenter=True)
+        res = eng.result()
+        eng.profile_enable(False)
+        gap = eng.profile_gap() if mode in (1, 2) else None
+        k1, k3 = eng.profile_read(0), eng.profile_read(1)
+        assert (k1[1], k3[1]) == want, (mode, k1, k3)
+        assert (k1[0] > 0) == (want[0] > 0) and (k3[0] > 0) == (want[1] > 0)
+        if gap is not None:
+            assert 0 < gap < 5.0
+        key = (out.cpu().numpy().copy(), res.hk)
+        if ref is None:
+            ref = key
+        assert np.array_equal(key[0], ref[0]) and key[1] == ref[1]          # (time stamps do not change the numbers)
+
+
 @pytest.mark.parametrize("update", ["aldi", "eks"])
 def test_pde_model_run_drop_in(eng_mod, update):
     """A ``type == 'pde'`` forward model (Lorenz '63 with carried state W0)
