@@ -372,7 +372,7 @@ struct Engine {
     // ---- the side stream joined through a polled word instead of a barrier packet (round 3, launch_dense) ----
     bool poll_join_ok = true;                     // CESX_POLL_JOIN=0: always join the side stream with the event
     unsigned long long* d_cholflag = nullptr;     // chol_seq of the last factorisation that completed on the side stream, stored by the kernel itself
-    bool chol_signals = false;                    // the factorisation in flight stores that word (one-kernel path, p <= 256)
+    bool chol_signals = false;                    // the factorisation in flight stores that word (its last kernel does)
     unsigned long long evb_waited_seq = 0;        // ... the last one whose ev_b a stream has waited for,
     hipStream_t evb_waited_stream = nullptr;      // and that stream
     int last_update_grid_x = 0, last_update_grid = 0, last_metric_parts = 0;

@@ -1315,7 +1315,7 @@ static int trsm_reg(Engine& e, hipStream_t s, int nr, int nc, const double* A, i
 // completion signal (hipExtLaunchKernel: no separate marker packet on the stream -- a marker costs ~6 us before the
 // next kernel of the stream starts); the blocked path records it behind its last kernel.
 static int potrf(Engine& e, hipStream_t s, int n, const double* A, double* Lp, hipEvent_t stop = nullptr,
-                 unsigned long long* done = nullptr, unsigned long long done_val = 0) {      // done: one-kernel factorisations only (np <= 256)
+                 unsigned long long* done = nullptr, unsigned long long done_val = 0) {      // done: stored by the chain's last kernel
     const int np = potrf_ld(n);
     if (np <= 256) {
         if (stop && !e.ext_events) {
@@ -1337,7 +1337,10 @@ static int potrf(Engine& e, hipStream_t s, int n, const double* A, double* Lp, h
     for (int k0 = 0; k0 < np; k0 += 256) {
         const int nb = std::min(256, np - k0), below = np - k0 - nb;
         double* Lkk = Lp + (size_t)k0 * np + k0;
-        if ((rc = potrf_reg_any(e, s, nb, nb, W + (size_t)k0 * np + k0, Lkk, np, np))) return rc;
+        // (the LAST diagonal block's factorisation is the chain's last kernel: it carries the completion word)
+        const bool last = below == 0;
+        if ((rc = potrf_reg_any(e, s, nb, nb, W + (size_t)k0 * np + k0, Lkk, np, np, nullptr, PotrfCen(),
+                                last ? done : nullptr, done_val))) return rc;
         if (below > 0) {
             double* X = Lp + (size_t)(k0 + nb) * np + k0;
             if ((rc = trsm_reg(e, s, below, nb, W + (size_t)(k0 + nb) * np + k0, np, Lkk, np, X, np))) return rc;
@@ -1580,7 +1583,7 @@ int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s, b
     CESX_HIP(hipGetLastError());
     if ((rc = potrf(e, e.side, p, e.d_C, e.d_L, e.ev_b, e.d_cholflag, e.chol_seq + 1))) return rc;      // ev_b: C, M, ubar, L -- what K2's scalar and assemble kernels read
     }
-    e.chol_signals = potrf_ld(p) <= 256;      // (the blocked factorisation ends in a GEMM launch: the event is its only hand-over)
+    e.chol_signals = true;      // (the one-kernel factorisation, or the last diagonal block of the blocked one, stores the word)
     ++e.chol_seq;
     if (e.xi_want >= 0 && e.d_xi[0]) {
         // noise blocks asked for by cesx_prefetch_noise (cesx_internal.h): this step's, unless the lookahead of an
