@@ -384,7 +384,9 @@ void gram_reduce_kernel(const T* __restrict__ slabs, const int* __restrict__ blk
 // cycles, 3 cycles per staged row (DMA issue, the in-place shift pass), 450 per tile (barrier, loop).
 static double gram_tile_cost(int tile, int blocks, int row_blocks) {
     const double mfma_cyc = tile == 32 ? 16 * 64.0 : 4 * 64.0;      // f32: 32 j / k=2; f64: 16 j / k=4
-    return 1.055 * mfma_cyc * (double)((blocks + 3) / 4) + 450.0 + 3.0 * (double)(row_blocks * tile);
+    // a type that stages more than 60 KiB per tile runs with one address add per fragment read (kernels_gram2.hip, IMM)
+    const double addr = row_blocks * tile * 128 > 60 * 1024 ? 6.0 * (double)((blocks + 3) / 4) * 4.0 : 0.0;
+    return 1.055 * mfma_cyc * (double)((blocks + 3) / 4) + 450.0 + 3.0 * (double)(row_blocks * tile) + addr;
 }
 
 // Slices per type that level the launch: whole tiles per slice, the busiest workgroup (tiles x cost per tile) as
@@ -435,58 +437,90 @@ GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset, 
     pl.own_hi = subset == 1 ? std::min(pbU, pl.nbr) : pl.nbr;
     std::vector<std::vector<std::pair<int, int>>> types;   // blocks (R, C) per type
     if (pl.nbr * tile <= max_rows_lds) {
-        // all rows fit in LDS: chop the row-major lower triangle into equal runs
-        std::vector<std::pair<int, int>> all;
+        // all rows fit in LDS: chop the lower triangle, listed row by row OR column by column, into runs.  Which
+        // listing is the better one depends on the subset: the second launch's blocks (G x U, then G x G) cut by
+        // COLUMNS give types that stage 14 + 10 block rows at C2 (U columns 0-5 | U columns 6-7 and G x G), cut by
+        // rows 13 + 16 -- fewer rows to fetch, to shift and to sum, and no type needs all 16 (the LDS-DMA kernel
+        // then keeps its fragment addresses in registers, kernels_gram2.hip IMM).
+        std::vector<std::pair<int, int>> all_rm, all_cm;
         for (int R = 0; R < pl.nbr; ++R)
             for (int C = 0; C <= R; ++C)
-                if (wanted(R, C)) all.push_back({R, C});
-        const int nt = std::max(std::max(1, min_types), ((int)all.size() + cap - 1) / cap);
+                if (wanted(R, C)) all_rm.push_back({R, C});
+        for (int C = 0; C < pl.nbr; ++C)
+            for (int R = C; R < pl.nbr; ++R)
+                if (wanted(R, C)) all_cm.push_back({R, C});
+        const int nb_all = (int)all_rm.size();
+        const int nt = std::max(std::max(1, min_types), (nb_all + cap - 1) / cap);
         // equal runs, rounded to multiples of 4 blocks: the 4 SIMDs of a workgroup then carry the same
         // number of blocks (the barrier of every J tile waits for the busiest SIMD); the last type
         // takes what is left
-        int per = std::max(1, ((int)all.size() + nt - 1) / nt);
+        int per = std::max(1, (nb_all + nt - 1) / nt);
         if (per > 4) per = std::min(cap / 4 * 4, (per + 3) / 4 * 4);
-        std::vector<int> sizes;
-        for (size_t lo = 0; lo < all.size(); lo += per) sizes.push_back((int)std::min(all.size() - lo, (size_t)per));
+        std::vector<int> sizes0;
+        for (int lo = 0; lo < nb_all; lo += per) sizes0.push_back(std::min(nb_all - lo, per));
         // ... unless another split of the same number of runs packs the launch better: tiles per slice are whole
-        // numbers (at C2 two runs of 52 + 48 blocks over 248 workgroups end at 16 and 18 tiles per slice, the
-        // second 7 % above the mean; 44 + 56 end at 19 and 15, level).  Two- and three-run plans are searched in
-        // steps of 4 blocks with the cost model below.
-        if (sizes.size() >= 2 && sizes.size() <= 3 && !std::getenv("CESX_GRAM_EQUAL_RUNS")) {
-            const int nb_all = (int)all.size();
-            auto eval = [&](const std::vector<int>& sz) {
-                std::vector<double> w;
-                int lo = 0;
-                for (int n_ : sz) {
-                    std::set<int> rws;
-                    for (int q = lo; q < lo + n_; ++q) { rws.insert(all[q].first); rws.insert(all[q].second); }
-                    w.push_back(gram_tile_cost(tile, n_, (int)rws.size()));
-                    lo += n_;
-                }
-                std::vector<int> ns;
-                return gram_level_slices(w, std::max(wg_budget, (int)sz.size()), ntiles, ns);
-            };
-            double best = eval(sizes);
-            std::vector<int> cand(sizes.size());
+        // numbers (at C2 two row-major runs of 52 + 48 blocks over 248 workgroups end at 16 and 18 tiles per slice,
+        // the second 7 % above the mean; 44 + 56 end at 19 and 15, level).  Two- and three-run plans are searched in
+        // steps of 4 blocks with the cost model below, over both listings.
+        // a candidate = (listing, run sizes): its levelled launch time (busiest workgroup) and the block rows all its
+        // workgroups stage per tile (what the launch fetches, shifts and sums); the lightest within 1 % of the fastest wins
+        struct Cand { const std::vector<std::pair<int, int>>* all; std::vector<int> sz; double cost, rows; };
+        auto eval = [&](const std::vector<std::pair<int, int>>& all, const std::vector<int>& sz) {
+            std::vector<double> w;
+            std::vector<int> nrw;
+            int lo = 0;
+            for (int n_ : sz) {
+                std::set<int> rws;
+                for (int q = lo; q < lo + n_; ++q) { rws.insert(all[q].first); rws.insert(all[q].second); }
+                w.push_back(gram_tile_cost(tile, n_, (int)rws.size()));
+                nrw.push_back((int)rws.size());
+                lo += n_;
+            }
+            std::vector<int> ns;
+            Cand c{&all, sz, 0.0, 0.0};
+            c.cost = gram_level_slices(w, std::max(wg_budget, (int)sz.size()), ntiles, ns);
+            for (size_t t = 0; t < sz.size(); ++t) c.rows += (double)nrw[t] * ns[t];
+            return c;
+        };
+        const bool search = sizes0.size() >= 2 && sizes0.size() <= 3 && !std::getenv("CESX_GRAM_EQUAL_RUNS");
+        std::vector<Cand> cands;
+        cands.push_back(eval(all_rm, sizes0));
+        for (const auto* all : {&all_rm, &all_cm}) {
+            if (all == &all_cm && (sizes0.size() < 2 || std::getenv("CESX_GRAM_ROW_MAJOR"))) break;
+            if (all == &all_cm) cands.push_back(eval(*all, sizes0));
+            if (!search) continue;
+            std::vector<int> cand(sizes0.size());
             for (int a = 4; a <= std::min(cap, nb_all - 4); a += 4) {
-                if (sizes.size() == 2) {
+                if (sizes0.size() == 2) {
                     cand = {a, nb_all - a};
                     if (cand[1] > cap) continue;
-                    const double c = eval(cand);
-                    if (c < best * 0.995) { best = c; sizes = cand; }
+                    cands.push_back(eval(*all, cand));
                 } else {
                     for (int b = 4; b <= std::min(cap, nb_all - a - 4); b += 4) {
                         cand = {a, b, nb_all - a - b};
                         if (cand[2] > cap) continue;
-                        const double c = eval(cand);
-                        if (c < best * 0.995) { best = c; sizes = cand; }
+                        cands.push_back(eval(*all, cand));
                     }
                 }
             }
         }
+        size_t pick = 0;
+        {
+            double best = cands[0].cost;
+            for (const Cand& c : cands) best = std::min(best, c.cost);
+            // (the equal-runs row-major plan stays unless something is clearly better: 0.5 % as before, and then the
+            //  lightest of the candidates within 1 % of the fastest)
+            if (best < cands[0].cost * 0.995) {
+                double rows = 1e300;
+                for (size_t i = 0; i < cands.size(); ++i)
+                    if (cands[i].cost <= best * 1.01 && cands[i].rows < rows) { rows = cands[i].rows; pick = i; }
+            }
+        }
+        const std::vector<std::pair<int, int>>* best_all = cands[pick].all;
+        const std::vector<int> sizes = cands[pick].sz;
         size_t lo = 0;
         for (int n_ : sizes) {
-            std::vector<std::pair<int, int>> v(all.begin() + lo, all.begin() + lo + n_);
+            std::vector<std::pair<int, int>> v(best_all->begin() + lo, best_all->begin() + lo + n_);
             types.push_back(v);
             lo += n_;
         }
