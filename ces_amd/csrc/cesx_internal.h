@@ -375,13 +375,6 @@ struct Engine {
     bool chol_signals = false;                    // the factorisation in flight stores that word (its last kernel does)
     unsigned long long evb_waited_seq = 0;        // ... the last one whose ev_b a stream has waited for,
     hipStream_t evb_waited_stream = nullptr;      // and that stream
-    // ---- both parts of the Gram in one launch (round 4, kernels_gram2.hip gram2_fused_kernel) ----
-    unsigned* d_gsync = nullptr;                  // 4 sets of 16 words {arrive, claim, done, -} used in turn, then the 64-bit `ready` word
-    unsigned long long fused_seq = 0;             // fused launches so far (the sequence number `ready` carries)
-    bool fused_ok = true;                         // CESX_GRAM_FUSED=0 switches the fused launch off
-    int side_prio = 0; bool side_has_prio = false;   // priority of the side stream (create_side_stream)
-    bool prio_checked = false, prio_ok = false;   // ... against the last caller's stream asked about (engine.hip stream_below_side)
-    hipStream_t prio_stream = nullptr;
     int last_update_grid_x = 0, last_update_grid = 0, last_metric_parts = 0;
     bool pending = false;
     // single-device fast path: the metric finalisation + publication of the last update rides on the next
@@ -409,10 +402,6 @@ int launch_gram(Engine& e, int part, const void* U, const void* G, double* mom, 
 int launch_gram_reduce(Engine& e, int part, double* mom, hipStream_t s, hipEvent_t stop = nullptr, const MetricFin* fin = nullptr);   // the fp64 slab reduce of that launch (stop: bound to its completion)
 // kernels_gram2.hip (LDS-DMA Gram): CESX_OK, an error, or -1 when the launch does not qualify (caller falls back)
 int launch_gram2(Engine& e, int part, const void* U, const void* G, hipStream_t s);
-// both parts in ONE launch with the U x U head reduced in-kernel (its completion polled by a one-wave kernel this call
-// puts on the side stream): CESX_OK, an error, or -1 when the shapes do not qualify.  The second part's reduce stays a launch.
-int launch_gram2_fused(Engine& e, const void* U, const void* G, double* mom, hipStream_t s, const MetricFin* fin);
-bool gram2_fused_qualifies(Engine& e, const void* U, const void* G);
 int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int phase, hipStream_t s);
 int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s, bool ev_a_bound = false);
 struct UpdateOpt {

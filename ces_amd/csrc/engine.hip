@@ -181,24 +181,8 @@ const char* cesx_last_error(cesx_handle h) {
 static hipError_t create_side_stream(Engine& e) {
     int lo = 0, hi = 0;
     const bool prio = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo;
-    if (prio && hipStreamCreateWithPriority(&e.side, hipStreamNonBlocking, hi) == hipSuccess) {
-        e.side_prio = hi; e.side_has_prio = true;
-        return hipSuccess;
-    }
+    if (prio && hipStreamCreateWithPriority(&e.side, hipStreamNonBlocking, hi) == hipSuccess) return hipSuccess;
     return hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking);
-}
-
-// Kernels of the caller's stream and of the side stream may WAIT for each other inside a launch (the polled join of
-// launch_dense, the fused Gram launch's head) only when the two streams cannot share a hardware queue: HIP maps the
-// streams of one priority level onto a few queues, and a waiter in front of what it waits for in one in-order queue
-// never ends.  True when `s` has a strictly lower priority than the side stream (numerically greater).
-static bool stream_below_side(Engine& e, hipStream_t s) {
-    if (!e.side_has_prio || s == e.side) return false;
-    if (e.prio_checked && s == e.prio_stream) return e.prio_ok;
-    int pr = 0;
-    const bool ok = hipStreamGetPriority(s, &pr) == hipSuccess && pr > e.side_prio;
-    e.prio_checked = true; e.prio_stream = s; e.prio_ok = ok;
-    return ok;
 }
 
 static int create_impl(const cesx_config* cfg, cesx_handle* out) {
@@ -228,7 +212,6 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
     if (const char* dv = std::getenv("CESX_DEFER_PUBLISH")) e.met_defer_ok = dv[0] != '0';
     if (const char* fv = std::getenv("CESX_FUSE_CENTER")) e.fuse_center_ok = fv[0] != '0';
     if (const char* pv = std::getenv("CESX_POLL_JOIN")) e.poll_join_ok = pv[0] != '0';
-    if (const char* gv = std::getenv("CESX_GRAM_FUSED")) e.fused_ok = gv[0] != '0';
     auto fail = [&](int rc) { g_create_err = e.err; cesx_destroy(reinterpret_cast<cesx_handle>(ep)); return rc; };
     int rc;
     DeviceGuard dg(cfg->device);
@@ -334,7 +317,6 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
     DM(e.d_absmax_part, (size_t)update_grid_blocks(e, p) * 8);
     DM(e.d_clk, 4 * 8);
     DM(e.d_cholflag, 128);
-    DM(e.d_gsync, 512);
     DM(e.d_lag, 3 * 8);
     DM(e.d_A64, (size_t)n * p * 8); DM(e.d_b64, n * 8); DM(e.d_lvec, 2 * n * 8);
 #undef DM
@@ -379,7 +361,7 @@ void cesx_destroy(cesx_handle h) {
                     e.gp[1].d_type_hdr, e.gp[1].d_rows, e.gp[1].d_wblk, e.gp[1].d_blk_rc, e.gp[1].d_row_own, e.gp[1].d_slabs, e.gp[1].d_rowsum_part, e.d_sums, e.d_ubar, e.d_gbar, e.d_m, e.d_dg,
                     e.d_wdel, e.d_C, e.d_L, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_Kp, e.d_M, e.d_P, e.d_PK,
                     e.d_t1, e.d_t2, e.d_t3, e.d_t4, e.d_Lp, e.d_lanczos, e.d_mv, e.d_part, e.d_scal, e.d_absmax,
-                    e.d_c0, e.d_absmax_part, e.d_clk, e.d_cholflag, e.d_gsync, e.d_lag, e.d_A64, e.d_b64, e.d_lvec};
+                    e.d_c0, e.d_absmax_part, e.d_clk, e.d_cholflag, e.d_lag, e.d_A64, e.d_b64, e.d_lvec};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     for (int w = 0; w < 2; ++w)
@@ -533,34 +515,6 @@ int cesx_moments_uu_chol(cesx_handle h, int update, const void* U, const void* G
     return launch_chol_async(e, update, mom, s, true);
 }
 
-int cesx_moments_all_chol(cesx_handle h, int update, const void* U, const void* G, double* mom, void* stream) {
-    if (!h) return CESX_EINVAL;
-    Engine& e = *reinterpret_cast<Engine*>(h);
-    TRY(moments_check(e, U, G, mom));
-    if (update < 0 || update > 2) { e.err = "cesx_moments_all_chol: bad argument"; return CESX_EINVAL; }
-    {
-        SET_DEVICE(e);
-        hipStream_t s = (hipStream_t)stream;
-        if (e.fused_ok && e.overlap_chol && e.ext_events && e.J == e.Jg && stream_below_side(e, s) && gram2_fused_qualifies(e, U, G)) {
-            if (e.met_deferred && e.met_stream != s) FLUSH(e);
-            MetricFin f{};
-            const bool ride = e.met_deferred;
-            if (ride) {
-                f = metric_fin_args(e, nullptr, true);
-                f.N = (double)e.Jg;
-                e.met_deferred = false;
-            }
-            TRY(launch_gram2_fused(e, U, G, mom, s, ride ? &f : nullptr));
-            TRY(launch_chol_async(e, update, mom, s, true));      // (the side stream is ordered behind the head by the wait kernel)
-            return launch_gram_reduce(e, 1, mom, s);
-        }
-    }
-    TRY(cesx_moments_uu_chol(h, update, U, G, mom, stream));
-    return cesx_moments_rest(h, U, G, mom, stream);
-}
-
-unsigned long long cesx_debug_fused_launches(cesx_handle h) { return h ? reinterpret_cast<Engine*>(h)->fused_seq : 0; }
-
 int cesx_moments_rest(cesx_handle h, const void* U, const void* G, double* mom, void* stream) {
     if (!h) return CESX_EINVAL;
     Engine& e = *reinterpret_cast<Engine*>(h);
@@ -676,12 +630,9 @@ int cesx_step(cesx_handle h, const cesx_step_params* prm, const void* U, const v
     if (!xi && e.overlap_chol) TRY(cesx_prefetch_noise(h, prm->step_index, stream));
     // U x U moments -> chol(C) on the side stream, beside the rest of the Gram -> apply.  (Putting the
     // U x U launch itself on the side stream too was measured slower: see ces_amd/dist.py.)
-    if (e.overlap_chol) {
-        TRY(cesx_moments_all_chol(h, prm->update, U, G, e.d_mom, stream));
-    } else {
-        TRY(cesx_moments_uu(h, U, G, e.d_mom, stream));
-        TRY(cesx_moments_rest(h, U, G, e.d_mom, stream));
-    }
+    if (e.overlap_chol) TRY(cesx_moments_uu_chol(h, prm->update, U, G, e.d_mom, stream));
+    else TRY(cesx_moments_uu(h, U, G, e.d_mom, stream));
+    TRY(cesx_moments_rest(h, U, G, e.d_mom, stream));
     return cesx_apply(h, prm, e.d_mom, U, G, xi, Unext, stream);
 }
 

@@ -177,8 +177,6 @@ class ShardedUpdate:
             with torch.cuda.stream(self._cs):
                 self._all_reduce(mom[:nuu], tag="head")          # N, sum(u - s), S_aa: all chol(C) needs
                 eng.chol_async(prm, mom)
-        elif self.world == 1 and not self._force_collectives and hasattr(eng, "moments_all_chol"):
-            eng.moments_all_chol(prm, U, G, out=mom)     # one device: both parts of the Gram in one launch where the shapes allow
         elif self.world == 1 and not self._force_collectives and hasattr(eng, "moments_uu_chol"):
             eng.moments_uu_chol(prm, U, G, out=mom)  # no collective between the two: one call, no marker packet
             eng.moments_rest(U, G, mom)

@@ -25,7 +25,7 @@ EXPORTS = ("cesx_abi_version", "cesx_create", "cesx_destroy", "cesx_last_error",
            "cesx_moments", "cesx_apply", "cesx_apply_drift", "cesx_apply_finish", "cesx_draw_noise",
            "cesx_forward_lineal", "cesx_debug_dense", "cesx_profile_enable", "cesx_profile_read",
            "cesx_moments_uu_len", "cesx_moments_uu", "cesx_chol_async", "cesx_moments_rest", "cesx_side_stream",
-           "cesx_prefetch_noise", "cesx_forward_set_lineal", "cesx_forward_apply", "cesx_moments_uu_chol", "cesx_moments_all_chol", "cesx_debug_fused_launches", "cesx_moments_uu_handover", "cesx_debug_gram_plan",
+           "cesx_prefetch_noise", "cesx_forward_set_lineal", "cesx_forward_apply", "cesx_moments_uu_chol", "cesx_moments_uu_handover", "cesx_debug_gram_plan",
            "cesx_profile_clock", "cesx_calibrate_mfma", "cesx_profile_gap", "cesx_moments_rest_lineal", "cesx_copy_cols_async")
 
 
@@ -130,9 +130,6 @@ def load_library(path=None):
     lib.cesx_draw_noise.argtypes = [vp, u64, vp, vp]
     lib.cesx_prefetch_noise.argtypes = [vp, u64, vp]
     lib.cesx_moments_uu_chol.argtypes = [vp, C.c_int32, vp, vp, vp, vp]
-    lib.cesx_moments_all_chol.argtypes = [vp, C.c_int32, vp, vp, vp, vp]
-    lib.cesx_debug_fused_launches.argtypes = [vp]
-    lib.cesx_debug_fused_launches.restype = C.c_ulonglong
     lib.cesx_moments_uu_handover.argtypes = [vp, vp, vp, vp, vp]
     lib.cesx_forward_lineal.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.cesx_forward_set_lineal.argtypes = [vp, vp, vp, vp]
@@ -578,18 +575,6 @@ class Engine:
         self._check(self.lib.cesx_moments_uu_chol(self._h, int(prm.update), U.data_ptr(), G.data_ptr(),
                                                   mom.data_ptr(), self._stream()))
         return mom
-
-    def moments_all_chol(self, prm, U, G, out=None):
-        """moments_uu_chol + moments_rest in one call: where the shapes allow, both parts of the Gram as ONE launch with
-        the U x U head reduced inside it (cesx_moments_all_chol); otherwise exactly the two calls."""
-        mom = torch.empty(self.moments_len(), dtype=torch.float64, device=self.device) if out is None else out
-        self._check(self.lib.cesx_moments_all_chol(self._h, int(prm.update), U.data_ptr(), G.data_ptr(),
-                                                   mom.data_ptr(), self._stream()))
-        return mom
-
-    def fused_launches(self):
-        """How many moments_all_chol / step calls took the one-launch form so far."""
-        return int(self.lib.cesx_debug_fused_launches(self._h))
 
     def moments_uu_handover(self, U, G, out=None):
         """moments_uu on the current stream, then the engine's side stream waits for it (cesx_moments_uu_handover)."""

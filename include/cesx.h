@@ -202,19 +202,6 @@ int cesx_moments_rest(cesx_handle h, const void* U_dev, const void* G_dev, doubl
    the hand-over to the side stream is then the U x U reduce kernel's own completion signal instead of a marker
    packet in front of the second Gram launch (~6 us per step at C2).  Same results as the two calls. */
 int cesx_moments_uu_chol(cesx_handle h, int update, const void* U_dev, const void* G_dev, double* mom_dev, void* stream);
-/* cesx_moments_uu_chol + cesx_moments_rest in one call, for an ensemble on ONE device: where the shapes allow (J a
-   multiple of 32 / 16 particles, 16-byte aligned ensembles, every workgroup type staging <= 480 rows) BOTH parts of
-   the Gram run as ONE launch -- each workgroup does its slice of the U x U part first, the fp64 reduce of that part is
-   spread over the workgroups of the same launch, and a one-wave kernel on the engine's side stream polls its
-   completion in front of the centring + chol(C) chain (np.cov / np.linalg.cholesky of ces/calibrate.py:476-478 beside
-   the J x J products of :461-467).  The caller's stream then carries one Gram launch and one reduce launch per step
-   instead of two of each.  Taken only when `stream` has a LOWER priority than the engine's side stream (they must not
-   share a hardware queue); otherwise, and for shapes that do not qualify, the call is exactly the two calls above.
-   Same numbers as the two-call sequence up to the summation order of the U x U reduce (fp64 sums of the same partial
-   blocks, 32 slice parts instead of 8): ~1e-16 relative on the moments, bit-identical from run to run. */
-int cesx_moments_all_chol(cesx_handle h, int update, const void* U_dev, const void* G_dev, double* mom_dev, void* stream);
-/* How many cesx_moments_all_chol / cesx_step calls of this handle took the one-launch form so far (tests, bench). */
-unsigned long long cesx_debug_fused_launches(cesx_handle h);
 /* The sharded form of the same hand-over: cesx_moments_uu on `stream`, after which the engine's SIDE stream waits
    for it (again through the reduce kernel's own completion signal).  The driver then issues the all-reduce of the
    buffer's head and cesx_chol_async on cesx_side_stream(), and goes on with cesx_moments_rest on `stream`: the

@@ -623,7 +623,6 @@ def test_single_device_fast_path_variants_match(eng_mod, monkeypatch, dtype):
         for k in ("CESX_EXT_EVENTS", "CESX_DEFER_PUBLISH", "CESX_NOISE_LOOKAHEAD"):
             monkeypatch.setenv(k, "1" if fast else "0")
         monkeypatch.setenv("CESX_K2_SPLIT", "0" if fast else "1")
-        monkeypatch.setenv("CESX_GRAM_FUSED", "0")      # (the one-launch Gram sums the U x U slabs in another order: its own test below)
         eng = eng_mod.Engine(p, n, J, dtype=dtype, seed=9)
         eng.set_problem(d["y"], d["Gamma"], d["mu"], d["sigma"], d["ustar"])
         sh = ShardedUpdate(eng)
@@ -650,81 +649,6 @@ def test_single_device_fast_path_variants_match(eng_mod, monkeypatch, dtype):
     for o in outs[1:]:
         assert np.array_equal(o[0], outs[0][0])
         assert o[1] == outs[0][1]
-
-
-def _chain(eng_mod, d, p, n, J, dtype, nsteps=5, pipelined=True, stream=None):
-    """A pipelined ALDI chain on one engine (ShardedUpdate.begin / finish as bench.py drives it); returns the engine,
-    the last ensemble, the per-step scalars and the moment buffer of the last step."""
-    import torch
-    from ces_amd.dist import ShardedUpdate
-    eng = eng_mod.Engine(p, n, J, dtype=dtype, seed=9)
-    eng.set_problem(d["y"], d["Gamma"], d["mu"], d["sigma"], d["ustar"])
-    sh = ShardedUpdate(eng)
-    ctx = torch.cuda.stream(stream) if stream is not None else None
-    if ctx is not None:
-        ctx.__enter__()
-    try:
-        U, G = eng.to_device(d["U0"]), eng.to_device(d["G"])
-        bufs = [eng.empty(p), eng.empty(p)]
-        t_last, chain = 0.0, []
-
-        def prm_of(i, t_last):
-            return eng_mod.step_params(update="aldi", first_step=(i == 0), t_len=min(i, 1), t_last=t_last, step_index=i)
-        mom = sh.begin(prm_of(0, 0.0), U, G, recenter=True, noise_step=0)
-        for i in range(nsteps):
-            out = sh.finish(prm_of(i, t_last), U, G, xi=None, out=bufs[i % 2])
-            if pipelined and i + 1 < nsteps:
-                mom = sh.begin(prm_of(i + 1, 0.0), out, G, noise_step=i + 1)
-            res = sh.result()
-            if not pipelined and i + 1 < nsteps:
-                mom = sh.begin(prm_of(i + 1, 0.0), out, G, noise_step=i + 1)
-            t_last = res.t_new
-            chain.append((res.hk, res.t_new, res.bias, res.self_bias, res.bias_data, res.self_bias_data))
-            U = out
-        torch.cuda.synchronize()
-        return eng, U.cpu().numpy().copy(), np.array(chain), mom.cpu().numpy().copy()
-    finally:
-        if ctx is not None:
-            ctx.__exit__(None, None, None)
-
-
-@pytest.mark.parametrize("dtype,p,n,J,tol", [("float32", 256, 256, 16384, 2e-4), ("float32", 128, 96, 8192, 2e-4),
-                                             ("float64", 128, 96, 4096, 1e-9), ("float64", 256, 64, 8192, 1e-9)])
-def test_one_launch_gram_matches_the_two_launch_sequence(eng_mod, monkeypatch, dtype, p, n, J, tol):
-    """Both parts of the Gram as ONE launch (cesx_moments_all_chol: the U x U head reduced inside the launch by its own
-    workgroups, its completion polled from the side stream) against the two-launch sequence (CESX_GRAM_FUSED=0): the
-    same partial blocks summed in fp64 in another fixed order -- moments equal to 1e-13, chains equal to the engine's
-    tolerance; the one-launch form is taken (counter), is bit-identical from run to run, pipelined and step by step."""
-    d = _synthetic(p, n, J, seed=78)
-    monkeypatch.setenv("CESX_GRAM_FUSED", "0")
-    e0, U0, c0, m0 = _chain(eng_mod, d, p, n, J, dtype)
-    assert e0.fused_launches() == 0
-    monkeypatch.setenv("CESX_GRAM_FUSED", "1")
-    e1, U1, c1, m1 = _chain(eng_mod, d, p, n, J, dtype)
-    assert e1.fused_launches() == 5
-    e2, U2, c2, m2 = _chain(eng_mod, d, p, n, J, dtype, pipelined=False)
-    assert np.array_equal(U1, U2) and np.array_equal(c1, c2) and np.array_equal(m1, m2)
-    scale = np.maximum(np.abs(m0), 1e-300)
-    assert np.max(np.abs(m1 - m0) / (scale + np.max(np.abs(m0)) * 1e-3)) < (1e-12 if dtype == "float64" else 1e-4)
-    assert np.max(np.abs(U1 - U0)) <= tol * np.max(np.abs(U0))
-    assert np.allclose(c1, c0, rtol=tol * 10, atol=0)
-
-
-def test_one_launch_gram_is_not_taken_on_a_high_priority_stream(eng_mod):
-    """The one-launch form lets a kernel of the side stream wait for the caller's stream INSIDE a launch: taken only when
-    the two cannot share a hardware queue, i.e. the caller's stream has a lower priority than the engine's side stream.
-    On a high-priority caller stream the call is the two-launch sequence (same numbers as CESX_GRAM_FUSED=0)."""
-    import torch
-    p, n, J = 128, 96, 8192
-    d = _synthetic(p, n, J, seed=79)
-    lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
-    s = torch.cuda.Stream(priority=-1)
-    e_hi, U_hi, c_hi, m_hi = _chain(eng_mod, d, p, n, J, "float32", stream=s)
-    assert e_hi.fused_launches() == 0
-    s2 = torch.cuda.Stream(priority=0)
-    e_lo, U_lo, c_lo, m_lo = _chain(eng_mod, d, p, n, J, "float32", stream=s2)
-    assert e_lo.fused_launches() == 5
-    assert np.max(np.abs(U_hi - U_lo)) <= 2e-4 * np.max(np.abs(U_lo))
 
 
 @pytest.mark.parametrize("dtype,p,n,J", [("float32", 256, 256, 16384), ("float32", 96, 80, 4096), ("float64", 128, 96, 4096),
