@@ -375,6 +375,18 @@ struct Engine {
     bool chol_signals = false;                    // the factorisation in flight stores that word (its last kernel does)
     unsigned long long evb_waited_seq = 0;        // ... the last one whose ev_b a stream has waited for,
     hipStream_t evb_waited_stream = nullptr;      // and that stream
+    // ---- the polled join made safe (round 4) ----
+    int side_prio = 0; bool side_has_prio = false;   // priority of the side stream (cesx_create)
+    bool prio_checked = false, prio_ok = false;   // ... against the last caller's stream asked about (stream_below_side)
+    hipStream_t prio_stream = nullptr;
+    unsigned long long poll_ticks = 200000000ull; // bound of the poll in 100-MHz wall-clock ticks (2 s; CESX_POLL_TIMEOUT_MS)
+    bool last_join_polled = false;                // the last launch_dense joined the side stream through the polled word
+    unsigned long long poll_recoveries = 0;       // steps whose poll ran out and that cesx_result re-ran with chol(C) in line
+    bool in_retry = false;
+    unsigned long long test_drop_signal_at = 0;   // CESX_TEST_DROP_CHOL_SIGNAL (tests): that factorisation does not store its word
+    unsigned long long moments_calls = 0;         // cesx_moments* calls so far (a re-run step tells whether a later one read an unwritten ensemble)
+    struct LastApply { bool valid = false; cesx_step_params prm{}; const double* mom = nullptr; const void *U = nullptr, *G = nullptr, *xi = nullptr;
+                       void* Unext = nullptr; hipStream_t s = nullptr; unsigned long long moments_calls = 0; } last_apply;
     int last_update_grid_x = 0, last_update_grid = 0, last_metric_parts = 0;
     bool pending = false;
     // single-device fast path: the metric finalisation + publication of the last update rides on the next
@@ -403,8 +415,15 @@ int launch_gram_reduce(Engine& e, int part, double* mom, hipStream_t s, hipEvent
 // kernels_gram2.hip (LDS-DMA Gram): CESX_OK, an error, or -1 when the launch does not qualify (caller falls back)
 int launch_gram2(Engine& e, int part, const void* U, const void* G, hipStream_t s);
 int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int phase, hipStream_t s);
+// Kernels of the caller's stream and of the side stream may WAIT for each other inside a launch (the polled join of
+// launch_dense) only when the two streams cannot share a hardware queue: HIP maps the streams of one priority level
+// onto a few queues, and a waiter in front of what it waits for in one in-order queue never ends.  True when `s` has a
+// strictly lower priority than the side stream (a numerically greater one).
+bool stream_below_side(Engine& e, hipStream_t s);
 int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s, bool ev_a_bound = false);
 struct UpdateOpt {
+    const unsigned long long* fault = nullptr;   // != nullptr: the launch leaves `out` untouched when *fault == fault_seq (a polled join that ran out)
+    unsigned long long fault_seq = 0;
     int ldw = 0;          // row stride of W (0: = ktot)
     int metric_seg = 1;   // K-segment that holds G (data metrics)
     const void* wf = nullptr;  // fragment-major copy of the WHOLE W (fp32): enables the LDS-DMA kernel

@@ -142,6 +142,7 @@ int run_update_main(Engine& e, const cesx_step_params& prm, const void* U, const
     UpdateOpt opt;
     opt.prof = 1;
     opt.wf = e.d_Wf;
+    if (e.last_join_polled) { opt.fault = e.d_cholflag + 1; opt.fault_seq = e.chol_seq; }
     int rc = launch_update(e, e.p, e.d_W, e.ktot, e.d_bias, src, 3, nullptr, nullptr, 0.0, nullptr, nullptr, 0.0,
                            Unext, nullptr, prm.step_index, e.diag_gamma, opt, s);
     e.last_metric_parts = e.last_update_grid_x;
@@ -181,7 +182,10 @@ const char* cesx_last_error(cesx_handle h) {
 static hipError_t create_side_stream(Engine& e) {
     int lo = 0, hi = 0;
     const bool prio = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo;
-    if (prio && hipStreamCreateWithPriority(&e.side, hipStreamNonBlocking, hi) == hipSuccess) return hipSuccess;
+    if (prio && hipStreamCreateWithPriority(&e.side, hipStreamNonBlocking, hi) == hipSuccess) {
+        e.side_prio = hi; e.side_has_prio = true;
+        return hipSuccess;
+    }
     return hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking);
 }
 
@@ -212,6 +216,8 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
     if (const char* dv = std::getenv("CESX_DEFER_PUBLISH")) e.met_defer_ok = dv[0] != '0';
     if (const char* fv = std::getenv("CESX_FUSE_CENTER")) e.fuse_center_ok = fv[0] != '0';
     if (const char* pv = std::getenv("CESX_POLL_JOIN")) e.poll_join_ok = pv[0] != '0';
+    if (const char* dv = std::getenv("CESX_TEST_DROP_CHOL_SIGNAL")) e.test_drop_signal_at = (unsigned long long)std::max(0, std::atoi(dv));
+    if (const char* tv = std::getenv("CESX_POLL_TIMEOUT_MS")) e.poll_ticks = (unsigned long long)std::max(1, std::atoi(tv)) * 100000ull;
     auto fail = [&](int rc) { g_create_err = e.err; cesx_destroy(reinterpret_cast<cesx_handle>(ep)); return rc; };
     int rc;
     DeviceGuard dg(cfg->device);
@@ -436,6 +442,7 @@ int cesx_set_shift(cesx_handle h, const double* sums, void* stream) {
 }
 
 static int moments_check(Engine& e, const void* U, const void* G, double* mom) {
+    ++e.moments_calls;
     if (!U || !G || !mom) { e.err = "cesx_moments: null pointer"; return CESX_EINVAL; }
     if (!e.problem_set) { e.err = "cesx_set_problem has not been called"; return CESX_ESTATE; }
     if (!e.shift_valid) { e.err = "no centring shift: call cesx_colsum + cesx_set_shift (or cesx_step with recenter) first"; return CESX_ESTATE; }
@@ -599,6 +606,7 @@ int cesx_apply(cesx_handle h, const cesx_step_params* prm, const double* mom, co
     SET_DEVICE(e);
     FLUSH(e);
     hipStream_t s = (hipStream_t)stream;
+    e.last_apply = Engine::LastApply{true, *prm, mom, U, G, xi, Unext, s, e.moments_calls};
     TRY(launch_dense(e, *prm, mom, 0, s));
     TRY(run_update_main(e, *prm, U, G, xi, Unext, s));
     // (Moving this last small kernel to the side stream was tried: the event record + wait pair costs
@@ -675,6 +683,26 @@ int cesx_result(cesx_handle h, cesx_step_result* out) {
         return CESX_ENOTPD;
     }
     if (sc.status == CESX_EHIP) {
+        // The polled join ran out (kernels_dense.hip): the step wrote NOTHING (no W, no centring shift, U_next untouched).
+        // From here on this engine joins its side stream with the event, and the step is re-run once with chol(C)
+        // in line on the caller's stream (correct whatever the side stream is doing).
+        e.poll_join_ok = false;
+        if (e.last_apply.valid && !e.in_retry && e.last_join_polled) {
+            const Engine::LastApply la = e.last_apply;
+            e.in_retry = true;
+            e.chol_inflight = false;
+            int rc = cesx_apply(h, &la.prm, la.mom, la.U, la.G, la.xi, la.Unext, (void*)la.s);
+            if (rc == CESX_OK) rc = cesx_result(h, out);
+            e.in_retry = false;
+            if (rc != CESX_OK) return rc;
+            ++e.poll_recoveries;
+            if (e.moments_calls != la.moments_calls) {
+                e.err = "the polled join of the side stream timed out; the step was re-run and its result is valid, but moments "
+                        "enqueued after it were taken of an ensemble that had not been written yet: redo them";
+                return CESX_ESTATE;
+            }
+            return CESX_OK;
+        }
         e.err = "the side stream's factorisation never signalled its completion (the polled join timed out)";
         return CESX_EHIP;
     }
@@ -685,6 +713,8 @@ int cesx_result(cesx_handle h, cesx_step_result* out) {
     }
     return CESX_OK;
 }
+
+unsigned long long cesx_debug_poll_recoveries(cesx_handle h) { return h ? reinterpret_cast<Engine*>(h)->poll_recoveries : 0; }
 
 int cesx_draw_noise(cesx_handle h, uint64_t step_index, void* xi, void* stream) {
     if (!h) return CESX_EINVAL;

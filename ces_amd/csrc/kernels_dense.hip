@@ -64,7 +64,10 @@ void center_kernel(MomView mv, const double* __restrict__ shift, const double* _
                    double* __restrict__ lag,
                    // join != nullptr (the G part on the caller's stream): workgroup 0 ends only when *join >= join_want --
                    // chol(C) has signalled on the side stream -- so that the assembly launch behind needs no barrier packet
-                   const unsigned long long* join = nullptr, unsigned long long join_want = 0) {
+                   const unsigned long long* join = nullptr, unsigned long long join_want = 0,
+                   // a poll that runs out (join_ticks of the 100-MHz wall clock) reports the step as failed AND marks it
+                   // in join[1]: the assembly and update launches behind leave every result of the step untouched then
+                   unsigned long long* fault = nullptr, unsigned long long join_ticks = 0) {
     __shared__ double red[1024 / 64];      // (launched with 256 or, for the U-only part beside a Gram launch, 1024 threads)
     // what & 1: the part that depends on U alone (C, M = C Sigma^{-1}, ubar, tr S_uu, |ubar - u*|^2):
     //           everything chol(C) needs, available before the rest of the Gram is finished
@@ -164,10 +167,14 @@ void center_kernel(MomView mv, const double* __restrict__ shift, const double* _
         if (threadIdx.x == 0) __threadfence();
     }
     if (join != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {      // (one small workgroup waits: chol(C) needs a CU of its own)
-        unsigned spins = 0;
+        const unsigned long long t0 = wall_clock64();
         while (__hip_atomic_load(join, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < join_want) {
             __builtin_amdgcn_s_sleep(16);
-            if (++spins > (1u << 21)) { sc->status = CESX_EHIP; break; }
+            if (wall_clock64() - t0 > join_ticks) {        // bounded in wall time (s_memrealtime), not in spins
+                sc->status = CESX_EHIP;
+                __hip_atomic_store(fault, join_want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
         }
     }
 }
@@ -948,10 +955,18 @@ void finish_aldi_kernel(MomView mv, cesx_step_params prm, const double* part, Sc
                         const double* __restrict__ y, const double* gbar, const double* __restrict__ mu,
                         const double* ubar, const double* __restrict__ gw, int mx, double* __restrict__ mvs,
                         T* __restrict__ W, T* __restrict__ bias, T* __restrict__ shiftT, double* __restrict__ shift64,
-                        T* __restrict__ rowc, T* __restrict__ gbarT, float* __restrict__ Wf) {
+                        T* __restrict__ rowc, T* __restrict__ gbarT, float* __restrict__ Wf,
+                        const unsigned long long* fault, unsigned long long fault_seq) {
     static_assert(DT == NPB, "one partial per thread");
     __shared__ double red[DT / 64];
     const int p = mv.p, n = mv.n, tid = threadIdx.x;
+    // POLLED and the poll in front of this launch ran out: chol(C) is not known to be complete -- nothing of this step is
+    // written (W, the next centring shift, the scalars), the status word says why (the U-only centring of the side stream
+    // may reset it when it runs at last: set again here)
+    if (POLLED && __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fault_seq) {
+        if (blockIdx.x == 0 && tid == 0) sc->status = CESX_EHIP;
+        return;
+    }
     const double N = mv.N();
     // POLLED: the side stream was joined through chol(C)'s signal word (a workgroup of the launch in front waited for
     // it), not through a barrier packet: what that stream wrote is read with agent-scope loads
@@ -1415,6 +1430,15 @@ static int assemble(Engine& e, hipStream_t s, int mode, int ktot, double sw) {
 
 // phase 0: everything for eks / aldi.  phase 1: aldi_constant drift coefficients.
 // phase 2: aldi_constant noise coefficients after hk is known.
+bool stream_below_side(Engine& e, hipStream_t s) {
+    if (!e.side_has_prio || s == e.side) return false;
+    if (e.prio_checked && s == e.prio_stream) return e.prio_ok;
+    int pr = 0;
+    const bool ok = hipStreamGetPriority(s, &pr) == hipSuccess && pr > e.side_prio;
+    e.prio_checked = true; e.prio_stream = s; e.prio_ok = ok;
+    return ok;
+}
+
 int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int phase, hipStream_t s) {
     const int p = e.p, n = e.n, mx = p > n ? p : n;
     const bool f32 = e.cfg.dtype == CESX_F32;
@@ -1444,19 +1468,24 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
     // loads (no queue-level acquire stands between that stream's kernels and it).  Only where nothing else sits between the two and reads those results (ALDI, default time
     // step, diagonal Gamma / Sigma, one device), and only for the one-kernel factorisation that signals.
     const bool can_poll = fused_finish && prm.time_step == CESX_TS_DEFAULT && early && !e.chol_fused_center && e.poll_join_ok &&
-        e.chol_signals && e.diag_gamma && e.diag_sigma && e.J == e.Jg && s != e.side;
+        e.chol_signals && e.diag_gamma && e.diag_sigma && e.J == e.Jg && s != e.side && stream_below_side(e, s);
     const bool polled = can_poll;
     hipLaunchKernelGGL(center_kernel, dim3(NPB), dim3(DT), 0, s, mv, e.d_shift64, e.d_y, e.d_ustar,
                        e.diag_gamma ? e.d_gw : (const double*)nullptr,
                        e.diag_sigma ? e.d_sw : (const double*)nullptr, unbiased, what, e.d_ubar, e.d_gbar,
                        e.d_m, e.d_dg, e.d_C, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_M, e.d_part, e.d_scal, e.d_lag,
                        polled ? (const unsigned long long*)e.d_cholflag : (const unsigned long long*)nullptr,
-                       (unsigned long long)e.chol_seq);
+                       (unsigned long long)e.chol_seq, e.d_cholflag + 1, e.poll_ticks);
     CESX_HIP(hipGetLastError());
+    e.last_join_polled = polled;
     if (!early)
         if ((rc = potrf(e, s, p, e.d_C, e.d_L))) return rc;
     if (early) {
         if (!polled) CESX_HIP(hipStreamWaitEvent(s, e.ev_b, 0));
+        // (polled: no queue-level wait was issued, but the launches behind are ordered behind chol(C) all the same -- the
+        //  poll ended on its word, or it ran out and they leave the step untouched (the update launch checks the same
+        //  fault word).  A noise block drawn BEFORE this chol(C) on the side stream is therefore complete: take_noise
+        //  relies on exactly that, as it does behind the event.)
         e.evb_waited_seq = e.chol_seq;
         e.evb_waited_stream = s;
         e.chol_inflight = false;
@@ -1495,7 +1524,8 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
                                e.kp, e.kn, e.rpad, e.ktot, (const double*)e.d_M, (const double*)e.d_K, (const double*)e.d_L, potrf_ld(p),
                                (const double*)e.d_y, (const double*)e.d_gbar, (const double*)e.d_mu,
                                (const double*)e.d_ubar, e.diag_gamma ? (const double*)e.d_gw : (const double*)nullptr, mx, e.d_mv, (T*)e.d_W,
-                               (T*)e.d_bias, (T*)e.d_shiftT, e.d_shift64, (T*)e.d_rowc, (T*)e.d_gbarT, (float*)e.d_Wf);
+                               (T*)e.d_bias, (T*)e.d_shiftT, e.d_shift64, (T*)e.d_rowc, (T*)e.d_gbarT, (float*)e.d_Wf,
+                               (const unsigned long long*)(e.d_cholflag + 1), (unsigned long long)e.chol_seq);
         };
         auto pick = [&](auto tag) {
             if (polled) go(tag, std::true_type{});
@@ -1581,7 +1611,9 @@ int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s, b
                        e.diag_sigma ? e.d_sw : (const double*)nullptr, unbiased, 1, e.d_ubar, e.d_gbar,
                        e.d_m, e.d_dg, e.d_C, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_M, e.d_part, e.d_scal, (double*)nullptr);
     CESX_HIP(hipGetLastError());
-    if ((rc = potrf(e, e.side, p, e.d_C, e.d_L, e.ev_b, e.d_cholflag, e.chol_seq + 1))) return rc;      // ev_b: C, M, ubar, L -- what K2's scalar and assemble kernels read
+    // (CESX_TEST_DROP_CHOL_SIGNAL=k, tests only: the k-th factorisation does not store its word -- the polled join of that step runs out)
+    unsigned long long* flag = e.test_drop_signal_at == e.chol_seq + 1 ? nullptr : e.d_cholflag;
+    if ((rc = potrf(e, e.side, p, e.d_C, e.d_L, e.ev_b, flag, e.chol_seq + 1))) return rc;      // ev_b: C, M, ubar, L -- what K2's scalar and assemble kernels read
     }
     e.chol_signals = true;      // (the one-kernel factorisation, or the last diagonal block of the blocked one, stores the word)
     ++e.chol_seq;

@@ -54,11 +54,14 @@ struct UpdArgs {
     // rowc[i] = {gbar_i, y_i, 1/Gamma_ii, 0}; metric_part[block] = {sum q_r^2, sum q_e^2}
     const T* rowc; double* metric_part; int metric_seg;
     int tri_seg;      // K-segment whose W columns are lower triangular (sqrt(2hk) L), -1 if none
+    const unsigned long long* fault; unsigned long long fault_seq;   // fault != nullptr and *fault == fault_seq: leave `out` untouched (UpdateOpt)
 };
 
 template <typename T, bool ALIGNED, int WCT>
 __global__ __launch_bounds__(UPD_THREADS, sizeof(T) == 4 ? 2 : 1)
 void update_kernel(const UpdArgs<T> a) {
+    // a polled join of the side stream that ran out in front of this launch (kernels_dense.hip): W is stale, the output stays as it was
+    if (a.fault != nullptr && __hip_atomic_load(a.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.fault_seq) return;
     using M = Mfma<T>;
     using vec_t = typename M::vec_t;
     using acc_t = typename M::acc_t;
@@ -452,6 +455,7 @@ static int update_t(Engine& e, int out_rows, const void* W, int ktot, const void
     a.rowc = (const T*)e.d_rowc;
     a.metric_part = metrics ? e.d_metric_part : nullptr;
     a.metric_seg = opt.metric_seg;
+    a.fault = opt.fault; a.fault_seq = opt.fault_seq;
     a.tri_seg = -1;
     for (int i = 0; i < nsrc; ++i)
         if (src[i].tri) a.tri_seg = i;

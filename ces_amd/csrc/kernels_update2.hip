@@ -50,6 +50,7 @@ struct Upd2Args {
     int stagger_from;     // workgroups with a linear index >= this start late (see the kernel)
     int stagger_n;        // ... by this many s_sleep(100) = 6.4k cycles each
     long long* clk;       // profiled launches only: wave 0 of workgroup (0, 0) writes its {s_memtime, s_memrealtime} ticks
+    const unsigned long long* fault; unsigned long long fault_seq;   // fault != nullptr and *fault == fault_seq: leave `out` untouched (UpdateOpt)
 };
 
 // wait until at most `n` of this wave's DMAs are outstanding, retire its LDS traffic, barrier
@@ -114,6 +115,8 @@ __device__ __forceinline__ void noise_pair(uint32_t a, uint32_t b, float& z0, fl
 template <bool NOISE>
 __global__ __launch_bounds__(U2_THREADS, 2)
 void update2_kernel(const Upd2Args a) {
+    // a polled join of the side stream that ran out in front of this launch (kernels_dense.hip): W is stale, the output stays as it was
+    if (a.fault != nullptr && __hip_atomic_load(a.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.fault_seq) return;
     using acc_t = Mfma<float>::acc_t;
     typedef float f4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -537,6 +540,7 @@ int launch_update2(Engine& e, int out_rows, const void* Wf, int ktot, const void
     a.rowc = (const float*)e.d_rowc;
     a.metric_part = metrics ? e.d_metric_part : nullptr;
     a.metric_seg = opt.metric_seg;
+    a.fault = opt.fault; a.fault_seq = opt.fault_seq;
     dim3 grid((unsigned)((e.J + U2_BN - 1) / U2_BN), (unsigned)((out_rows + U2_RC - 1) / U2_RC));
     // the dispatcher gives every CU one workgroup before any CU gets its second: from there on start late
     a.stagger_from = (long long)grid.x * grid.y > e.num_cus ? e.num_cus : 0x7fffffff;

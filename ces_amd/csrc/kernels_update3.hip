@@ -42,10 +42,13 @@ struct Upd3Args {
     const double* rowc; double* metric_part; int metric_seg;
     int tri_seg;
     long long* clk;       // profiled launches only: wave 0 of workgroup (0, 0) writes its {s_memtime, s_memrealtime} ticks
+    const unsigned long long* fault; unsigned long long fault_seq;   // fault != nullptr and *fault == fault_seq: leave `out` untouched (UpdateOpt)
 };
 
 __global__ __launch_bounds__(U3_THREADS, 2)
 void update3_kernel(const Upd3Args a) {
+    // a polled join of the side stream that ran out in front of this launch (kernels_dense.hip): W is stale, the output stays as it was
+    if (a.fault != nullptr && __hip_atomic_load(a.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.fault_seq) return;
     using d4 = double __attribute__((ext_vector_type(4)));
     using d2 = double __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -295,6 +298,7 @@ int launch_update3(Engine& e, int out_rows, const void* Wd, int ktot, const void
     a.rowc = (const double*)e.d_rowc;
     a.metric_part = metrics ? e.d_metric_part : nullptr;
     a.metric_seg = opt.metric_seg;
+    a.fault = opt.fault; a.fault_seq = opt.fault_seq;
     dim3 grid((unsigned)((e.J + U3_BN - 1) / U3_BN), (unsigned)((out_rows + U3_RC - 1) / U3_RC));
     CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(update3_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));

@@ -25,7 +25,7 @@ EXPORTS = ("cesx_abi_version", "cesx_create", "cesx_destroy", "cesx_last_error",
            "cesx_moments", "cesx_apply", "cesx_apply_drift", "cesx_apply_finish", "cesx_draw_noise",
            "cesx_forward_lineal", "cesx_debug_dense", "cesx_profile_enable", "cesx_profile_read",
            "cesx_moments_uu_len", "cesx_moments_uu", "cesx_chol_async", "cesx_moments_rest", "cesx_side_stream",
-           "cesx_prefetch_noise", "cesx_forward_set_lineal", "cesx_forward_apply", "cesx_moments_uu_chol", "cesx_moments_uu_handover", "cesx_debug_gram_plan",
+           "cesx_prefetch_noise", "cesx_forward_set_lineal", "cesx_forward_apply", "cesx_moments_uu_chol", "cesx_debug_poll_recoveries", "cesx_moments_uu_handover", "cesx_debug_gram_plan",
            "cesx_profile_clock", "cesx_calibrate_mfma", "cesx_profile_gap", "cesx_moments_rest_lineal", "cesx_copy_cols_async")
 
 
@@ -131,6 +131,8 @@ def load_library(path=None):
     lib.cesx_prefetch_noise.argtypes = [vp, u64, vp]
     lib.cesx_moments_uu_chol.argtypes = [vp, C.c_int32, vp, vp, vp, vp]
     lib.cesx_moments_uu_handover.argtypes = [vp, vp, vp, vp, vp]
+    lib.cesx_debug_poll_recoveries.argtypes = [vp]
+    lib.cesx_debug_poll_recoveries.restype = C.c_ulonglong
     lib.cesx_forward_lineal.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.cesx_forward_set_lineal.argtypes = [vp, vp, vp, vp]
     lib.cesx_forward_apply.argtypes = [vp, vp, vp, vp]
@@ -575,6 +577,10 @@ class Engine:
         self._check(self.lib.cesx_moments_uu_chol(self._h, int(prm.update), U.data_ptr(), G.data_ptr(),
                                                   mom.data_ptr(), self._stream()))
         return mom
+
+    def poll_recoveries(self):
+        """Steps whose polled join of the side stream ran out and that cesx_result re-ran (include/cesx.h)."""
+        return int(self.lib.cesx_debug_poll_recoveries(self._h))
 
     def moments_uu_handover(self, U, G, out=None):
         """moments_uu on the current stream, then the engine's side stream waits for it (cesx_moments_uu_handover)."""

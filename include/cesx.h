@@ -168,6 +168,19 @@ int cesx_step(cesx_handle h, const cesx_step_params* prm, const void* U_dev, con
    copied into engine-owned memory by cesx_apply's own kernels.) */
 int cesx_result(cesx_handle h, cesx_step_result* out);
 
+/* How the caller's stream joins the engine's side stream (centring + chol(C)), and what happens when that goes wrong.
+   One device, ALDI, default time step, diagonal Gamma / Sigma: the join is a word the factorisation stores last and one
+   workgroup of the caller's stream polls -- ONLY when `stream` has a strictly lower priority than the side stream (two
+   streams of one priority level can share a hardware queue, and a waiter queued in front of what it waits for never
+   ends); any other stream is joined with an event.  The poll is bounded in wall time (2 s; CESX_POLL_TIMEOUT_MS).  A poll
+   that runs out marks the step: its assembly and update launches write NOTHING (U_next, the centring shift and the
+   scalars stay as they were), cesx_result switches the engine to the event join for the rest of its life and re-runs
+   the step once with chol(C) in line on the caller's stream.  It then returns CESX_OK -- or CESX_ESTATE when
+   cesx_moments* calls were enqueued after the failed step (a pipelined driver): the re-run step's result and U_next
+   are valid, those moments were taken of an ensemble that had not been written and must be redone.
+   cesx_debug_poll_recoveries: how many steps of this handle were re-run that way. */
+unsigned long long cesx_debug_poll_recoveries(cesx_handle h);
+
 /* ---- split entry points (multi-device, testing) ----------------------- */
 
 /* Length in doubles of the packed moment buffer that is summed across devices:

@@ -694,6 +694,95 @@ def test_polled_side_stream_join_is_bit_identical(eng_mod, monkeypatch, dtype, p
     assert np.array_equal(outs[4][0], outs[3][0]) and outs[4][1] == outs[3][1]
 
 
+def _aldi_chain(eng_mod, d, p, n, J, dtype, nsteps=4, pipelined=False, stream=None, on_error=None):
+    """An ALDI chain on one engine through ShardedUpdate.begin / finish (as bench.py and ShardedSampler drive it).
+    Returns (engine, last ensemble, per-step scalars)."""
+    import torch
+    from ces_amd.dist import ShardedUpdate
+    ctx = torch.cuda.stream(stream) if stream is not None else None
+    if ctx is not None:
+        ctx.__enter__()
+    try:
+        eng = eng_mod.Engine(p, n, J, dtype=dtype, seed=9)
+        eng.set_problem(d["y"], d["Gamma"], d["mu"], d["sigma"], d["ustar"])
+        sh = ShardedUpdate(eng)
+        U, G = eng.to_device(d["U0"]), eng.to_device(d["G"])
+        bufs = [eng.empty(p), eng.empty(p)]
+        t_last, chain = 0.0, []
+
+        def prm_of(i, t_last):
+            return eng_mod.step_params(update="aldi", first_step=(i == 0), t_len=min(i, 1), t_last=t_last, step_index=i)
+        sh.begin(prm_of(0, 0.0), U, G, recenter=True, noise_step=0)
+        for i in range(nsteps):
+            out = sh.finish(prm_of(i, t_last), U, G, xi=None, out=bufs[i % 2])
+            if pipelined and i + 1 < nsteps:
+                sh.begin(prm_of(i + 1, 0.0), out, G, noise_step=i + 1)
+            try:
+                res = sh.result()
+            except eng_mod.CesxError as err:
+                if on_error is None:
+                    raise
+                on_error(err)
+                res = sh.result()                                   # (the re-run step's result is valid)
+                if i + 1 < nsteps:
+                    sh.begin(prm_of(i + 1, 0.0), out, G, noise_step=i + 1)     # ... the moments behind it are redone
+            if not pipelined and i + 1 < nsteps:
+                sh.begin(prm_of(i + 1, 0.0), out, G, noise_step=i + 1)
+            t_last = res.t_new
+            chain.append((res.hk, res.t_new, res.bias, res.self_bias, res.bias_data, res.self_bias_data))
+            U = out
+        torch.cuda.synchronize()
+        return eng, U.cpu().numpy().copy(), np.array(chain)
+    finally:
+        if ctx is not None:
+            ctx.__exit__(None, None, None)
+
+
+def test_polled_join_that_runs_out_leaves_the_step_untouched_and_is_rerun(eng_mod, monkeypatch):
+    """The polled join of the side stream (launch_dense) is bounded in wall time.  A factorisation that never stores its
+    word (CESX_TEST_DROP_CHOL_SIGNAL: the second one) makes the poll of that step run out: the assembly and update
+    launches write nothing, cesx_result switches the engine to the event join and re-runs the step with chol(C) in line
+    -- the chain is bit-identical to one that never polled (CESX_POLL_JOIN=0); a pipelined driver is told (CESX_ESTATE)
+    that the moments it enqueued behind the failed step must be redone."""
+    p, n, J = 128, 96, 8192
+    d = _synthetic(p, n, J, seed=81)
+    monkeypatch.setenv("CESX_POLL_JOIN", "0")
+    e0, U0, c0 = _aldi_chain(eng_mod, d, p, n, J, "float32")
+    monkeypatch.setenv("CESX_POLL_JOIN", "1")
+    monkeypatch.setenv("CESX_POLL_TIMEOUT_MS", "20")
+    monkeypatch.setenv("CESX_TEST_DROP_CHOL_SIGNAL", "2")
+    e1, U1, c1 = _aldi_chain(eng_mod, d, p, n, J, "float32")
+    assert e1.poll_recoveries() == 1
+    assert np.array_equal(U1, U0) and np.array_equal(c1, c0)
+    seen = []
+    e2, U2, c2 = _aldi_chain(eng_mod, d, p, n, J, "float32", pipelined=True, on_error=seen.append)
+    assert e2.poll_recoveries() == 1 and len(seen) == 1 and "redo" in str(seen[0])
+    assert np.array_equal(U2, U0) and np.array_equal(c2, c0)
+
+
+def test_polled_join_only_below_the_side_streams_priority(eng_mod, monkeypatch):
+    """A waiter in front of what it waits for in one hardware queue never ends, and streams of one priority level may
+    share a queue: the caller's stream polls the factorisation's word only when its priority is strictly lower than the
+    side stream's.  On a high-priority caller stream, and with six engines alive, the chain is bit-identical to the
+    event-joined one (CESX_POLL_JOIN=0) and no poll runs out."""
+    import torch
+    p, n, J = 128, 96, 8192
+    d = _synthetic(p, n, J, seed=82)
+    monkeypatch.setenv("CESX_POLL_JOIN", "0")
+    e0, U0, c0 = _aldi_chain(eng_mod, d, p, n, J, "float32")
+    monkeypatch.setenv("CESX_POLL_JOIN", "1")
+    monkeypatch.setenv("CESX_POLL_TIMEOUT_MS", "200")
+    hi = torch.cuda.Stream(priority=-1)
+    keep = [eng_mod.Engine(p, n, J, dtype="float32", seed=k) for k in range(5)]      # five more engines alive (their side streams too)
+    e1, U1, c1 = _aldi_chain(eng_mod, d, p, n, J, "float32", stream=hi)
+    assert e1.poll_recoveries() == 0
+    assert np.array_equal(U1, U0) and np.array_equal(c1, c0)
+    e2, U2, c2 = _aldi_chain(eng_mod, d, p, n, J, "float32")                         # default stream, six engines alive
+    assert e2.poll_recoveries() == 0
+    assert np.array_equal(U2, U0) and np.array_equal(c2, c0)
+    del keep
+
+
 def test_profile_modes_select_the_sampled_kernel(eng_mod):
     """cesx_profile_enable(h, 3 / 4): only the update / only the moments launches of a step carry kernel-bound events
     (bench.py samples the dominant kernel alone inside its timed region); 1: both; 2: the gap's two events, which
