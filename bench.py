@@ -410,6 +410,32 @@ def darcy_leg(engine, dev_index, J=512, T=2):
                          "update (host-array calling convention), the final forward evaluation")
 
 
+class Platform:
+    """What main() needs of the machine.  The default is the GPU box (one rank per GPU over RCCL).  tests/bench_rehearsal.py
+    substitutes a CPU stand-in -- gloo, the numpy engine of the CPU tests -- to drive the RANK CONTROL FLOW of this file
+    (the pre-warm decision every rank must take alike, the barriers, the max-reduce of the elapsed time, the tear-down of
+    the ranks that do not print) on two processes here, so that the driver's 8-GPU run does not meet it for the first time."""
+    backend = "nccl"
+
+    def device(self, local):
+        torch.cuda.set_device(local)
+        return torch.device("cuda", local)
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+    def modules(self):
+        from ces_amd import build, engine
+        from ces_amd.dist import ShardedUpdate
+        return build.build_lib, engine, ShardedUpdate
+
+    def generator(self, dev):
+        return torch.Generator(device=dev)
+
+
+PLATFORM = Platform()
+
+
 def self_launch(args):
     """No launcher (WORLD_SIZE unset) and --gpus N > 1: start the N ranks as children of this process, which
     has not touched the GPU, relay their output, exit with their status."""
@@ -450,8 +476,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    plat = PLATFORM
+    dev = plat.device(local)
     rehearse = world == 1 and os.environ.get("CESX_FORCE_COLLECTIVES") == "1"   # one-rank run of the N > 1 code path
     rccl_nranks = 0                               # ranks RCCL saw in an actual all-reduce (0: no communicator)
     if world > 1 or rehearse:
@@ -464,23 +490,24 @@ def main():
             if rehearse:
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
                 os.environ.setdefault("MASTER_PORT", "29533")
-                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+                dist.init_process_group(plat.backend, rank=0, world_size=1, device_id=dev)
                 os.environ["CESX_FORCE_COMM_OVERLAP"] = "1"
-            else:
+            elif plat.backend == "nccl":
                 dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(plat.backend)
             one = torch.ones(1, device=dev)
             dist.all_reduce(one)
             rccl_nranks = int(one.item())
-            torch.cuda.synchronize()
+            plat.sync()
         finally:
             sys.stdout.flush()
             os.dup2(saved_out, 1)
             os.close(saved_out)
 
-    from ces_amd import build, engine
-    from ces_amd.dist import ShardedUpdate
+    build_lib, engine, ShardedUpdate = plat.modules()
     if rank == 0:
-        build.build_lib()
+        build_lib()
     if world > 1:
         dist.barrier()
 
@@ -493,7 +520,7 @@ def main():
 
     # resident inputs: ring of distinct synthetic batches, G = A U on device
     NB = 4
-    gen = torch.Generator(device=dev)
+    gen = plat.generator(dev)
     gen.manual_seed(20240 + rank)
     ustar_d = torch.as_tensor(prob["ustar"], device=dev, dtype=eng.torch_dtype)
     batches = []
@@ -502,7 +529,7 @@ def main():
         G = eng.forward_lineal(prob["A"], U)
         batches.append((U, G))
     out = eng.empty(p)
-    torch.cuda.synchronize()
+    plat.sync()
 
     t_hist = [0.0]
     prm0 = engine.step_params(update=args.update)
@@ -584,7 +611,7 @@ def main():
         prof["gap_at"] = 12 if (prewarm == 0 and prof["on"]) else -2
         tb = time.perf_counter()
         run_steps(0, WIN)
-        torch.cuda.synchronize()
+        plat.sync()
         win_ms.append((time.perf_counter() - tb) * 1e3 / WIN)
         if prewarm == 0 and prof["on"]:
             eng.profile_read(0), eng.profile_read(1)
@@ -608,7 +635,7 @@ def main():
     if prof["on"]:
         prof["at"], prof["gap_at"], prof["mode"], prof["steps"] = 24, 28, True, 0
         run_steps(0, 48)
-        torch.cuda.synchronize()
+        plat.sync()
         pre_gap = eng.profile_gap()
         pre_k1, pre_k3 = eng.profile_read(0), eng.profile_read(1)
         sh.read_collective_ms()
@@ -620,7 +647,7 @@ def main():
         run_steps(0, args.warmup)
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    plat.sync()
     # exactly ONE step of the timed region -- the middle one -- is HIP-event sampled, its dominant kernel alone
     dom_is_k3 = pre_k3[0] >= pre_k1[0]
     prof["steps"] = 0
@@ -629,7 +656,7 @@ def main():
     del stamps[:]
     t0 = time.perf_counter()
     res = run_steps(args.warmup, args.steps)
-    torch.cuda.synchronize()
+    plat.sync()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -646,7 +673,7 @@ def main():
     calib_tf, calib_ghz = eng.calibrate_mfma(5.0)
     sclk_probe["at"] = args.warmup + args.steps + 16
     run_steps(args.warmup + args.steps, 32)     # (untimed: the same steps again, the sysfs clock read while they run)
-    torch.cuda.synchronize()
+    plat.sync()
     sclk_after, sclk_probe["at"] = sclk_probe["val"], -1
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)

@@ -387,6 +387,10 @@ struct Engine {
     unsigned long long moments_calls = 0;         // cesx_moments* calls so far (a re-run step tells whether a later one read an unwritten ensemble)
     struct LastApply { bool valid = false; cesx_step_params prm{}; const double* mom = nullptr; const void *U = nullptr, *G = nullptr, *xi = nullptr;
                        void* Unext = nullptr; hipStream_t s = nullptr; unsigned long long moments_calls = 0; } last_apply;
+    // ---- RCCL communicator of a sharded ensemble (comm.hip; nullptr: none) ----
+    void* comm = nullptr;
+    int comm_nranks = 0, comm_rank = 0;
+    unsigned long long comm_calls = 0, comm_doubles = 0;
     int last_update_grid_x = 0, last_update_grid = 0, last_metric_parts = 0;
     bool pending = false;
     // single-device fast path: the metric finalisation + publication of the last update rides on the next

@@ -379,6 +379,7 @@ void cesx_destroy(cesx_handle h) {
     for (hipEvent_t ev : {e.ev_x[0], e.ev_x[1]})
         if (ev) (void)hipEventDestroy(ev);
     if (e.side) (void)hipStreamDestroy(e.side);
+    if (e.comm) (void)cesx_comm_destroy(h);
     for (void* q : e.d_xi)
         if (q) (void)hipFree(q);
     delete &e;

@@ -45,11 +45,12 @@ def shard_range(J, world, rank):
 class ShardedUpdate:
     """Drives one engine (this rank's shard) through sharded steps."""
 
-    def __init__(self, engine, group=None, overlap_comm=None, single_allreduce=None):
+    def __init__(self, engine, group=None, overlap_comm=None, single_allreduce=None, native_comm=None):
         self.engine = engine
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._recentered = False
+        self.native_comm = False          # set below: the all-reduces go through the engine's own RCCL communicator (cesx_allreduce_*)
         # CESX_SINGLE_ALLREDUCE=1 (or single_allreduce=True): the north star's literal form -- ONE all-reduce of the
         # whole moment buffer per step, after the complete Gram, with chol(C) in line behind it (on the critical
         # path).  The default splits the same payload in two (head beside the second Gram launch, then the rest) so
@@ -80,8 +81,33 @@ class ShardedUpdate:
         self._moms, self._mom_idx = None, 0
         # one-rank rehearsal of the multi-GPU path: issue the collectives even though world == 1
         self._force_collectives = dist.is_initialized() and os.environ.get("CESX_FORCE_COLLECTIVES") == "1"
+        # The exchange step behind the C ABI (include/cesx.h, cesx_comm_* / cesx_allreduce_*): on GPUs with the "nccl"
+        # backend the engine gets an RCCL communicator of its own -- rank 0 draws the id, torch.distributed only carries
+        # those 128 bytes to the other ranks -- and every all-reduce of a step is issued by the library on the stream it
+        # belongs to.  torch.distributed stays the path of the CPU (gloo) tests and of CESX_NATIVE_COMM=0.
+        if native_comm is None:
+            native_comm = (os.environ.get("CESX_NATIVE_COMM", "1") != "0" and hasattr(engine, "comm_init")
+                           and isinstance(dev, torch.device) and dev.type == "cuda" and dist.is_initialized()
+                           and dist.get_backend(group) == "nccl" and (self.world > 1 or self._force_collectives))
+        if native_comm:
+            self._init_native_comm()
 
-    def _all_reduce(self, t, op=dist.ReduceOp.SUM, tag="moments"):
+    def _init_native_comm(self):
+        eng = self.engine
+        if eng.comm_nranks() == 0:
+            rank = dist.get_rank(self.group) if dist.is_initialized() else 0
+            box = [eng.comm_unique_id() if rank == 0 else None]
+            if self.world > 1:
+                src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+                dist.broadcast_object_list(box, src=src, group=self.group)
+            eng.comm_init(self.world, rank, box[0])
+        if eng.comm_nranks() != self.world:
+            raise RuntimeError("the engine's communicator spans %d ranks, the process group %d" % (eng.comm_nranks(), self.world))
+        self.native_comm = True
+
+    def _all_reduce(self, t, op=dist.ReduceOp.SUM, tag="moments", mom=None):
+        """``mom``: the whole moment buffer when ``t`` is its head / tail / whole (``tag``) -- the engine's communicator
+        then sums that piece itself (cesx_allreduce_head / _tail / _whole)."""
         if self.world > 1 or self._force_collectives:
             self.n_collectives += 1
             self.collective_doubles += int(t.numel())
@@ -89,7 +115,13 @@ class ShardedUpdate:
             if timed:
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record(torch.cuda.current_stream(t.device))
-            dist.all_reduce(t, op=op, group=self.group)
+            if self.native_comm and t.is_cuda:
+                if mom is not None and tag in ("head", "tail", "whole"):
+                    self.engine.allreduce(mom, part=tag)
+                else:
+                    self.engine.allreduce(t, op="max" if op == dist.ReduceOp.MAX else "sum")
+            else:
+                dist.all_reduce(t, op=op, group=self.group)
             if timed:
                 b.record(torch.cuda.current_stream(t.device))
                 self._coll_events.append((tag, int(t.numel()), a, b))
@@ -151,7 +183,7 @@ class ShardedUpdate:
             # factors C in line (K2 of launch_dense) -- no side stream, no second collective
             eng.moments_uu(U, G, out=mom)             # (= cesx_moments: both Gram launches back to back)
             eng.moments_rest(U, G, mom)
-            self._all_reduce(mom, tag="whole")
+            self._all_reduce(mom, tag="whole", mom=mom)
             self._mom = mom
             return mom
         if self.overlap_comm and not self.side_gram and hasattr(eng, "moments_uu_handover"):
@@ -161,7 +193,7 @@ class ShardedUpdate:
                 self._cs = eng.side_stream()
             eng.moments_uu_handover(U, G, out=mom)
             with torch.cuda.stream(self._cs):
-                self._all_reduce(mom[:nuu], tag="head")          # N, sum(u - s), S_aa: all chol(C) needs
+                self._all_reduce(mom[:nuu], tag="head", mom=mom)  # N, sum(u - s), S_aa: all chol(C) needs
                 eng.chol_async(prm, mom)
             eng.moments_rest(U, G, mom)
         elif self.overlap_comm or self.side_gram:
@@ -175,17 +207,17 @@ class ShardedUpdate:
                 eng.moments_uu(U, G, out=mom)
             eng.moments_rest(U, G, mom)
             with torch.cuda.stream(self._cs):
-                self._all_reduce(mom[:nuu], tag="head")          # N, sum(u - s), S_aa: all chol(C) needs
+                self._all_reduce(mom[:nuu], tag="head", mom=mom)  # N, sum(u - s), S_aa: all chol(C) needs
                 eng.chol_async(prm, mom)
         elif self.world == 1 and not self._force_collectives and hasattr(eng, "moments_uu_chol"):
             eng.moments_uu_chol(prm, U, G, out=mom)  # no collective between the two: one call, no marker packet
             eng.moments_rest(U, G, mom)
         else:
             eng.moments_uu(U, G, out=mom)
-            self._all_reduce(mom[:nuu], tag="head")
+            self._all_reduce(mom[:nuu], tag="head", mom=mom)
             eng.chol_async(prm, mom)                 # C, then L = chol(C) on the side stream ...
             eng.moments_rest(U, G, mom)              # ... beside the rest of the Gram
-        self._all_reduce(mom[nuu:], tag="tail")      # apply() joins the side stream before K2 reads the head
+        self._all_reduce(mom[nuu:], tag="tail", mom=mom)      # apply() joins the side stream before K2 reads the head
         self._mom = mom
         return mom
 

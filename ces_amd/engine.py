@@ -25,7 +25,8 @@ EXPORTS = ("cesx_abi_version", "cesx_create", "cesx_destroy", "cesx_last_error",
            "cesx_moments", "cesx_apply", "cesx_apply_drift", "cesx_apply_finish", "cesx_draw_noise",
            "cesx_forward_lineal", "cesx_debug_dense", "cesx_profile_enable", "cesx_profile_read",
            "cesx_moments_uu_len", "cesx_moments_uu", "cesx_chol_async", "cesx_moments_rest", "cesx_side_stream",
-           "cesx_prefetch_noise", "cesx_forward_set_lineal", "cesx_forward_apply", "cesx_moments_uu_chol", "cesx_debug_poll_recoveries", "cesx_moments_uu_handover", "cesx_debug_gram_plan",
+           "cesx_prefetch_noise", "cesx_forward_set_lineal", "cesx_forward_apply", "cesx_moments_uu_chol", "cesx_debug_poll_recoveries", "cesx_comm_unique_id", "cesx_comm_init", "cesx_comm_destroy", "cesx_comm_nranks",
+           "cesx_comm_stats", "cesx_allreduce_head", "cesx_allreduce_tail", "cesx_allreduce_whole", "cesx_allreduce_sum", "cesx_allreduce_max", "cesx_moments_uu_handover", "cesx_debug_gram_plan",
            "cesx_profile_clock", "cesx_calibrate_mfma", "cesx_profile_gap", "cesx_moments_rest_lineal", "cesx_copy_cols_async")
 
 
@@ -131,6 +132,15 @@ def load_library(path=None):
     lib.cesx_prefetch_noise.argtypes = [vp, u64, vp]
     lib.cesx_moments_uu_chol.argtypes = [vp, C.c_int32, vp, vp, vp, vp]
     lib.cesx_moments_uu_handover.argtypes = [vp, vp, vp, vp, vp]
+    lib.cesx_comm_unique_id.argtypes = [vp]
+    lib.cesx_comm_init.argtypes = [vp, i32, i32, vp]
+    lib.cesx_comm_destroy.argtypes = [vp]
+    lib.cesx_comm_nranks.argtypes = [vp]
+    lib.cesx_comm_stats.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+    for name in ("cesx_allreduce_head", "cesx_allreduce_tail", "cesx_allreduce_whole"):
+        getattr(lib, name).argtypes = [vp, vp, vp]
+    for name in ("cesx_allreduce_sum", "cesx_allreduce_max"):
+        getattr(lib, name).argtypes = [vp, vp, C.c_size_t, vp]
     lib.cesx_debug_poll_recoveries.argtypes = [vp]
     lib.cesx_debug_poll_recoveries.restype = C.c_ulonglong
     lib.cesx_forward_lineal.argtypes = [vp, vp, vp, vp, vp, vp]
@@ -577,6 +587,49 @@ class Engine:
         self._check(self.lib.cesx_moments_uu_chol(self._h, int(prm.update), U.data_ptr(), G.data_ptr(),
                                                   mom.data_ptr(), self._stream()))
         return mom
+
+    # -- the exchange step of a sharded ensemble behind the C ABI (RCCL; include/cesx.h cesx_comm_*) --
+    COMM_ID_BYTES = 128
+
+    def comm_unique_id(self):
+        """Rank 0: the 128-byte id every rank passes to ``comm_init`` (ncclGetUniqueId)."""
+        buf = C.create_string_buffer(self.COMM_ID_BYTES)
+        rc = self.lib.cesx_comm_unique_id(buf)
+        if rc != OK:
+            raise CesxError(rc, "cesx_comm_unique_id failed (librccl.so not loadable?)")
+        return bytes(buf.raw)
+
+    def comm_init(self, nranks, rank, unique_id):
+        """Collective over the ranks: an RCCL communicator on this engine's device (ncclCommInitRank)."""
+        assert len(unique_id) == self.COMM_ID_BYTES
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cesx_comm_init(self._h, int(nranks), int(rank), C.c_char_p(unique_id)))
+
+    def comm_destroy(self):
+        self._check(self.lib.cesx_comm_destroy(self._h))
+
+    def comm_nranks(self):
+        return int(self.lib.cesx_comm_nranks(self._h))
+
+    def comm_stats(self):
+        """(all-reduces issued through the engine's communicator so far, their total payload in doubles)."""
+        a, b = C.c_ulonglong(0), C.c_ulonglong(0)
+        self._check(self.lib.cesx_comm_stats(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def allreduce(self, t, op="sum", part=None):
+        """In-place RCCL all-reduce on the current stream through the engine's communicator.  ``part`` in
+        {"head", "tail", "whole"}: ``t`` is the whole moment buffer and the named piece of it is summed
+        (cesx_allreduce_head / _tail / _whole); otherwise ``t`` is any contiguous float64 device tensor."""
+        assert t.dtype == torch.float64 and t.is_contiguous()
+        if part is not None:
+            fn = {"head": self.lib.cesx_allreduce_head, "tail": self.lib.cesx_allreduce_tail, "whole": self.lib.cesx_allreduce_whole}[part]
+            assert t.numel() == self.moments_len()
+            self._check(fn(self._h, t.data_ptr(), self._stream()))
+        else:
+            fn = self.lib.cesx_allreduce_max if op == "max" else self.lib.cesx_allreduce_sum
+            self._check(fn(self._h, t.data_ptr(), t.numel(), self._stream()))
+        return t
 
     def poll_recoveries(self):
         """Steps whose polled join of the side stream ran out and that cesx_result re-ran (include/cesx.h)."""

@@ -42,6 +42,7 @@ extern "C" {
                                   ces/calibrate.py:446, :487, :526)                      */
 #define CESX_EHIP          3   /* HIP runtime failure                                     */
 #define CESX_ESTATE        4   /* call order violated (e.g. no problem set)              */
+#define CESX_ERCCL         7   /* RCCL failure (cesx_comm_*, cesx_allreduce_*)            */
 #define CESX_ENOCONV       6   /* time_step='spectral': the eigenvalue iteration did not meet
                                   its residual criterion (np.linalg.LinAlgError "Eigenvalues
                                   did not converge", what np.linalg.eigvals of :250 raises)  */
@@ -220,6 +221,34 @@ int cesx_moments_uu_chol(cesx_handle h, int update, const void* U_dev, const voi
    buffer's head and cesx_chol_async on cesx_side_stream(), and goes on with cesx_moments_rest on `stream`: the
    U x U launch has the device to itself, the collective and chol(C) run beside the second launch. */
 int cesx_moments_uu_handover(cesx_handle h, const void* U_dev, const void* G_dev, double* mom_dev, void* stream);
+
+/* ---- the exchange step of a SHARDED ensemble, for callers without torch.distributed ----
+   Rank r of N holds the particle columns [j_offset, j_offset + J_local) (cesx_config); per step the packed fp64 moment
+   buffer is summed over the ranks -- the only data that crosses GPUs -- by RCCL all-reduces over xGMI, issued on the
+   stream the caller names:
+       cesx_comm_unique_id   rank 0 draws the 128-byte id (ncclGetUniqueId) and ships it to the others by any host channel
+       cesx_comm_init        every rank, collectively: ncclCommInitRank on the handle's device
+       cesx_allreduce_head   sum of the leading cesx_moments_uu_len() doubles (N, sum(u - s), S_aa: all chol(C) needs) --
+                             between cesx_moments_uu_handover and cesx_chol_async, on cesx_side_stream()
+       cesx_allreduce_tail   sum of the rest, behind cesx_moments_rest on the caller's stream
+       cesx_allreduce_whole  the north star's literal single all-reduce of the whole buffer (cesx_moments, then this, then
+                             cesx_apply factors C in line)
+       cesx_allreduce_sum / _max   `count` doubles in place: the first step's centring sums (cesx_colsum) and
+                             aldi_constant's max|drift| (ces/calibrate.py:519)
+   All in place on device memory, asynchronous on `stream`.  CESX_ERCCL on an RCCL error (text in cesx_last_error).
+   librccl.so is bound at run time (a process that already holds a copy keeps using it).  ces_amd/dist.py calls these
+   when its engine has a communicator; torch.distributed remains the path of the CPU (gloo) tests. */
+#define CESX_COMM_ID_BYTES 128
+int cesx_comm_unique_id(void* id_out);
+int cesx_comm_init(cesx_handle h, int nranks, int rank, const void* unique_id);
+int cesx_comm_destroy(cesx_handle h);
+int cesx_comm_nranks(cesx_handle h);                                  /* 0: no communicator */
+int cesx_comm_stats(cesx_handle h, unsigned long long* calls, unsigned long long* doubles);   /* all-reduces issued so far, their payload */
+int cesx_allreduce_head(cesx_handle h, double* mom_dev, void* stream);
+int cesx_allreduce_tail(cesx_handle h, double* mom_dev, void* stream);
+int cesx_allreduce_whole(cesx_handle h, double* mom_dev, void* stream);
+int cesx_allreduce_sum(cesx_handle h, double* buf_dev, size_t count, void* stream);
+int cesx_allreduce_max(cesx_handle h, double* buf_dev, size_t count, void* stream);
 
 /* cesx_moments_rest for a LINEAR forward map (utils.lineal, ces/utils.py:25-31) installed with
    cesx_forward_set_lineal, without a pass over G: with g_j = A u_j + b every G-dependent moment of

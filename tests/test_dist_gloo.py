@@ -214,3 +214,31 @@ def test_shard_range_covers_everything():
         assert cuts[0][0] == 0 and cuts[-1][1] == J
         assert all(a[1] == b[0] for a, b in zip(cuts[:-1], cuts[1:]))
         assert max(b - a for a, b in cuts) - min(b - a for a, b in cuts) <= 1
+
+
+def test_bench_rank_control_flow_on_two_gloo_ranks():
+    """bench.py as the driver launches it for N > 1 (``python -m torch.distributed.run --nproc-per-node 2 ... bench.py
+    --gpus 2``), with the platform swapped for the CPU stand-in (tests/bench_rehearsal.py: gloo, the numpy engine): both
+    ranks run the same number of pre-warm windows, pass the barriers, reduce the elapsed time, rank 0 prints ONE JSON
+    line with n_gpus == 2, and both processes end with status 0 -- no hang at the first contact of an 8-GPU run."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, CESX_BENCH_PREWARM_S="0", CESX_BENCH_NOPROF="1", OMP_NUM_THREADS="2", CESX_NATIVE_COMM="0",
+               BENCH_REHEARSAL_ARGS="--p 8 --n 6 --J 64 --dtype float64 --no-cpu-baseline --no-extras")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "bench_rehearsal.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1"]
+    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["value"] > 0
+    assert rec["config"]["J_global"] == 128 and rec["sampled_step"]["collectives_per_step"] == 2
+    assert rec["prewarm_steps"] == 512 and rec["scaling"] == "weak"

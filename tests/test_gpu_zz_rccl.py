@@ -47,7 +47,7 @@ def rccl_one_rank():
     dist.destroy_process_group()
 
 
-def _chain(engine, d, update, p, n, J, steps, monkeypatch, collectives, counter, single=False):
+def _chain(engine, d, update, p, n, J, steps, monkeypatch, collectives, counter, single=False, native=False, stats=None):
     import torch.distributed as dist
     from ces_amd.dist import ShardedUpdate
     if collectives:
@@ -56,6 +56,7 @@ def _chain(engine, d, update, p, n, J, steps, monkeypatch, collectives, counter,
     else:
         monkeypatch.delenv("CESX_FORCE_COLLECTIVES", raising=False)
         monkeypatch.delenv("CESX_FORCE_COMM_OVERLAP", raising=False)
+    monkeypatch.setenv("CESX_NATIVE_COMM", "1" if native else "0")
     real = dist.all_reduce
 
     def counted(t, *a, **k):
@@ -66,6 +67,7 @@ def _chain(engine, d, update, p, n, J, steps, monkeypatch, collectives, counter,
     eng.set_problem(d["y"], d["Gamma"], d["mu"], d["sigma"], d["ustar"])
     sh = ShardedUpdate(eng, single_allreduce=single)
     assert sh.overlap_comm == collectives
+    assert sh.native_comm == (native and collectives)
     U = eng.to_device(d["U0"])
     t_last, chain = 0.0, []
     for i in range(steps):
@@ -76,6 +78,8 @@ def _chain(engine, d, update, p, n, J, steps, monkeypatch, collectives, counter,
         t_last = res.t_new
         chain.append((res.hk, res.t_new, res.bias_data, res.self_bias_data, res.lag_bias_data))
     monkeypatch.setattr(dist, "all_reduce", real)
+    if stats is not None:
+        stats.append((sh.n_collectives, sh.collective_doubles) + (eng.comm_stats() if sh.native_comm else (0, 0)))
     return U.cpu().numpy(), chain
 
 
@@ -93,6 +97,56 @@ def test_one_rank_rccl_path_is_bit_identical(rccl_one_rank, monkeypatch, update)
     assert calls_rccl == [1 + p + n] + per_step * steps    # centring shift once, then head + tail (+ max) per step
     assert np.array_equal(ref[0], got[0])
     assert ref[1] == got[1]
+
+
+@pytest.mark.parametrize("update", ["aldi", "aldi_constant"])
+@pytest.mark.parametrize("single", [False, True])
+def test_one_rank_collectives_behind_the_c_abi(rccl_one_rank, monkeypatch, update, single):
+    """The exchange step behind the C ABI (cesx_comm_init / cesx_allreduce_head / _tail / _whole / _sum / _max,
+    include/cesx.h): the engine's own RCCL communicator -- one rank here, torch.distributed only carries the id --
+    issues every all-reduce of a step on the stream it belongs to.  Bit-identical to the torch.distributed path and to
+    the run without collectives; count and payload of the all-reduces asserted on the library's own counters (both
+    modes: head + tail, and the north star's single all-reduce of the whole buffer)."""
+    from ces_amd import engine
+    p, n, J, steps = 128, 96, 8192, 4
+    d = _problem(p, n, J)
+    st_plain, st_torch, st_native, torch_calls = [], [], [], []
+    ref = _chain(engine, d, update, p, n, J, steps, monkeypatch, False, [], stats=st_plain)
+    viat = _chain(engine, d, update, p, n, J, steps, monkeypatch, True, torch_calls, single=single, stats=st_torch)
+    got = _chain(engine, d, update, p, n, J, steps, monkeypatch, True, [], single=single, native=True, stats=st_native)
+    nuu, nall = 1 + p + p * p, 1 + p + n + p * p + p * n + n * n + 2
+    per_step = ([nall] if single else [nuu, nall - nuu]) + ([1] if update == "aldi_constant" else [])
+    want_calls, want_doubles = 1 + len(per_step) * steps, (1 + p + n) + sum(per_step) * steps
+    assert st_plain[0] == (0, 0, 0, 0)
+    assert st_torch[0] == (want_calls, want_doubles, 0, 0) and torch_calls == [1 + p + n] + per_step * steps
+    assert st_native[0] == (want_calls, want_doubles, want_calls, want_doubles)
+    assert np.array_equal(ref[0], got[0]) and np.array_equal(viat[0], got[0])
+    assert ref[1] == got[1] and viat[1] == got[1]
+
+
+def test_comm_entry_points_check_their_arguments(rccl_one_rank):
+    """cesx_allreduce_* without a communicator -> CESX_ESTATE; a second cesx_comm_init on a handle -> CESX_ESTATE;
+    cesx_comm_destroy twice is harmless."""
+    import torch
+    from ces_amd import engine
+    eng = engine.Engine(16, 8, 256, dtype="float32")
+    t = torch.zeros(eng.moments_len(), dtype=torch.float64, device=eng.device)
+    with pytest.raises(engine.CesxError, match="cesx_comm_init has not been called"):
+        eng.allreduce(t, part="head")
+    uid = eng.comm_unique_id()
+    assert len(uid) == 128 and eng.comm_nranks() == 0
+    eng.comm_init(1, 0, uid)
+    assert eng.comm_nranks() == 1
+    with pytest.raises(engine.CesxError, match="already has a communicator"):
+        eng.comm_init(1, 0, uid)
+    t[:] = 3.0
+    eng.allreduce(t, part="whole")
+    eng.allreduce(t[:5].contiguous(), op="max")
+    torch.cuda.synchronize()
+    assert float(t.min()) == 3.0 and eng.comm_stats() == (2, eng.moments_len() + 5)
+    eng.comm_destroy()
+    eng.comm_destroy()
+    assert eng.comm_nranks() == 0
 
 
 @pytest.mark.parametrize("update", ["aldi", "aldi_constant"])
@@ -156,6 +210,7 @@ def _two_rank_worker(rank, world, port, q):
     smp = ShardedSampler(eng, p, n, J)
     smp.T = T
     U = smp.run(d["y"], d["U0"][:, lo:hi], lineal(d["A"]), d["Gamma"], d["mu"], d["sigma"], d["ustar"], t_tol=1e9)
+    assert eng.comm_nranks() == world and eng.comm_stats()[0] > 0      # the collectives went through the library's own communicator
     gathered = [None] * world
     dist.all_gather_object(gathered, (lo, U.cpu().numpy()))
     if rank == 0:
