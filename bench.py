@@ -359,7 +359,7 @@ def engine_leg(engine, name, p, n, J, dtype, steps, dev_index, prewarm_s=0.6, up
     return rec
 
 
-def darcy_leg(engine, dev_index, J=512, T=2):
+def darcy_leg(engine, dev_index, J=512, T=3):
     """BASELINE.json configs[3] end to end at a J the host finishes in seconds: the host Darcy forward map
     (ces_amd/darcy.py, model_trunc(p=64), 50 observations; the reference's MATLAB map restated, parity unpinned)
     + the GPU update, driven like examples/scripts/darcy-flow.py:43-93 through sampling.run."""
@@ -398,9 +398,11 @@ def darcy_leg(engine, dev_index, J=512, T=2):
     t0 = time.perf_counter()
     eks.run(y_obs, U0, model, Gamma, np.linalg.cholesky(Gamma), t_tol=1e30, trace=False)
     el = time.perf_counter() - t0
-    fwd_s, upd_ms = float(np.mean(fwd)), float(np.median(upd)) * 1e3
+    # (the first call creates the engine and factors Gamma / Sigma: the steady-state call is the last one)
+    fwd_s, upd_ms, upd_first_ms = float(np.mean(fwd)), float(upd[-1]) * 1e3, float(upd[0]) * 1e3
     return dict(J=J, iterations=len(upd), wall_s=round(el, 3), host_forward_s_per_iteration=round(fwd_s, 4),
                 host_forward_ms_per_particle=round(1e3 * fwd_s / J, 4), update_call_ms=round(upd_ms, 4),
+                first_update_call_ms=round(upd_first_ms, 4),
                 forward_share=round(sum(fwd) / el, 4),
                 extrapolated_J8192=dict(host_forward_s_per_iteration=round(fwd_s / J * 8192, 2),
                                         note="one host core, serial G_ens (ces/calibrate.py:123-130); the update of the "
@@ -434,6 +436,64 @@ class Platform:
 
 
 PLATFORM = Platform()
+
+
+def small_j_leg(engine, dev_index, shapes=((64, 50, 512), (256, 50, 768)), calls=40):
+    """The ensemble sizes the reference's own scripts run (examples/scripts/darcy-flow.py:97-105, darcy-flow.ipynb: J in
+    17 .. 768 at p = 64 / 256): one ``eks_update_aldi`` call through the reference's calling convention -- float64 host
+    arrays in, a fresh float64 host array out -- timed in steady state (median of `calls` after a few untimed ones),
+    with the noise drawn on the device and from numpy's global stream (what the reference's CPU path pays too), next
+    to the CPU restatement of ces/calibrate.py:451-490 as written (the J x J form) timed on this box (cpu_baseline leg)."""
+    from ces_amd.calibrate import sampling
+    out = []
+    for (p, n, J) in shapes:
+        rng = np.random.default_rng(5)
+        A = rng.standard_normal((n, p)) / np.sqrt(p)
+        ustar = rng.standard_normal((p, 1))
+        Gamma, sigma, mu = 0.01 * np.eye(n), 100.0 * np.eye(p), np.zeros((p, 1))
+        y = (A @ ustar).ravel() + 0.1 * rng.standard_normal(n)
+        U0 = ustar + rng.standard_normal((p, J))
+        G0 = A @ U0
+        rec = dict(p=p, n_obs=n, J=J)
+        for noise in ("device", "numpy"):
+            eks = sampling(p=p, n_obs=n, J=J)
+            eks.ustar, eks.mu, eks.sigma = ustar, mu, sigma
+            eks.engine_dtype, eks.noise, eks.device, eks.T = "float32", noise, dev_index, 30
+            eks.Uall = [U0, U0]                  # (not the first step: ces/calibrate.py:262)
+            eks._ensure_metrics()
+            eks.metrics["t"].append(0.1)
+            tt = []
+            for it in range(calls + 5):
+                t0 = time.perf_counter()
+                eks.eks_update_aldi(y, U0, G0, Gamma, it)
+                if it >= 5:
+                    tt.append(time.perf_counter() - t0)
+            rec["update_call_ms_%s_noise" % noise] = round(float(np.median(tt)) * 1e3, 4)
+        rec["cpu_literal_step_ms"] = cpu_baseline_small(p, n, J, mu, sigma, ustar, y, U0, G0, Gamma)
+        rec["speedup_vs_cpu_literal"] = round(rec["cpu_literal_step_ms"] / rec["update_call_ms_numpy_noise"], 1)
+        out.append(rec)
+    return dict(cases=out, cores=cpu_share(),
+                how="update_call_ms: median wall time of sampling.eks_update_aldi(y, U0, Geval, Gamma, i) with float64 numpy "
+                    "arrays in and out (set-up unchanged between calls, the engine's problem fingerprint skips it); "
+                    "cpu_literal_step_ms: oracle.literal_step -- ces/calibrate.py:451-490 as written, J x J matrices, numpy "
+                    "on this box's host cores, its noise block drawn outside the timed call; speedup: against the numpy-noise "
+                    "call, the like-for-like one (both sides draw p x J normals from numpy's global stream)")
+
+
+def cpu_baseline_small(p, n, J, mu, sigma, ustar, y, U0, G0, Gamma, reps=5):
+    """CPU baseline leg of small_j_leg: the oracle's literal step (test infrastructure, the CHECKER timed as the CPU
+    reference -- never part of the measured path)."""
+    from oracle import ces_numpy as oc
+    st = oc.OracleState(p, n, J, mu, sigma, ustar)
+    st.metrics["t"].append(0.1)
+    rng = np.random.default_rng(6)
+    tl = []
+    for _ in range(reps):
+        xi = rng.standard_normal((p, J))
+        t0 = time.perf_counter()
+        oc.literal_step(st, y, U0, G0, Gamma, xi, update="aldi")
+        tl.append(time.perf_counter() - t0)
+    return round(float(np.median(tl)) * 1e3, 3)
 
 
 def self_launch(args):
@@ -830,6 +890,7 @@ def main():
                 extra["C4"]["e2e_darcy"] = darcy_leg(engine, local)
             except Exception as ex:             # (scipy missing, ...): the engine legs above still stand
                 extra["C4"]["e2e_darcy"] = dict(error=repr(ex))
+            extra["small_J"] = small_j_leg(engine, local)
             rec["extra"] = extra
         rec["e2e"] = e2e_block(engine, prob, p, n, J, args.dtype, args.update, local)
     if world == 1 and not args.no_cpu_baseline:

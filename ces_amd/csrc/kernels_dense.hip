@@ -1590,6 +1590,8 @@ int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s, b
         }
     }
     int rc;
+    // (round 4: also measured at C4 -- p = 64, where the separate centring launch is a third of the side chain: 0.0844
+    //  against 0.0805 ms/step with it fused, the one workgroup's load phase is the longer way; stays opt-in)
     e.chol_fused_center = e.fuse_center_ok && potrf_ld(p) <= 256;
     if (e.chol_fused_center) {
         // p <= 256 (one register-resident factorisation): the covariance is formed while the kernel loads the raw
