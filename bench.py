@@ -264,6 +264,11 @@ def e2e_block(engine, prob, p, n, J, dtype, update, dev_index):
                               update_call_ms_median=float(np.median(calls)) if calls else None,
                               iteration_ms_pct=pct(iters), update_call_ms_pct=pct(calls), host_forward_ms_pct=pct(fwd_it),
                               forward_calls_per_iteration=per_it,
+                              # where an iteration's time outside the forward map goes (ms per step): the driving thread's
+                              # waits (down0 / down1: first / later blocks of the new ensemble not yet widened; up: G blocks
+                              # not yet cast and enqueued; result: the step's scalars) and the staging thread's own work
+                              driver_waits_ms={k: round(1e3 * v / nst, 3) for k, v in sorted(getattr(eks, "_pipe_times", {}).items())},
+                              stager_work_ms={k: round(1e3 * v / nst, 3) for k, v in sorted(getattr(eks, "_pipe_stage_times", {}).items())},
                               host_threads=nthreads, copy_threads=int(engine.Engine.copy_threads),
                               cgroup_periods_throttled="%d of %d" % (st1.get("nr_throttled", 0) - st0.get("nr_throttled", 0),
                                                                      st1.get("nr_periods", 0) - st0.get("nr_periods", 0)),
@@ -776,7 +781,7 @@ def main():
     cfg_name = "C2" if is_c2 else "C5" if is_c5 else "custom"
     # HBM bytes per step of each kernel from the rocprofv3 PMC passes (profiles/traffic.json, taken on the
     # named config with tools/prof_summary.py; collected in separate --pmc runs as the guide prescribes)
-    traffic_tab = {}
+    traffic_tab, traffic_stale = {}, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath) and cfg_name != "custom":
         try:
@@ -784,13 +789,25 @@ def main():
             traffic_tab = tj.get(cfg_name, tj if cfg_name == "C2" and "gram_kernel" in tj else {})
         except Exception:
             traffic_tab = {}
+        # counters of ANOTHER build of the kernels are not this line's traffic: the table carries the hash of the
+        # kernel sources its profile ran from (tools/prof_summary.py), compared with the tree this run uses
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from prof_summary import kernel_sources_sha
+            have, want = traffic_tab.get("_src_sha16"), kernel_sources_sha()
+            if traffic_tab and have != want:
+                traffic_stale = ("profiles/traffic.json[%s] was taken from kernel sources %s (%s), this tree is %s: refused"
+                                 % (cfg_name, have, traffic_tab.get("_source", "?"), want))
+                traffic_tab = {}
+        except Exception as ex:
+            traffic_stale, traffic_tab = "traffic.json could not be checked against the kernel sources (%r): refused" % (ex,), {}
     k3name = "update2_kernel" if dname == "float32" else ("update3_kernel" if "update3_kernel" in traffic_tab else "update_kernel")
     tkey = {"gram_kernel(K1)": "gram_kernel", "update_kernel(K3)": k3name}
     traffic = traffic_tab.get(tkey[dom])
     step_s = elapsed / args.steps
     esz = np.dtype(args.dtype).itemsize
     alg_bytes = float(esz * (3 * p + 2 * n)) * J               # s (3p + 2n) per particle-update
-    traffic_source = None
+    traffic_source = traffic_stale
     if traffic_tab:
         traffic_source = ("profiles/traffic.json[%s] <- profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an "
                           "EARLIER run of this configuration (2 x FETCH + WRITE, the guide's gfx950 correction), not "

@@ -352,7 +352,7 @@ class sampling(enka):
             if i + 1 < self.T:                                     # first half of the next iteration, ahead of the read
                 ns = None if xis is not None else self._step_counter
                 if fast:
-                    _, G_next = sh.begin_lineal(prm0, U_new, lambda u: model.forward_device(eng, u), noise_step=ns)
+                    _, G_next = sh.begin_lineal(prm0, U_new, lambda u: model.forward_device(eng, u), noise_step=ns, model=model)
                 else:
                     G_next = model.forward_device(eng, U_new)
                     sh.begin(prm0, U_new, G_next, noise_step=ns)
@@ -373,9 +373,16 @@ class sampling(enka):
         self.Gstar = Gfinal[:self.n_obs, :]
         self.Ustar_device, self.Gstar_device = U, G                # build-only: the final ensemble without the D2H copy
 
+    def _updates_overridden(self):
+        """A subclass or the instance replaced ``eks_update*`` / ``G_ens`` hooks the pipelined loop would bypass: the
+        reference's ``run`` calls those methods (ces/calibrate.py:364-369), so the plain loop -- which does -- runs then."""
+        cls = type(self)
+        names = ("eks_update", "eks_update_aldi", "eks_update_aldi_constant", "_device_update")
+        return any(getattr(cls, nm) is not getattr(sampling, nm) or nm in self.__dict__ for nm in names)
+
     def _host_pipeline_ok(self, model, save_online, kwargs):
         big = self.p * self.J >= (1 << 22)              # (small ensembles keep the reference's flow call for call)
-        return (big and getattr(model, "type", None) == "map" and not save_online
+        return (big and getattr(model, "type", None) == "map" and not save_online and not self._updates_overridden()
                 and getattr(self, "host_pipeline", True) and os.environ.get("CESX_HOST_PIPELINE", "1") != "0"
                 and (self.noise == "device" or kwargs.get("xis", None) is not None)
                 and kwargs.get("update", "aldi") in _engine.UPDATES
@@ -387,6 +394,12 @@ class sampling(enka):
 
             block c of U_{i+1} arrives (D2H + widening to float64)  ->  G_ens on that block (host)  ->
             its G rows cross PCIe (cast to the engine dtype, H2D)   ...   update of the whole ensemble
+
+        (Side effect, bounded to the duration of the call: torch's intra-op thread pool -- process-wide -- is sized to the
+        engine's copy threads while the loop runs, because the staging casts run on it beside the forward map's BLAS
+        threads and the two together must not exceed the CPU share; a forward map that itself uses torch CPU ops runs on
+        that many threads.  ``self.host_pipeline_torch_threads = 0`` leaves the pool alone, ``host_pipeline = False``
+        takes the plain loop.)
 
         A helper thread does the staging (widening the arriving blocks, casting and sending the G blocks:
         cesx_copy_cols_async, pinned buffers) while this thread evaluates the forward map, so the host forward map of
@@ -423,6 +436,8 @@ class sampling(enka):
 
         # the staging thread: tasks in FIFO order; an exception is handed back to this thread
         tasks, failure = queue.Queue(), []
+        import time as _time
+        stg = self._pipe_stage_times = {}            # seconds the STAGING thread spent per kind of work (diagnostics, bench.py e2e)
 
         def stager():
             torch.cuda.set_device(dev)
@@ -433,12 +448,21 @@ class sampling(enka):
                 try:
                     kind, c, arr, done, extra = job
                     a, b = cuts[c]
+                    t0 = _time.perf_counter()
                     if kind == "down":               # block c of the new ensemble: wait for its D2H, widen it
                         ev_u[c].synchronize()
+                        t1 = _time.perf_counter()
                         torch.from_numpy(arr)[:, a:b].copy_(pin_u[:, a:b])
+                        t2 = _time.perf_counter()
+                        stg["d2h_wait"] = stg.get("d2h_wait", 0.0) + t1 - t0
+                        stg["widen"] = stg.get("widen", 0.0) + t2 - t1
                     else:                            # block c of G: cast into pinned memory, send it up
                         pin_g[:, a:b].copy_(torch.from_numpy(np.asarray(arr)))
+                        t1 = _time.perf_counter()
                         eng.copy_cols_async(extra, pin_g, a, b, True, stream=raw_stream)
+                        t2 = _time.perf_counter()
+                        stg["cast"] = stg.get("cast", 0.0) + t1 - t0
+                        stg["h2d_enqueue"] = stg.get("h2d_enqueue", 0.0) + t2 - t1
                 except BaseException as ex:          # noqa: B036 -- reported by the driving thread
                     failure.append(ex)
                 finally:
@@ -446,12 +470,12 @@ class sampling(enka):
         # torch's intra-op pool serves the staging casts only while this loop runs: sized ONCE to the copy threads
         # (resizing it around every block costs more than the casts)
         old_threads = torch.get_num_threads()
-        if old_threads > eng.copy_threads:
-            torch.set_num_threads(eng.copy_threads)
+        want_threads = int(getattr(self, "host_pipeline_torch_threads", eng.copy_threads))
+        if want_threads > 0 and old_threads > want_threads:
+            torch.set_num_threads(want_threads)
         th = threading.Thread(target=stager, daemon=True, name="cesx-hoststage")
         th.start()
 
-        import time as _time
         tm = self._pipe_times = {}                   # seconds this thread spent waiting / outside the forward map (diagnostics)
 
         def wait(evt, what="wait"):
@@ -526,7 +550,9 @@ class sampling(enka):
         Geval = self.G_ens(U_host, model)                              # :390-398 the final ensemble, one call
         if trace:                                                      # :400-405
             self.Uall.append(U_host)
-            self.Gall.append(Geval)
+            # (a 'map' model returns n_obs rows: every trace entry has them; should one return more, the loop above
+            #  kept the first n_obs of each block -- the final entry gets the same rows, so that np.array(Gall) is regular)
+            self.Gall.append(np.asarray(Geval)[:self.n_obs, :])
             self.Uall = np.asarray(self.Uall)
             self.Gall = np.array(self.Gall)
         self.Ustar = U_host

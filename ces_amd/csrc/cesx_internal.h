@@ -342,12 +342,15 @@ struct Engine {
     double *d_A64 = nullptr, *d_b64 = nullptr;   // the installed map in fp64 (n x p, n): cesx_moments_rest_lineal
     double *d_lvec = nullptr;                    // [2][n] c = A s_u + b - s_g and A sa
     // per-kernel profiling (cesx_profile_*)
+    int prof_part = 0;                 // which moments launch (0: U x U, 1: the rest) the next profiled Gram launch is
+    unsigned long long prof_step = 0;  // bumped by every first-half entry point (cesx_moments_uu*): the step the next profiled launches belong to
     bool profile = false;
     int  profile_only = -1;            // cesx_profile_enable(h, 3 / 4): only the update (1) / the moments (0) launches carry events
     bool profile_gap_only = false;     // cesx_profile_enable(h, 2): bind ONLY the stop of the second moments launch and the start of the
                                        // update launch (the gap between them, cesx_profile_gap): a step whose launches carry start AND stop
                                        // events runs ~70 us longer and its gap reads anywhere between 40 and 150 us
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[2];
+    std::vector<unsigned long long> prof_tag[2];       // the step (Engine::moments_calls at the launch) each pair belongs to: cesx_profile_gap pairs events of ONE step
     std::vector<hipEvent_t> prof_pool;
     long long* d_clk = nullptr;    // [4] {s_memtime, s_memrealtime} ticks of the last PROFILED update launch (workgroup 0, wave 0)
     // results
@@ -505,6 +508,7 @@ struct ProfScope {
         if (!on()) return;
         if (!bound) (void)hipEventRecord(b, s);
         e.prof_ev[which].push_back({a, b});
+        e.prof_tag[which].push_back(e.prof_step * 2 + (which == 0 ? (unsigned long long)e.prof_part : 1ull));
     }
 };
 

@@ -456,6 +456,7 @@ int cesx_moments_uu(cesx_handle h, const void* U, const void* G, double* mom, vo
     TRY(moments_check(e, U, G, mom));
     SET_DEVICE(e);
     FLUSH(e);
+    ++e.prof_step;
     return launch_gram(e, 0, U, G, mom, (hipStream_t)stream);
 }
 
@@ -474,6 +475,7 @@ int cesx_chol_async(cesx_handle h, int update, const double* mom, void* stream) 
 // finalisation is still pending on this stream, that too as the reduce launch's first workgroup.  The side stream
 // is made to wait for ev_a.
 static int moments_uu_handover(Engine& e, const void* U, const void* G, double* mom, hipStream_t s) {
+    ++e.prof_step;
     if (e.met_deferred && e.met_stream != s) FLUSH(e);
     TRY(launch_gram(e, 0, U, G, mom, s, true));
     if (e.met_deferred) {
@@ -496,6 +498,7 @@ int cesx_moments_uu_handover(cesx_handle h, const void* U, const void* G, double
     hipStream_t s = (hipStream_t)stream;
     if (s == e.side || !e.ext_events) {      // nothing to hand over / plain markers: the caller's own ordering applies
         FLUSH(e);
+        ++e.prof_step;
         TRY(launch_gram(e, 0, U, G, mom, s));
         if (s != e.side) {
             CESX_HIP(hipEventRecord(e.ev_a, s));
@@ -515,6 +518,7 @@ int cesx_moments_uu_chol(cesx_handle h, int update, const void* U, const void* G
     hipStream_t s = (hipStream_t)stream;
     if (s == e.side || !e.ext_events) {
         FLUSH(e);
+        ++e.prof_step;
         TRY(launch_gram(e, 0, U, G, mom, s));
         return launch_chol_async(e, update, mom, s);
     }
@@ -818,6 +822,7 @@ int cesx_profile_read(cesx_handle h, int which, double* total_ms, int* launches)
         if (pr.second) e.prof_pool.push_back(pr.second);
     }
     e.prof_ev[which].clear();
+    e.prof_tag[which].clear();
     *total_ms = tot;
     *launches = cnt;
     return CESX_OK;
@@ -846,6 +851,9 @@ int cesx_profile_gap(cesx_handle h, double* gap_ms) {
     SET_DEVICE(e);
     hipEvent_t gram_end = e.prof_ev[0].back().second, upd_start = e.prof_ev[1].back().first;
     if (!gram_end || !upd_start) return CESX_OK;
+    // both events must belong to ONE step: a step without a second moments launch (the linear-map fast path, a shard
+    // whose second part is empty) leaves an older Gram event at the back -- no gap then (-1)
+    if (e.prof_tag[0].empty() || e.prof_tag[1].empty() || e.prof_tag[0].back() != e.prof_tag[1].back()) return CESX_OK;
     CESX_HIP(hipEventSynchronize(upd_start));
     float ms = 0.f;
     CESX_HIP(hipEventElapsedTime(&ms, gram_end, upd_start));

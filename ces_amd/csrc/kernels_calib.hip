@@ -51,9 +51,6 @@ static int calibrate_t(Engine& e, double target_ms, double* tflops, double* cloc
     const int wgs = 2 * e.num_cus;
     T *in = nullptr, *out = nullptr;
     long long* clk = nullptr;
-    CESX_HIP(hipMalloc(reinterpret_cast<void**>(&in), 1024 * sizeof(T)));
-    CESX_HIP(hipMalloc(reinterpret_cast<void**>(&out), (size_t)wgs * 256 * sizeof(T)));
-    CESX_HIP(hipMalloc(reinterpret_cast<void**>(&clk), 16));
     std::vector<T> h(1024);
     uint32_t x = 12345u;
     for (auto& v : h) { x = x * 1664525u + 1013904223u; v = (T)((double)(x >> 8) / 8388608.0 - 1.0); }
@@ -61,7 +58,11 @@ static int calibrate_t(Engine& e, double target_ms, double* tflops, double* cloc
     int rc = CESX_OK;
     auto fail = [&](const char* what, hipError_t st) { e.err = std::string(what) + ": " + hipGetErrorString(st); rc = CESX_EHIP; };
     hipError_t st;
-    if ((st = hipMemcpy(in, h.data(), 1024 * sizeof(T), hipMemcpyHostToDevice)) != hipSuccess) fail("hipMemcpy", st);
+    // (every exit goes through the frees at the bottom: a failed allocation leaves the earlier ones to them)
+    if ((st = hipMalloc(reinterpret_cast<void**>(&in), 1024 * sizeof(T))) != hipSuccess) fail("hipMalloc", st);
+    if (rc == CESX_OK && (st = hipMalloc(reinterpret_cast<void**>(&out), (size_t)wgs * 256 * sizeof(T))) != hipSuccess) fail("hipMalloc", st);
+    if (rc == CESX_OK && (st = hipMalloc(reinterpret_cast<void**>(&clk), 16)) != hipSuccess) fail("hipMalloc", st);
+    if (rc == CESX_OK && (st = hipMemcpy(in, h.data(), 1024 * sizeof(T), hipMemcpyHostToDevice)) != hipSuccess) fail("hipMemcpy", st);
     if (rc == CESX_OK && ((st = hipEventCreate(&ea)) != hipSuccess || (st = hipEventCreate(&eb)) != hipSuccess)) fail("hipEventCreate", st);
     // flops of one loop iteration of the whole grid: 16 MFMAs per wave, 2 TILE^2 KSTEP flops each
     const double fl_iter = (double)wgs * 4 * 16 * 2.0 * M::TILE * M::TILE * M::KSTEP;
@@ -88,7 +89,9 @@ static int calibrate_t(Engine& e, double target_ms, double* tflops, double* cloc
     }
     if (ea) (void)hipEventDestroy(ea);
     if (eb) (void)hipEventDestroy(eb);
-    (void)hipFree(in); (void)hipFree(out); (void)hipFree(clk);
+    if (in) (void)hipFree(in);
+    if (out) (void)hipFree(out);
+    if (clk) (void)hipFree(clk);
     return rc;
 }
 

@@ -682,6 +682,7 @@ static int launch_gram_t(Engine& e, int part, const void* U, const void* G, hipS
     CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     {
+        e.prof_part = part;
         ProfScope prof(e, 0, s);
         hipLaunchKernelGGL(kern, grid, block, lds, s, (const T*)U, (const T*)G, (const T*)e.d_shiftT,
                            e.p, e.n, (long long)e.J, gp.d_type_hdr, pl.ntypes, gp.d_rows, gp.d_wblk,

@@ -438,6 +438,7 @@ static int launch_gram2_t(Engine& e, int part, const void* U, const void* G, hip
                    : (imm ? gram2_kernel<T, false, true> : gram2_kernel<T, false, false>);
     CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     {
+        e.prof_part = part;
         ProfScope prof(e, (e.profile_gap_only && part == 0) ? -1 : 0, s, true);      // (gap-only: the second launch's stop, nothing else)
         if (prof.on())
             hipExtLaunchKernelGGL(kern, dim3(pl.total_wgs), dim3(G2_THREADS), (unsigned)lds, s, prof.a, prof.b, 0,

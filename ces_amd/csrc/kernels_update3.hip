@@ -52,8 +52,11 @@ void update3_kernel(const Upd3Args a) {
     using d4 = double __attribute__((ext_vector_type(4)));
     using d2 = double __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // [ X ring 3 x 8 KiB | rowc kn x 32 B ]
-    double* const sRowc = reinterpret_cast<double*>(smem + U3_RING * U3_XSLOT);
+    // [ X ring 3 x 8 KiB | per-thread metric sums 256 x 64 B | rowc kn x 32 B ]
+    // (the eight per-particle metric sums of a thread live in LDS, not in registers: 16 of the kernel's 255 registers --
+    //  it sat one register from spilling; they are touched in the 32 of 96 k-tiles that carry G rows only)
+    double* const sMq = reinterpret_cast<double*>(smem + U3_RING * U3_XSLOT);
+    double* const sRowc = sMq + U3_THREADS * 8;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(
         (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
 
@@ -125,7 +128,10 @@ void update3_kernel(const Upd3Args a) {
         const int rows4 = (met_t1 - met_t0) * U3_BK * 4;
         for (int i = tid; i < rows4; i += U3_THREADS) sRowc[i] = a.rowc[i];
     }
-    double mq_e[4] = {0, 0, 0, 0}, mq_r[4] = {0, 0, 0, 0};
+    if (do_metrics) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) sMq[c * U3_THREADS + tid] = 0.0;       // (thread-private, [c][tid]: conflict-free)
+    }
 
     d2 afA[4][2], afB[4][2];
     issue_x(0, 0);
@@ -156,8 +162,8 @@ void update3_kernel(const Upd3Args a) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const double b = xv[c] - gb, r = xv[c] - yy;
-                mq_e[c] += w * b * b;
-                mq_r[c] += w * r * r;
+                sMq[c * U3_THREADS + tid] += w * b * b;
+                sMq[(4 + c) * U3_THREADS + tid] += w * r * r;
             }
         }
 #pragma unroll
@@ -225,8 +231,8 @@ void update3_kernel(const Upd3Args a) {
         const int grp = tid >> 4;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            comb[grp * U3_BN + 4 * (tid & 15) + c] = mq_e[c];
-            comb[16 * U3_BN + grp * U3_BN + 4 * (tid & 15) + c] = mq_r[c];
+            comb[grp * U3_BN + 4 * (tid & 15) + c] = sMq[c * U3_THREADS + tid];
+            comb[16 * U3_BN + grp * U3_BN + 4 * (tid & 15) + c] = sMq[(4 + c) * U3_THREADS + tid];
         }
         __syncthreads();
         double se = 0.0, sr = 0.0;
@@ -269,7 +275,7 @@ int launch_update3(Engine& e, int out_rows, const void* Wd, int ktot, const void
                    void* out, double* absmax_part, bool metrics, const UpdateOpt& opt, hipStream_t s) {
     if (e.cfg.dtype != CESX_F64 || !Wd || opt.ldw != 0 || nsrc < 1 || nsrc > 3) return -1;
     if (e.J % 4 != 0 || e.J < 4 || ktot % U3_BK != 0) return -1;
-    const int lds = U3_RING * U3_XSLOT + e.kn * 32;      // (the epilogue's 16 KiB metric scratch reuses the ring)
+    const int lds = U3_RING * U3_XSLOT + U3_THREADS * 64 + e.kn * 32;      // (the epilogue's 16 KiB metric scratch reuses the ring)
     if (lds > 78 * 1024) return -1;
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     if (!al16(Wd) || !al16(out) || (add1 && !al16(add1)) || (add2 && !al16(add2))) return -1;

@@ -230,13 +230,15 @@ class ShardedUpdate:
                 and self.world == 1 and not self._force_collectives and not self.single_allreduce
                 and os.environ.get("CESX_LINEAL_FAST", "1") != "0")
 
-    def begin_lineal(self, prm, U, forward, noise_step=None):
+    def begin_lineal(self, prm, U, forward, noise_step=None, model=None):
         """``begin`` for a linear forward map the engine evaluates itself: only the U x U Gram
         runs; G = forward(U) is evaluated on the caller's stream BESIDE chol(C), and every G-dependent moment
         follows from the U-only head (cesx_moments_rest_lineal: two small fp64 products instead of the second Gram
         launch and its reduce -- 100 of the 136 blocks at p = n_obs = 256).  The centring shift must be valid (a
         first step goes through ``begin`` with ``recenter``).  Returns (mom, G)."""
         eng = self.engine
+        if model is not None and hasattr(model, "ensure_installed"):
+            model.ensure_installed(eng)              # the moment kernels below read the INSTALLED map: this model's, as of now
         if noise_step is not None:
             eng.prefetch_noise(noise_step)
         mom = self._moment_buffer()
@@ -335,7 +337,7 @@ class ShardedSampler:
                 U = self.sh.finish(prm, U, G, xi=xi)
                 if i + 1 < self.T:
                     if fast:
-                        _, G = self.sh.begin_lineal(prm0, U, lambda u: self._forward(model, u),
+                        _, G = self.sh.begin_lineal(prm0, U, lambda u: self._forward(model, u), model=model,
                                                     noise_step=self._steps_done if draw else None)
                     else:
                         G = self._forward(model, U)

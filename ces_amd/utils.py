@@ -60,6 +60,14 @@ class lineal(object):
             if np.ndim(self.b) > 0 or self.b != 0:
                 b = np.broadcast_to(np.asarray(self.b, dtype=np.float64), (self.n_obs,))
             return engine.forward_lineal(self.A, U_dev, b=b, out=out)
+        self.ensure_installed(engine)
+        return engine.forward_apply(U_dev, out=out)
+
+    def ensure_installed(self, engine):
+        """Make THIS map the one installed in ``engine`` (build-only).  Called by ``forward_device`` and -- before the moment
+        kernels that read the installed map, cesx_moments_rest_lineal -- by ``ShardedUpdate.begin_lineal``: the G-dependent
+        moments, G itself and K3 then all use the same map in every step (an edit of A or b between two steps, or another
+        model that installed its map on the same engine, re-installs first)."""
         # the installed map is reused while A and b are THE SAME OBJECTS (strong references are kept, so an id cannot be
         # recycled) and a cheap fingerprint of their contents (shape, dtype, 64 strided samples, the sum) is unchanged:
         # an in-place edit of A or b between two calls re-installs the map.  ``invalidate_device()`` forces it.
@@ -72,7 +80,6 @@ class lineal(object):
                 b = np.broadcast_to(np.asarray(self.b, dtype=np.float64), (self.n_obs,))
             self._dev_token = engine.forward_set_lineal(np.asarray(self.A), b)      # (another model may have installed its map)
             self._dev_A, self._dev_b, self._dev_fp = self.A, self.b, fp
-        return engine.forward_apply(U_dev, out=out)
 
 
 def __getattr__(name):

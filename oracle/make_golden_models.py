@@ -26,15 +26,10 @@ def make_models(ru):
     th = rng.standard_normal(3)
     g["lineal_A"], g["lineal_theta"] = A, th
     g["lineal_out"] = ru.lineal(A, b=0.25)(th)
-    g["lineal_log_out"] = ru.lineal_log(A)(th)
-    g["lineal_log_grad"] = ru.lineal_log(A).grad_logjacobian(th)
-    g["lineal_log_jac"] = np.asarray(ru.lineal_log(A).logjacobian(th))
-    th2 = rng.standard_normal((2, 6))
-    g["theta2"] = th2
-    g["elliptic_out"] = np.asarray(ru.elliptic()(th2))
-    g["elliptic_dG"] = ru.elliptic()(th2[:, 0], dG=True)
-    g["banana_out"] = np.stack([ru.banana(a=1.3, b=0.4)(th2[:, k]) for k in range(th2.shape[1])], axis=1)
-    g["banana_Gamma"] = ru.banana(rho=0.7).Gamma
+    # (lineal_log, elliptic and banana of ces/utils.py:33-122 are outside the hot-path scope -- SURVEY.md section 2 -- and
+    #  are not shipped by ces_amd.models: no fixtures for them.  The draw below stays so that the fixtures behind it
+    #  keep the values of the rounds before.)
+    rng.standard_normal((2, 6))
     # --- lorenz 63 --------------------------------------------------------------------
     l63 = ru.lorenz63(l_window=2, freq=25)
     t63 = np.linspace(0, 6, 151)                       # 150 samples after t0 = 3 windows of 50
@@ -74,8 +69,7 @@ def make_models(ru):
     g["l96_grad_logjac"] = full.grad_logjacobian(np.array([1.0, 2.0, 3.0, 4.0]))
     np.random.seed(5)
     g["l96_initial"] = ru.lorenz96(n_slow=6, n_fast=3).generate_initial()
-    reprs = {k: repr(v) for k, v in dict(lineal=ru.lineal(A), lineal_log=ru.lineal_log(A), elliptic=ru.elliptic(),
-                                         banana=ru.banana(), lorenz63=l63, lorenz63_log=l63l, lorenz96=full,
+    reprs = {k: repr(v) for k, v in dict(lineal=ru.lineal(A), lorenz63=l63, lorenz63_log=l63l, lorenz96=full,
                                          lorenz96Fc=ru.lorenz96Fc(), lorenz96Fb=ru.lorenz96Fb(),
                                          lorenz96hFb=ru.lorenz96hFb(), lorenz96hcb=ru.lorenz96hcb()).items()}
     return g, reprs

@@ -30,6 +30,19 @@ def short(name):
     return name.split("<")[0].split("(")[0]
 
 
+def kernel_sources_sha():
+    """sha1 (16 hex digits) of the kernel sources the profiled library was built from: bench.py compares it with the
+    tree it runs in and refuses HBM counters of another build (profiles/traffic.json `_src_sha16`)."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "ces_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h")):
+            h.update(fn.encode())
+            h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def traffic_per_step(summary):
     """HBM bytes per step and kernel from the per-counter summaries.  Every --pmc pass is a run of its own and the
     benchmark's pre-warm is time-based, so the passes hold DIFFERENT numbers of steps: each counter is normalised by
@@ -59,6 +72,7 @@ def main():
         per_step = traffic_per_step(summary)
         per_step["gram_kernel"] = per_step.get("gram2_kernel", 0) + per_step.get("gram_kernel", 0)
         per_step["_source"] = tag + "_pmc_summary.json"
+        per_step["_src_sha16"] = summary.get("_src_sha16") or kernel_sources_sha()
         traffic[config] = per_step
         json.dump(traffic, open(tpath, "w"), indent=1, sort_keys=True)
         print({k: v for k, v in per_step.items() if isinstance(v, int) and v > 1e6})
@@ -121,6 +135,7 @@ def main():
             # (update_kernel also counts the forward-map launches of the bench set-up: the step's K3 is
             #  update2_kernel (fp32) / update3_kernel (fp64) when the LDS-DMA kernels ran)
             per_step["_source"] = tag + "_pmc_summary.json"
+            per_step["_src_sha16"] = kernel_sources_sha()      # (run right behind the profile passes, on the tree they ran from)
             traffic[config] = per_step
         json.dump(traffic, open(tpath, "w"), indent=1, sort_keys=True)
     print("wrote", sorted(os.listdir(out)))
