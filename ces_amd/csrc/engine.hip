@@ -242,6 +242,7 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
             GramPart& gp = e.gp[part];
             int min_types = 1;
             if (part == 0) if (const char* gv = std::getenv("CESX_GRAM_UU_TYPES")) min_types = std::atoi(gv);
+            if (part == 1) if (const char* gv = std::getenv("CESX_GRAM_B_TYPES")) min_types = std::atoi(gv);
             // part 1: 7 workgroups per shader engine (8 CUs), so that the Cholesky always finds a free CU
             // Part 1 runs beside what the side stream carries, and a kernel on another stream is only placed
             // while it needs no more whole CUs than are free (tools/place_probe.hip: beside 248 one-per-CU
