@@ -696,6 +696,12 @@ int cesx_result(cesx_handle h, cesx_step_result* out) {
         if (e.last_apply.valid && !e.in_retry && e.last_join_polled) {
             const Engine::LastApply la = e.last_apply;
             e.in_retry = true;
+            // whatever a pipelined driver put on the side stream behind the failed step (the centring + chol(C) of moments of
+            // an unwritten ensemble: it may well report "not positive definite") ends BEFORE the re-run resets the status word
+            {
+                SET_DEVICE(e);
+                CESX_HIP(hipStreamSynchronize(e.side));
+            }
             e.chol_inflight = false;
             int rc = cesx_apply(h, &la.prm, la.mom, la.U, la.G, la.xi, la.Unext, (void*)la.s);
             if (rc == CESX_OK) rc = cesx_result(h, out);

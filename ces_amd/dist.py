@@ -50,6 +50,7 @@ class ShardedUpdate:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._recentered = False
+        self._last_begin = None           # how to redo the `begin` enqueued behind the last `finish` (result(): a re-run step)
         self.native_comm = False          # set below: the all-reduces go through the engine's own RCCL communicator (cesx_allreduce_*)
         # CESX_SINGLE_ALLREDUCE=1 (or single_allreduce=True): the north star's literal form -- ONE all-reduce of the
         # whole moment buffer per step, after the complete Gram, with chol(C) in line behind it (on the critical
@@ -172,6 +173,7 @@ class ShardedUpdate:
         and an error raised here (HIP, RCCL) propagates, so that all ranks fail together instead
         of one rank issuing an extra collective."""
         eng = self.engine
+        self._last_begin = lambda: self.begin(prm, U, G, recenter=False, noise_step=noise_step)
         if recenter or not self._recentered:
             self.recenter(U, G)
         if noise_step is not None and hasattr(eng, "prefetch_noise") and not self.single_allreduce:
@@ -237,6 +239,7 @@ class ShardedUpdate:
         launch and its reduce -- 100 of the 136 blocks at p = n_obs = 256).  The centring shift must be valid (a
         first step goes through ``begin`` with ``recenter``).  Returns (mom, G)."""
         eng = self.engine
+        self._last_begin = lambda: self.begin_lineal(prm, U, forward, noise_step=noise_step, model=model)
         if model is not None and hasattr(model, "ensure_installed"):
             model.ensure_installed(eng)              # the moment kernels below read the INSTALLED map: this model's, as of now
         if noise_step is not None:
@@ -254,6 +257,7 @@ class ShardedUpdate:
 
     def finish(self, prm, U, G, xi=None, out=None):
         """Second half: K2 with this step's parameters (t_last, time-step rule) and K3."""
+        self._last_begin = None                 # (a `begin` enqueued from here on belongs to the NEXT step: only that one is ever redone)
         eng, mom = self.engine, self._mom
         if prm.update == 2:                     # aldi_constant: max|drift| over all shards
             out = eng.empty(eng.p) if out is None else out
@@ -270,7 +274,19 @@ class ShardedUpdate:
         """Result of the last step.  On more than one rank ``bias_data`` /
         ``self_bias_data`` are this shard's share; ``lag_*`` are the complete values of
         the previous step."""
-        return self.engine.result()
+        try:
+            return self.engine.result()
+        except Exception as err:
+            # cesx_result re-ran a step whose polled join of the side stream had run out (a profiler that serialises the
+            # streams does that to it) and says that the `begin` enqueued behind it read an ensemble that had not been
+            # written: redo that `begin` (the step's own result is valid and attached), carry on with the event join
+            redo, res = self._last_begin, getattr(err, "result", None)
+            if res is None or redo is None or getattr(err, "code", None) != 4:
+                raise
+            self.redone_begins = getattr(self, "redone_begins", 0) + 1
+            self._last_begin = None
+            redo()
+            return res
 
     def flush_data_metrics(self, res):
         """Complete data metrics of the LAST step (one tiny all-reduce at the end of a run)."""

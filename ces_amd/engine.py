@@ -51,9 +51,10 @@ class StepResult(C.Structure):
 
 
 class CesxError(RuntimeError):
-    def __init__(self, code, msg):
+    def __init__(self, code, msg, result=None):
         super().__init__("cesx error %d: %s" % (code, msg))
         self.code = code
+        self.result = result      # cesx_result's CESX_ESTATE after a re-run step: the (valid) result of that step
 
 
 _lib = None
@@ -542,6 +543,12 @@ class Engine:
     def result(self):
         res = StepResult()
         rc = self.lib.cesx_result(self._h, C.byref(res))
+        if rc == ESTATE and self.poll_recoveries() > self.__dict__.get("_seen_recoveries", 0):
+            # a polled join ran out, the step was re-run and `res` is valid; moments enqueued behind it must be redone
+            # (include/cesx.h): the pipelined drivers (ShardedUpdate.result) do that and carry on
+            self._seen_recoveries = self.poll_recoveries()
+            raise CesxError(rc, self.lib.cesx_last_error(self._h).decode(), result=res)
+        self._seen_recoveries = self.poll_recoveries()
         self._check(rc)
         return res
 

@@ -694,9 +694,9 @@ def test_polled_side_stream_join_is_bit_identical(eng_mod, monkeypatch, dtype, p
     assert np.array_equal(outs[4][0], outs[3][0]) and outs[4][1] == outs[3][1]
 
 
-def _aldi_chain(eng_mod, d, p, n, J, dtype, nsteps=4, pipelined=False, stream=None, on_error=None):
+def _aldi_chain(eng_mod, d, p, n, J, dtype, nsteps=4, pipelined=False, stream=None):
     """An ALDI chain on one engine through ShardedUpdate.begin / finish (as bench.py and ShardedSampler drive it).
-    Returns (engine, last ensemble, per-step scalars)."""
+    Returns (engine, last ensemble, per-step scalars, the driver)."""
     import torch
     from ces_amd.dist import ShardedUpdate
     ctx = torch.cuda.stream(stream) if stream is not None else None
@@ -717,22 +717,14 @@ def _aldi_chain(eng_mod, d, p, n, J, dtype, nsteps=4, pipelined=False, stream=No
             out = sh.finish(prm_of(i, t_last), U, G, xi=None, out=bufs[i % 2])
             if pipelined and i + 1 < nsteps:
                 sh.begin(prm_of(i + 1, 0.0), out, G, noise_step=i + 1)
-            try:
-                res = sh.result()
-            except eng_mod.CesxError as err:
-                if on_error is None:
-                    raise
-                on_error(err)
-                res = sh.result()                                   # (the re-run step's result is valid)
-                if i + 1 < nsteps:
-                    sh.begin(prm_of(i + 1, 0.0), out, G, noise_step=i + 1)     # ... the moments behind it are redone
+            res = sh.result()
             if not pipelined and i + 1 < nsteps:
                 sh.begin(prm_of(i + 1, 0.0), out, G, noise_step=i + 1)
             t_last = res.t_new
             chain.append((res.hk, res.t_new, res.bias, res.self_bias, res.bias_data, res.self_bias_data))
             U = out
         torch.cuda.synchronize()
-        return eng, U.cpu().numpy().copy(), np.array(chain)
+        return eng, U.cpu().numpy().copy(), np.array(chain), sh
     finally:
         if ctx is not None:
             ctx.__exit__(None, None, None)
@@ -743,20 +735,19 @@ def test_polled_join_that_runs_out_leaves_the_step_untouched_and_is_rerun(eng_mo
     word (CESX_TEST_DROP_CHOL_SIGNAL: the second one) makes the poll of that step run out: the assembly and update
     launches write nothing, cesx_result switches the engine to the event join and re-runs the step with chol(C) in line
     -- the chain is bit-identical to one that never polled (CESX_POLL_JOIN=0); a pipelined driver is told (CESX_ESTATE)
-    that the moments it enqueued behind the failed step must be redone."""
+    that the moments it enqueued behind the failed step must be redone, which ShardedUpdate.result does by itself."""
     p, n, J = 128, 96, 8192
     d = _synthetic(p, n, J, seed=81)
     monkeypatch.setenv("CESX_POLL_JOIN", "0")
-    e0, U0, c0 = _aldi_chain(eng_mod, d, p, n, J, "float32")
+    e0, U0, c0, _ = _aldi_chain(eng_mod, d, p, n, J, "float32")
     monkeypatch.setenv("CESX_POLL_JOIN", "1")
     monkeypatch.setenv("CESX_POLL_TIMEOUT_MS", "20")
     monkeypatch.setenv("CESX_TEST_DROP_CHOL_SIGNAL", "2")
-    e1, U1, c1 = _aldi_chain(eng_mod, d, p, n, J, "float32")
-    assert e1.poll_recoveries() == 1
+    e1, U1, c1, sh1 = _aldi_chain(eng_mod, d, p, n, J, "float32")
+    assert e1.poll_recoveries() == 1 and getattr(sh1, "redone_begins", 0) == 0
     assert np.array_equal(U1, U0) and np.array_equal(c1, c0)
-    seen = []
-    e2, U2, c2 = _aldi_chain(eng_mod, d, p, n, J, "float32", pipelined=True, on_error=seen.append)
-    assert e2.poll_recoveries() == 1 and len(seen) == 1 and "redo" in str(seen[0])
+    e2, U2, c2, sh2 = _aldi_chain(eng_mod, d, p, n, J, "float32", pipelined=True)
+    assert e2.poll_recoveries() == 1 and sh2.redone_begins == 1
     assert np.array_equal(U2, U0) and np.array_equal(c2, c0)
 
 
@@ -769,15 +760,15 @@ def test_polled_join_only_below_the_side_streams_priority(eng_mod, monkeypatch):
     p, n, J = 128, 96, 8192
     d = _synthetic(p, n, J, seed=82)
     monkeypatch.setenv("CESX_POLL_JOIN", "0")
-    e0, U0, c0 = _aldi_chain(eng_mod, d, p, n, J, "float32")
+    e0, U0, c0, _ = _aldi_chain(eng_mod, d, p, n, J, "float32")
     monkeypatch.setenv("CESX_POLL_JOIN", "1")
     monkeypatch.setenv("CESX_POLL_TIMEOUT_MS", "200")
     hi = torch.cuda.Stream(priority=-1)
     keep = [eng_mod.Engine(p, n, J, dtype="float32", seed=k) for k in range(5)]      # five more engines alive (their side streams too)
-    e1, U1, c1 = _aldi_chain(eng_mod, d, p, n, J, "float32", stream=hi)
+    e1, U1, c1, _ = _aldi_chain(eng_mod, d, p, n, J, "float32", stream=hi)
     assert e1.poll_recoveries() == 0
     assert np.array_equal(U1, U0) and np.array_equal(c1, c0)
-    e2, U2, c2 = _aldi_chain(eng_mod, d, p, n, J, "float32")                         # default stream, six engines alive
+    e2, U2, c2, _ = _aldi_chain(eng_mod, d, p, n, J, "float32")                         # default stream, six engines alive
     assert e2.poll_recoveries() == 0
     assert np.array_equal(U2, U0) and np.array_equal(c2, c0)
     del keep

@@ -8,8 +8,12 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 ARGS="bench.py --config $CFG --no-cpu-baseline --no-extras --steps 12 --warmup 3"
 export CESX_BENCH_PREWARM_S=${CESX_BENCH_PREWARM_S:-0.3}
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_k -- python3 $ARGS > gpurun_out/prof_${TAG}_k.log 2>&1 || exit 2
+# (--pmc serialises the streams' kernels: a kernel of the caller's stream that polls for one of the side stream would wait
+#  for its time-out -- the engine recovers, bench.py carries on, but the event join is the honest mode for these passes)
+export CESX_POLL_JOIN=0
 for ctr in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
   rocprofv3 --pmc $ctr --output-format csv -d gpurun_out/prof_${TAG}_$ctr -- python3 $ARGS > gpurun_out/prof_${TAG}_$ctr.log 2>&1 || exit 3
 done
+unset CESX_POLL_JOIN
 python3 bench.py --config $CFG > gpurun_out/prof_${TAG}_bench.json 2> gpurun_out/prof_${TAG}_bench.err
 echo done $TAG $CFG
