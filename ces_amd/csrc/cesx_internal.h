@@ -134,6 +134,45 @@ __device__ __forceinline__ void normal4(uint4x r, double out[4]) {
     out[0] = ra * ca; out[1] = ra * sa; out[2] = rb * cb; out[3] = rb * sb;
 }
 
+// One workgroup's share of a noise block xi[p][J] (256 threads; thread = rows 4 by .. 4 by + 3 of NP consecutive
+// particles of column block bx): the body of noise_kernel (kernels_update.hip) and of the workgroups that draw the
+// NEXT step's block while riding on the Gram's reduce launches (NoiseRide below).
+template <typename T, bool VEC4>
+__device__ __forceinline__ void noise_body(T* __restrict__ xi, int p, long long J, long long j_offset, unsigned seed_lo,
+                                           unsigned seed_hi, unsigned step, unsigned bx, unsigned by) {
+    constexpr int NP = VEC4 ? 4 : 1;
+    const long long j0 = ((long long)bx * 256 + threadIdx.x) * NP;
+    const int q = (int)by;
+    if (j0 >= J) return;
+    T z[NP][4];
+#pragma unroll
+    for (int c = 0; c < NP; ++c) {
+        const unsigned long long gj = (unsigned long long)(j_offset + j0 + c);
+        const uint4x r = philox4x32_10((uint32_t)gj, (uint32_t)(gj >> 32), (uint32_t)q, step, seed_lo, seed_hi);
+        normal4(r, z[c]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (4 * q + e >= p) break;
+        T* dst = xi + (size_t)(4 * q + e) * J + j0;
+        if (VEC4) {
+            typedef T v4 __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<v4*>(dst) = v4{z[0][e], z[NP > 1 ? 1 : 0][e], z[NP > 2 ? 2 : 0][e], z[NP > 3 ? 3 : 0][e]};
+        } else {
+            dst[0] = z[0][e];
+        }
+    }
+}
+
+// A range [wg0, wg0 + nwg) of the gx x gy workgroups of a noise block, drawn by extra workgroups of another launch
+// (xi == nullptr: none).  The two slab reduces of a step are latency / HBM bound with the vector ALUs idle: the next
+// step's block rides on them, half each, instead of running as a kernel of its own beside K2's latency-bound chain,
+// which it stretched by 10 - 20 us (round 4).
+struct NoiseRide {
+    void* xi = nullptr; int p = 0; long long J = 0, j_offset = 0; unsigned seed_lo = 0, seed_hi = 0, step = 0;
+    unsigned gx = 1, wg0 = 0, nwg = 0;
+};
+
 // ---------------------------------------------------------------------------
 // Packed fp64 moment buffer (the only data that crosses GPUs).  The part that
 // depends on U alone comes first and is contiguous, so that it can be reduced
@@ -335,6 +374,20 @@ struct Engine {
     bool gram_v2 = true;           // K1 through the LDS-DMA kernel when the shapes allow (CESX_GRAM_V1=1 switches back)
     int num_cus = 256;
     void* d_bias = nullptr;        // [rpad]
+    // ---- ALDI with the time step kept OUT of the update coefficients (round 4; launch_dense, "hk-free") ----
+    // U_next = hk ( sqrt(2/hk) L xi + (a I - M + I/hk) U - K G + b' ),  b' = K y + M mu - a ubar: the image
+    // Wq = [ L | a I - M (+ 1/hk on the diagonal) | -K ] needs hk in p diagonal entries only.  L and a I - M are written by
+    // the side stream's own kernels (the factorisation stores its panels into the image as it finishes them, the U-only
+    // centring writes a I - M and the two matvecs M mu, M ubar), the caller's stream adds -K, the diagonal and b' in ONE
+    // launch behind the second reduce (tail_aldi_kernel: its last workgroup, by ticket, sums the Frobenius partials, joins
+    // the side stream and writes hk), and K3 takes hk and sqrt(2hk) from the scalar block at run time: xi segment first,
+    // accumulators rescaled once by sqrt(2/hk), the result times hk in the epilogue.
+    void* d_Wq = nullptr;          // [rpad][ktot] fragment-major (wf_index), fp32; zero outside what the kernels above write
+    double* d_qv = nullptr;        // [3][p] M mu | M ubar | a - M_ii  (side stream)
+    unsigned* d_ticket = nullptr;  // arrival counter of tail_aldi_kernel
+    bool hkfree_ok = true;         // CESX_HKFREE=0 switches the path off
+    bool side_img = false;         // the factorisation in flight wrote its share of d_Wq / d_qv (launch_chol_async)
+    bool last_hkfree = false;      // the last launch_dense took the path: the update launch reads d_Wq in the order [xi; U; G]
     void* d_Wfwd = nullptr;        // forward-map staging [npad][kp]
     void* d_Wfwd_f = nullptr;      // the same map in the fragment-major order of the LDS-DMA update kernels (cesx_forward_set_lineal)
     void* d_bfwd = nullptr;        // [rpad] its offset b
@@ -370,6 +423,17 @@ struct Engine {
     long long xi_step[2] = {-1, -1};                 // step index block b holds (-1: none)
     unsigned long long xi_seq[2] = {0, 0};           // chol_seq of the cesx_chol_async call that drew block b
     long long xi_want = -1;          // step index asked for by cesx_prefetch_noise, drawn behind the next chol(C)
+    // the lookahead block riding on the reduce launches of the caller's stream (NoiseRide): planned by the U x U reduce,
+    // completed by the second reduce (or flushed as a launch of its own by whatever needs the block first)
+    struct XiRide { bool active = false; long long step = -1; int buf = 0; unsigned done = 0, total = 0, gx = 1; hipStream_t stream = nullptr; } xi_ride;
+    bool xi_ride_ok = false;         // CESX_NOISE_RIDE=1 switches the ride on (default: the lookahead block is drawn by a kernel on the
+                                     // side stream, behind chol(C)).  Measured at C2 (round 4, tools/ab_env.py): the reduces are HBM bound, not
+                                     // idle -- 30 % of the block on each takes them from 11.8 / 12.1 to 14.6 / 15.4 us; step 0.3973 (30:40:30),
+                                     // 0.3984 (20:50:30), 0.4010 (25:25:50), 0.3996 (40:20:40) against 0.3944-0.3950 with the whole draw behind chol(C)
+    int  xi_ride_pct = 30;           // share of the block that rides on the first reduce, and the share the side stream draws
+    int  xi_ride_pct_side = 40;      // behind chol(C) (beside the tail of K2); the rest rides on the second reduce (CESX_NOISE_RIDE_PCT=a,s)
+    hipEvent_t ev_r[2] = {nullptr, nullptr};         // block b's ride shares are complete on xi_stream[b] (another stream asked for the block)
+    hipStream_t xi_stream[2] = {nullptr, nullptr};   // != nullptr: block b was drawn on that stream (ordered for kernels enqueued there later)
     bool xi_lookahead = true;        // CESX_NOISE_LOOKAHEAD=0 switches the second draw off
     unsigned long long chol_seq = 0;              // cesx_chol_async calls so far
     // ---- the side stream joined through a polled word instead of a barrier packet (round 3, launch_dense) ----
@@ -417,21 +481,29 @@ struct UpdateSrc {            // one K-segment of the update GEMM
 
 int launch_colsum(Engine& e, const void* U, const void* G, double* sums, hipStream_t s);
 int launch_set_shift(Engine& e, const double* sums, hipStream_t s);
-int launch_gram(Engine& e, int part, const void* U, const void* G, double* mom, hipStream_t s, bool no_reduce = false);   // part 0 / 1
-int launch_gram_reduce(Engine& e, int part, double* mom, hipStream_t s, hipEvent_t stop = nullptr, const MetricFin* fin = nullptr);   // the fp64 slab reduce of that launch (stop: bound to its completion)
+int launch_gram(Engine& e, int part, const void* U, const void* G, double* mom, hipStream_t s, bool no_reduce = false,
+                const NoiseRide* ride = nullptr);   // part 0 / 1
+int launch_gram_reduce(Engine& e, int part, double* mom, hipStream_t s, hipEvent_t stop = nullptr, const MetricFin* fin = nullptr,
+                       const NoiseRide* ride = nullptr);   // the fp64 slab reduce of that launch (stop: bound to its completion)
+int launch_noise_range(Engine& e, const NoiseRide& r, hipStream_t s);      // the same range as a launch of its own
+NoiseRide ride_range(Engine& e, unsigned n);                                 // the next n workgroups of the ride in flight (engine.hip)
 // kernels_gram2.hip (LDS-DMA Gram): CESX_OK, an error, or -1 when the launch does not qualify (caller falls back)
 int launch_gram2(Engine& e, int part, const void* U, const void* G, hipStream_t s);
-int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int phase, hipStream_t s);
+int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int phase, hipStream_t s, bool upd2_ok = false);
 // Kernels of the caller's stream and of the side stream may WAIT for each other inside a launch (the polled join of
 // launch_dense) only when the two streams cannot share a hardware queue: HIP maps the streams of one priority level
 // onto a few queues, and a waiter in front of what it waits for in one in-order queue never ends.  True when `s` has a
 // strictly lower priority than the side stream (a numerically greater one).
 bool stream_below_side(Engine& e, hipStream_t s);
 int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s, bool ev_a_bound = false);
+// whether an update launch [xi; U; G] -> Unext of this engine qualifies for the LDS-DMA fp32 kernel (kernels_update2.hip)
+bool update2_qualifies(const Engine& e, const void* U, const void* G, const void* xi, const void* Unext);
 struct UpdateOpt {
     const unsigned long long* fault = nullptr;   // != nullptr: the launch leaves `out` untouched when *fault == fault_seq (a polled join that ran out)
     unsigned long long fault_seq = 0;
     int ldw = 0;          // row stride of W (0: = ktot)
+    const double* hkp = nullptr;   // != nullptr (LDS-DMA fp32 kernel, triangular segment FIRST): W carries no time step -- the accumulators
+    const double* s2p = nullptr;   // are scaled by *s2p / *hkp behind the first segment and the result (+ bias) by *hkp in the epilogue
     int metric_seg = 1;   // K-segment that holds G (data metrics)
     const void* wf = nullptr;  // fragment-major copy of the WHOLE W (fp32): enables the LDS-DMA kernel
     int prof = -1;        // profiling slot (1 = K3) or -1

@@ -120,12 +120,22 @@ int finish_step(Engine& e, const cesx_step_params& prm, hipStream_t s) {
     return CESX_OK;
 }
 
+int ride_flush(Engine& e);
+
 // the noise block of this step drawn ahead by cesx_prefetch_noise (nullptr: draw inside the update kernel)
 const void* prefetched_noise(Engine& e, const cesx_step_params& prm, hipStream_t s) {
     // drawn on the side stream behind chol(C); its own event, waited for HERE (right before the update kernel):
     // K2's scalar and assemble kernels do not need the block and run beside the draw
+    if (e.xi_ride.active && e.xi_ride.step == (long long)prm.step_index && ride_flush(e) != CESX_OK) return nullptr;
     for (int b = 0; b < 2; ++b) {
         if (!e.d_xi[b] || e.xi_step[b] != (long long)prm.step_index) continue;
+        if (e.xi_stream[b] != nullptr) {          // shares drawn on a caller's stream (the ride): ordered for that stream's later kernels
+            if (e.xi_stream[b] != s) {
+                if (!e.ev_r[b] && hipEventCreateWithFlags(&e.ev_r[b], hipEventDisableTiming) != hipSuccess) return nullptr;
+                if (hipEventRecord(e.ev_r[b], e.xi_stream[b]) != hipSuccess || hipStreamWaitEvent(s, e.ev_r[b], 0) != hipSuccess) return nullptr;
+            }
+            if (e.xi_seq[b] == 0) return e.d_xi[b];      // (no share on the side stream)
+        }
         // a block drawn behind an EARLIER chol(C) precedes this step's chol(C) on the side stream: a stream that has
         // waited for this step's ev_b is already ordered behind the draw
         const bool ordered = e.xi_seq[b] < e.evb_waited_seq && s == e.evb_waited_stream;
@@ -143,6 +153,16 @@ int run_update_main(Engine& e, const cesx_step_params& prm, const void* U, const
     opt.prof = 1;
     opt.wf = e.d_Wf;
     if (e.last_join_polled) { opt.fault = e.d_cholflag + 1; opt.fault_seq = e.chol_seq; }
+    if (e.last_hkfree) {
+        // the coefficient image without the time step (launch_dense): [L | a I - M + I/hk | -K] against [xi; U; G]
+        src[0] = UpdateSrc{xi, e.p, xi ? 0 : 1, 1};
+        src[1] = UpdateSrc{U, e.p, 0, 0};
+        src[2] = UpdateSrc{G, e.n, 0, 0};
+        opt.wf = e.d_Wq;
+        opt.metric_seg = 2;
+        opt.hkp = &e.d_scal->hk;
+        opt.s2p = &e.d_scal->sqrt2hk;
+    }
     int rc = launch_update(e, e.p, e.d_W, e.ktot, e.d_bias, src, 3, nullptr, nullptr, 0.0, nullptr, nullptr, 0.0,
                            Unext, nullptr, prm.step_index, e.diag_gamma, opt, s);
     e.last_metric_parts = e.last_update_grid_x;
@@ -153,6 +173,52 @@ int run_update_main(Engine& e, const cesx_step_params& prm, const void* U, const
 int finish_metrics(Engine& e, const double* mom, const void* G, bool publish, hipStream_t s) {
     if (!e.diag_gamma) TRY(launch_data_metrics(e, G, s));
     return launch_metric_final(e, mom, publish, s);
+}
+
+// ---- the lookahead noise block riding on the reduce launches (cesx_internal.h, NoiseRide / Engine::xi_ride) ----
+}  // namespace
+namespace cesx {
+NoiseRide ride_range(Engine& e, unsigned n) {
+    Engine::XiRide& r = e.xi_ride;
+    NoiseRide nr;
+    n = std::min(n, r.total - r.done);
+    nr.xi = e.d_xi[r.buf]; nr.p = e.p; nr.J = e.J; nr.j_offset = e.cfg.j_offset;
+    nr.seed_lo = (unsigned)e.cfg.seed; nr.seed_hi = (unsigned)(e.cfg.seed >> 32); nr.step = (unsigned)r.step;
+    nr.gx = r.gx; nr.wg0 = r.done; nr.nwg = n;
+    r.done += n;
+    if (r.done == r.total) {         // every workgroup of the block is enqueued (r.stream; the side stream's share: xi_seq)
+        e.xi_step[r.buf] = r.step;
+        e.xi_stream[r.buf] = r.stream;
+        r.active = false;
+    }
+    return nr;
+}
+}  // namespace cesx
+namespace {
+// plan the ride of block (xi_want + 1) and return its first share (nothing to ride: xi == nullptr)
+NoiseRide ride_begin(Engine& e, hipStream_t s) {
+    NoiseRide none;
+    if (e.xi_ride.active && e.xi_ride.step != e.xi_want + 1) e.xi_ride.active = false;      // (a ride nobody completed: its buffer stays marked empty)
+    if (!e.xi_ride_ok || e.xi_ride.active || e.xi_want < 0 || !e.xi_lookahead || !e.d_xi[0] || !e.d_xi[1]) return none;
+    if (e.J % 4 != 0 || ((uintptr_t)e.d_xi[0] % (4 * e.esz)) || ((uintptr_t)e.d_xi[1] % (4 * e.esz))) return none;
+    const int have = e.xi_step[0] == e.xi_want ? 0 : e.xi_step[1] == e.xi_want ? 1 : -1;
+    const int lb = have < 0 ? 1 : have ^ 1;      // (have < 0: launch_chol_async draws block xi_want into buffer 0)
+    if (e.xi_step[lb] == e.xi_want + 1) return none;
+    Engine::XiRide& r = e.xi_ride;
+    r.active = true; r.step = e.xi_want + 1; r.buf = lb; r.done = 0; r.stream = s;
+    r.gx = (unsigned)((e.J / 4 + 255) / 256);
+    r.total = r.gx * (unsigned)((e.p + 3) / 4);
+    e.xi_step[lb] = -1;
+    e.xi_stream[lb] = nullptr;
+    e.xi_seq[lb] = 0;
+    return ride_range(e, (unsigned)((unsigned long long)r.total * (unsigned)e.xi_ride_pct / 100));
+}
+// what is left of a ride, as a launch of its own on the ride's stream (the second reduce never came)
+int ride_flush(Engine& e) {
+    if (!e.xi_ride.active) return CESX_OK;
+    hipStream_t s = e.xi_ride.stream;
+    const NoiseRide nr = ride_range(e, e.xi_ride.total);
+    return launch_noise_range(e, nr, s);
 }
 
 // the deferred metric finalisation + publication of the last update (Engine::met_deferred), as a kernel of its own
@@ -216,6 +282,14 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
     if (const char* dv = std::getenv("CESX_DEFER_PUBLISH")) e.met_defer_ok = dv[0] != '0';
     if (const char* fv = std::getenv("CESX_FUSE_CENTER")) e.fuse_center_ok = fv[0] != '0';
     if (const char* pv = std::getenv("CESX_POLL_JOIN")) e.poll_join_ok = pv[0] != '0';
+    if (const char* hv = std::getenv("CESX_HKFREE")) e.hkfree_ok = hv[0] != '0';
+    if (const char* rv = std::getenv("CESX_NOISE_RIDE")) e.xi_ride_ok = rv[0] != '0';
+    if (const char* rv = std::getenv("CESX_NOISE_RIDE_PCT")) {
+        e.xi_ride_ok = true;
+        e.xi_ride_pct = std::max(0, std::min(100, std::atoi(rv)));
+        const char* c = std::strpbrk(rv, ",:");
+        e.xi_ride_pct_side = c ? std::max(0, std::min(100 - e.xi_ride_pct, std::atoi(c + 1))) : 0;
+    }
     if (const char* dv = std::getenv("CESX_TEST_DROP_CHOL_SIGNAL")) e.test_drop_signal_at = (unsigned long long)std::max(0, std::atoi(dv));
     if (const char* tv = std::getenv("CESX_POLL_TIMEOUT_MS")) e.poll_ticks = (unsigned long long)std::max(1, std::atoi(tv)) * 100000ull;
     auto fail = [&](int rc) { g_create_err = e.err; cesx_destroy(reinterpret_cast<cesx_handle>(ep)); return rc; };
@@ -288,6 +362,7 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
         DM(t, (size_t)e.rpad * e.ktot * e.esz); e.d_W = t;
         DM(t, (size_t)e.rpad * e.ktot * e.esz); e.d_Wf = t;
         DM(t, (size_t)e.rpad * e.esz); e.d_bias = t;
+        if (cfg->dtype == CESX_F32) { DM(t, (size_t)e.rpad * e.ktot * 4); e.d_Wq = t; }
         DM(t, (size_t)e.rpad * e.kp * e.esz); e.d_Wfwd = t;
         DM(t, (size_t)e.rpad * e.kp * e.esz); e.d_Wfwd_f = t;
         DM(t, (size_t)e.rpad * e.esz); e.d_bfwd = t;
@@ -324,6 +399,7 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
     DM(e.d_absmax_part, (size_t)update_grid_blocks(e, p) * 8);
     DM(e.d_clk, 4 * 8);
     DM(e.d_cholflag, 128);
+    DM(e.d_qv, (size_t)3 * p * 8); DM(e.d_ticket, 64);
     DM(e.d_lag, 3 * 8);
     DM(e.d_A64, (size_t)n * p * 8); DM(e.d_b64, n * 8); DM(e.d_lvec, 2 * n * 8);
 #undef DM
@@ -368,7 +444,7 @@ void cesx_destroy(cesx_handle h) {
                     e.gp[1].d_type_hdr, e.gp[1].d_rows, e.gp[1].d_wblk, e.gp[1].d_blk_rc, e.gp[1].d_row_own, e.gp[1].d_slabs, e.gp[1].d_rowsum_part, e.d_sums, e.d_ubar, e.d_gbar, e.d_m, e.d_dg,
                     e.d_wdel, e.d_C, e.d_L, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_Kp, e.d_M, e.d_P, e.d_PK,
                     e.d_t1, e.d_t2, e.d_t3, e.d_t4, e.d_Lp, e.d_lanczos, e.d_mv, e.d_part, e.d_scal, e.d_absmax,
-                    e.d_c0, e.d_absmax_part, e.d_clk, e.d_cholflag, e.d_lag, e.d_A64, e.d_b64, e.d_lvec};
+                    e.d_c0, e.d_absmax_part, e.d_clk, e.d_cholflag, e.d_lag, e.d_A64, e.d_b64, e.d_lvec, e.d_Wq, e.d_qv, e.d_ticket};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     for (int w = 0; w < 2; ++w)
@@ -377,7 +453,7 @@ void cesx_destroy(cesx_handle h) {
     if (e.h_scal) (void)hipHostFree(e.h_scal);
     if (e.ev_a) (void)hipEventDestroy(e.ev_a);
     if (e.ev_b) (void)hipEventDestroy(e.ev_b);
-    for (hipEvent_t ev : {e.ev_x[0], e.ev_x[1]})
+    for (hipEvent_t ev : {e.ev_x[0], e.ev_x[1], e.ev_r[0], e.ev_r[1]})
         if (ev) (void)hipEventDestroy(ev);
     if (e.side) (void)hipStreamDestroy(e.side);
     if (e.comm) (void)cesx_comm_destroy(h);
@@ -479,13 +555,15 @@ static int moments_uu_handover(Engine& e, const void* U, const void* G, double* 
     ++e.prof_step;
     if (e.met_deferred && e.met_stream != s) FLUSH(e);
     TRY(launch_gram(e, 0, U, G, mom, s, true));
+    // (the next step's noise block: its first share rides on this reduce launch, the rest on the second one)
+    const NoiseRide nr = ride_begin(e, s);
     if (e.met_deferred) {
         MetricFin f = metric_fin_args(e, nullptr, true);
         f.N = (double)e.Jg;
         e.met_deferred = false;
-        TRY(launch_gram_reduce(e, 0, mom, s, e.ev_a, &f));
+        TRY(launch_gram_reduce(e, 0, mom, s, e.ev_a, &f, &nr));
     } else {
-        TRY(launch_gram_reduce(e, 0, mom, s, e.ev_a));
+        TRY(launch_gram_reduce(e, 0, mom, s, e.ev_a, nullptr, &nr));
     }
     CESX_HIP(hipStreamWaitEvent(e.side, e.ev_a, 0));
     return CESX_OK;
@@ -536,6 +614,10 @@ int cesx_moments_rest(cesx_handle h, const void* U, const void* G, double* mom, 
     FLUSH(e);
     // (the reduce kernel of this launch also copies this shard's data-metric sums of the PREVIOUS
     //  apply to the tail of the buffer: they ride on this step's all-reduce)
+    if (e.xi_ride.active && e.xi_ride.stream == (hipStream_t)stream) {
+        const NoiseRide nr = ride_range(e, e.xi_ride.total);
+        return launch_gram(e, 1, U, G, mom, (hipStream_t)stream, false, &nr);
+    }
     return launch_gram(e, 1, U, G, mom, (hipStream_t)stream);
 }
 
@@ -548,6 +630,7 @@ int cesx_moments_rest_lineal(cesx_handle h, double* mom, void* stream) {
     if (!e.fwd_set) { e.err = "cesx_moments_rest_lineal: cesx_forward_set_lineal has not been called"; return CESX_ESTATE; }
     SET_DEVICE(e);
     FLUSH(e);
+    TRY(ride_flush(e));          // (no second reduce launch on this path)
     return launch_moments_lineal(e, mom, (hipStream_t)stream);
 }
 
@@ -613,7 +696,8 @@ int cesx_apply(cesx_handle h, const cesx_step_params* prm, const double* mom, co
     FLUSH(e);
     hipStream_t s = (hipStream_t)stream;
     e.last_apply = Engine::LastApply{true, *prm, mom, U, G, xi, Unext, s, e.moments_calls};
-    TRY(launch_dense(e, *prm, mom, 0, s));
+    // (whether the update launch qualifies for the LDS-DMA kernel is known here: the hk-free K2 has no other consumer)
+    TRY(launch_dense(e, *prm, mom, 0, s, update2_qualifies(e, U, G, xi, Unext)));
     TRY(run_update_main(e, *prm, U, G, xi, Unext, s));
     // (Moving this last small kernel to the side stream was tried: the event record + wait pair costs
     //  as much GPU idle time as the 7 us kernel itself.)

@@ -184,6 +184,10 @@ __device__ __forceinline__ double ld_agent(const double* ptr) {
     return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+__device__ __forceinline__ void st_agent(double* ptr, double v) {
+    __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // part[blk*4 + 2] = sum A .* B   (dense-Gamma Frobenius term)
 __global__ __launch_bounds__(DT)
 void dot_kernel(const double* __restrict__ A, const double* __restrict__ B, long long len,
@@ -380,7 +384,11 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
                       int cen_unbiased = 0,
                       // done != nullptr: the factor (and the status word) written back at agent scope, then *done =
                       // done_val with release semantics -- what the caller's stream polls instead of waiting for an event
-                      unsigned long long* done = nullptr, unsigned long long done_val = 0) {
+                      unsigned long long* done = nullptr, unsigned long long done_val = 0,
+                      // wq != nullptr: every finished panel also goes, in fp32, into the first K segment (columns [0, wq_kp)) of
+                      // the fragment-major coefficient image of the hk-free update (Engine::d_Wq, wf_index): a row's 8 panel
+                      // entries are two 16-byte pieces of it (even / odd columns = the two k sub-blocks of the MFMA operand)
+                      float* __restrict__ wq = nullptr, int wq_nkt = 0, int wq_kp = 0) {
     if (lda == 0) lda = n;
     if (ldl == 0) ldl = np;
     double cinvN = 1.0, cinvdiv = 1.0;
@@ -528,6 +536,11 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
                 neg[j * LDT + r] = -x[j];
                 dst[j] = x[j];
             }
+            if (wq != nullptr && kb + r < n && kb < wq_kp) {
+                typedef float f4w __attribute__((ext_vector_type(4)));
+                *reinterpret_cast<f4w*>(wq + wf_index(kb + r, kb, wq_nkt)) = f4w{(float)x[0], (float)x[2], (float)x[4], (float)x[6]};
+                *reinterpret_cast<f4w*>(wq + wf_index(kb + r, kb + 1, wq_nkt)) = f4w{(float)x[1], (float)x[3], (float)x[5], (float)x[7]};
+            }
         }
         if (tid < QNB) {                                   // the factored diagonal block itself
             double* dst = Lp + (size_t)(kb + tid) * ldl + kb;
@@ -537,8 +550,18 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
                 cur[j * LDT + tid] = v;
                 dst[j] = v;
             }
+            if (wq != nullptr && kb + tid < n && kb < wq_kp) {
+                typedef float f4w __attribute__((ext_vector_type(4)));
+                float z[QNB];
+#pragma clang loop unroll(full)
+                for (int j = 0; j < QNB; ++j) z[j] = j <= tid ? (float)d[j] : 0.f;
+                *reinterpret_cast<f4w*>(wq + wf_index(kb + tid, kb, wq_nkt)) = f4w{z[0], z[2], z[4], z[6]};
+                *reinterpret_cast<f4w*>(wq + wf_index(kb + tid, kb + 1, wq_nkt)) = f4w{z[1], z[3], z[5], z[7]};
+            }
         }
-        __syncthreads();
+        // (raw barriers in this loop: __syncthreads() also waits for the global STORES of the panel -- vmcnt(0) -- and the
+        //  16 - 24 KB a panel writes leave one CU at ~8 B/clk; nothing in the loop reads global memory)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         PH(2)
         // (d) rank-8 update of the tiles whose columns lie right of the panel (two MFMAs per
         //     tile: A = -L21 rows of the tile, B = L21 rows of the tile's columns); the tile
@@ -579,7 +602,7 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
                 if (s + 1 < SLOTS) { if (two && kn < np && TCOL(s + 1) == kn / 16) publish(s + 1, kn, nxt); }
             }
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         PH(4)
     }
 #undef TROW
@@ -1037,6 +1060,177 @@ void finish_aldi_kernel(MomView mv, cesx_step_params prm, const double* part, Sc
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// ALDI, default time step, fp32, diagonal Gamma / Sigma, the update through the LDS-DMA kernel: the G part of the
+// centring AND what is left of the assembly once hk is out of the coefficient matrix, as ONE launch behind the second
+// reduce (center_kernel(what = 2) + finish_aldi_kernel took two, 8 + 9-17 us beside the noise draw, with W rewritten
+// in full between them).  The side stream has already written L (potrf_reg_kernel), a I - M and M mu, M ubar
+// (center_kernel) into Engine::d_Wq / d_qv; here:
+//   every workgroup : rows of K = C_ug Gamma^{-1} (one wave per row: -K into the image, K_i . y, K_i . gbar),
+//                     S_ee, S_rr and its partial of the Frobenius term, gbar and the data-metric constants;
+//   the LAST one to arrive (ticket): joins the side stream (polled word, as center_kernel did), sums the partials in the
+//                     fixed order of finish_aldi_kernel -> hk, t, metrics (bit-identical scalars), then b' = K y + M mu - a ubar,
+//                     the p diagonal entries a - M_ii + 1/hk of the image and the next centring shift.
+// Nothing of the step is written when the poll runs out (the update launch checks the same fault word).
+// Launched with NPB workgroups of DT threads.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(DT)
+void tail_aldi_kernel(MomView mv, cesx_step_params prm, const double* shift, const double* __restrict__ y,
+                      const double* __restrict__ gw, double* __restrict__ gbar, double* __restrict__ mvec,
+                      double* __restrict__ dg, double* __restrict__ Cug, double* __restrict__ See,
+                      double* __restrict__ Srr, double* __restrict__ K, double* part, Scalars* sc,
+                      double* __restrict__ lag, double* mvs, int mx, const double* __restrict__ sw,
+                      const double* __restrict__ mu, const double* __restrict__ ustar,
+                      float* wq, int nkt, int kp, int kn, float* __restrict__ bias, float* shiftT, double* shift64,
+                      float* __restrict__ rowc, float* __restrict__ gbarT, unsigned* ticket,
+                      const unsigned long long* join, unsigned long long join_want, unsigned long long* fault,
+                      unsigned long long join_ticks) {
+    static_assert(DT == NPB, "one partial per thread");
+    __shared__ double red[DT / 64];
+    __shared__ int s_flag;
+    const int p = mv.p, n = mv.n, tid = threadIdx.x, lane = tid & 63;
+    const double N = mv.N();
+    const double* sa = mv.sa();
+    const double* sb = mv.sb();
+    const double* Sab = mv.Sab();
+    const double* Sbb = mv.Sbb();
+    const unsigned gid = blockIdx.x * DT + tid, gsz = gridDim.x * DT;
+    if (lag != nullptr && gid == 0) { lag[0] = N; lag[1] = mv.mom[mv.ml().tail()]; lag[2] = mv.mom[mv.ml().tail() + 1]; }
+    // rows of K and of M = C Sigma^{-1} (the arithmetic of center_kernel and of finish_aldi_kernel's matvecs, element for
+    // element; M straight from the moments' head: nothing here waits for the side stream).  One WORKGROUP per row: a
+    // thread holds one entry of each (every load of the row is in flight at once -- a wave per row walked its 2 x 4
+    // dependent iterations in ~8 us), the four matvec sums keep finish_aldi_kernel's order (lane l adds its entries
+    // c = l, l + 64, ... in turn, then the shuffle tree) through one LDS exchange per 256 columns.
+    const double* Saa = mv.Saa();
+    const double invN = 1.0 / N, invdiv = 1.0 / (N - 1.0), al0 = (p + 1.0) / N;
+    __shared__ double xch[4][DT];
+    const int wv = tid >> 6;
+    for (int i = blockIdx.x; i < p; i += gridDim.x) {
+        double ky = 0.0, kg = 0.0, mm = 0.0, mu_ = 0.0;
+        const int cmax = p > n ? p : n;
+        for (int c0 = 0; c0 < cmax; c0 += DT) {
+            const int c = c0 + tid;
+            double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+            if (c < p) {
+                const double m_ = cov_entry(Saa[(size_t)i * p + c], sa[i], sa[c], invN, invdiv, i == c, nullptr) * sw[c];
+                if (i == c) st_agent(mvs + (size_t)4 * mx + i, al0 - m_);      // (the diagonal entry gets 1/hk from the last workgroup)
+                else wq[wf_index(i, kp + c, nkt)] = (float)(-m_);
+                v2 = m_ * mu[c];
+                v3 = m_ * (shift[c] + sa[c] / N);
+            }
+            if (c < n) {
+                const size_t k = (size_t)i * n + c;
+                const double cug = (Sab[k] - sa[i] * sb[c] / N) / N;
+                const double kk = cug * gw[c];
+                Cug[k] = cug;
+                K[k] = kk;
+                wq[wf_index(i, 2 * kp + c, nkt)] = (float)(-kk);
+                v0 = kk * y[c];
+                v1 = kk * (shift[p + c] + sb[c] / N);
+            }
+            __syncthreads();
+            xch[0][tid] = v0; xch[1][tid] = v1; xch[2][tid] = v2; xch[3][tid] = v3;
+            __syncthreads();
+            if (wv == 0) {
+#pragma unroll
+                for (int w = 0; w < DT / 64; ++w) {
+                    ky += xch[0][w * 64 + lane]; kg += xch[1][w * 64 + lane];
+                    mm += xch[2][w * 64 + lane]; mu_ += xch[3][w * 64 + lane];
+                }
+            }
+        }
+        if (wv == 0) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                ky += __shfl_down(ky, o, 64); kg += __shfl_down(kg, o, 64);
+                mm += __shfl_down(mm, o, 64); mu_ += __shfl_down(mu_, o, 64);
+            }
+            if (lane == 0) { st_agent(mvs + i, ky); st_agent(mvs + (size_t)mx + i, kg); st_agent(mvs + (size_t)2 * mx + i, mm); st_agent(mvs + (size_t)3 * mx + i, mu_); }
+        }
+    }
+    double fr = 0.0;
+    const unsigned nn = (unsigned)n * n;
+    for (unsigned k = gid; k < nn; k += gsz) {
+        const unsigned i = k / (unsigned)n, j = k - i * (unsigned)n;
+        const double see = Sbb[k] - sb[i] * sb[j] / N;
+        const double mi = shift[p + i] + sb[i] / N - y[i], mj = shift[p + j] + sb[j] / N - y[j];
+        const double srr = see + N * mi * mj;
+        See[k] = see;
+        Srr[k] = srr;
+        fr += see * srr * gw[i] * gw[j];
+    }
+    for (unsigned i = gid; i < (unsigned)kn; i += gsz) {
+        double gb = 0.0;
+        if (i < (unsigned)n) {
+            const double d = sb[i] / N;
+            gb = shift[p + i] + d;
+            gbar[i] = gb;
+            dg[i] = d;
+            mvec[i] = gb - y[i];
+            gbarT[i] = (float)gb;
+        }
+        rowc[i * 4 + 0] = (float)gb;
+        rowc[i * 4 + 1] = (float)(i < (unsigned)n ? y[i] : 0.0);
+        rowc[i * 4 + 2] = (float)(i < (unsigned)n ? gw[i] : 0.0);
+        rowc[i * 4 + 3] = 0.f;
+    }
+    fr = dblock_sum(fr, red);
+    // arrival.  What the last workgroup reads of this one (the Frobenius partial, the row's four sums and diagonal base)
+    // is stored at agent scope (write-through, by the threads that hold it) and waited for; NO write-back of the L2 -- 256
+    // of them beside a noise draw that has tens of MB of dirty lines in flight took this kernel from ~12 to 29 us.
+    // Everything else written above is read by LATER launches only.
+    if (tid == 0) st_agent(part + blockIdx.x * 4 + 2, fr);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_flag = t == gridDim.x - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (s_flag == 0) return;
+    // ---- the last workgroup ----
+    if (tid == 0) {
+        int ok = 1;
+        if (join != nullptr) {
+            const unsigned long long t0 = wall_clock64();
+            while (__hip_atomic_load(join, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < join_want) {
+                __builtin_amdgcn_s_sleep(16);
+                if (wall_clock64() - t0 > join_ticks) {
+                    sc->status = CESX_EHIP;
+                    __hip_atomic_store(fault, join_want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = 0;
+                    break;
+                }
+            }
+        }
+        *ticket = 0u;
+        s_flag = ok ? 2 : 3;
+    }
+    __syncthreads();
+    if (s_flag == 3) return;
+    const double tr = dblock_sum(ld_agent(part + tid * 4), red);
+    const double b2 = dblock_sum(ld_agent(part + tid * 4 + 1), red);
+    const double frs = dblock_sum(ld_agent(part + tid * 4 + 2), red);
+    const double hk = step_hk(prm, N, frs, 0.0), al = (p + 1.0) / N;
+    if (tid == 0) write_scalars(prm, p, N, tr, b2, frs, sc);
+    for (int i = tid; i < p; i += DT) {
+        const double ub = shift[i] + sa[i] / N;
+        const double ky = ld_agent(mvs + i), kg = ld_agent(mvs + (size_t)mx + i);
+        const double mm = ld_agent(mvs + (size_t)2 * mx + i), mu_ = ld_agent(mvs + (size_t)3 * mx + i), db = ld_agent(mvs + (size_t)4 * mx + i);
+        bias[i] = (float)(ky + mm - al * ub);
+        const float st = (float)(ub + (-hk * (mu_ - mm) - hk * (kg - ky)));
+        shiftT[i] = st;
+        shift64[i] = (double)st;
+        wq[wf_index(i, kp + i, nkt)] = (float)(db + 1.0 / hk);
+    }
+    for (int i = tid; i < n; i += DT) {
+        const float st = (float)(shift[p + i] + sb[i] / N);
+        shiftT[p + i] = st;
+        shift64[p + i] = (double)st;
+    }
+}
+
 // forward map A (n x p) -> zero-padded rpad x kp row-major image + the fragment-major image the LDS-DMA update
 // kernels read (wf_index / wd_index), b -> padded offset vector
 template <typename T>
@@ -1163,17 +1357,18 @@ template <int SLOTS>
 static int potrf_reg_launch(Engine& e, hipStream_t s, int n, int np, const double* A, double* Lp, int lda = 0, int ldl = 0,
                             hipEvent_t stop = nullptr,        // stop: event bound to this kernel's own completion signal
                             PotrfCen cen = PotrfCen(),
-                            unsigned long long* done = nullptr, unsigned long long done_val = 0) {
+                            unsigned long long* done = nullptr, unsigned long long done_val = 0, float* wq = nullptr) {
     constexpr int NPMAX = SLOTS <= 2 ? 64 : SLOTS <= 5 ? 128 : SLOTS <= 10 ? 192 : 256;
     const size_t lds = (size_t)3 * QNB * (2 * NPMAX + 4) * 8 + (cen.sa ? (size_t)NPMAX * 8 : 0);      // panel x 2, its negative (each k-row behind NPMAX zeros), the row sums of a fused centring
     CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_reg_kernel<SLOTS>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (stop)
         hipExtLaunchKernelGGL(potrf_reg_kernel<SLOTS>, dim3(1), dim3(PRT), (unsigned)lds, s, nullptr, stop, 0, n, np, A, Lp,
-                              &e.d_scal->status, (long long*)nullptr, lda, ldl, cen.sa, cen.N, cen.unbiased, done, done_val);
+                              &e.d_scal->status, (long long*)nullptr, lda, ldl, cen.sa, cen.N, cen.unbiased, done, done_val,
+                              wq, e.ktot / 16, e.kp);
     else
     hipLaunchKernelGGL(potrf_reg_kernel<SLOTS>, dim3(1), dim3(PRT), lds, s, n, np, A, Lp, &e.d_scal->status, (long long*)nullptr,
-                       lda, ldl, cen.sa, cen.N, cen.unbiased, done, done_val);
+                       lda, ldl, cen.sa, cen.N, cen.unbiased, done, done_val, wq, e.ktot / 16, e.kp);
     CESX_HIP(hipGetLastError());
     return CESX_OK;
 }
@@ -1304,12 +1499,12 @@ int potrf_ld(int n) { return (n + PNB - 1) / PNB * PNB; }
 
 static int potrf_reg_any(Engine& e, hipStream_t s, int n, int np, const double* A, double* Lp, int lda, int ldl,
                          hipEvent_t stop = nullptr, PotrfCen cen = PotrfCen(),
-                         unsigned long long* done = nullptr, unsigned long long done_val = 0) {
+                         unsigned long long* done = nullptr, unsigned long long done_val = 0, float* wq = nullptr) {
     const int T = np / 16, ntile = T * (T + 1) / 2, slots = (ntile + 7) / 8;
-    if (slots <= 2) return potrf_reg_launch<2>(e, s, n, np, A, Lp, lda, ldl, stop, cen, done, done_val);       // np <= 64
-    if (slots <= 5) return potrf_reg_launch<5>(e, s, n, np, A, Lp, lda, ldl, stop, cen, done, done_val);       // np <= 128
-    if (slots <= 10) return potrf_reg_launch<10>(e, s, n, np, A, Lp, lda, ldl, stop, cen, done, done_val);     // np <= 192
-    if (slots <= 17) return potrf_reg_launch<17>(e, s, n, np, A, Lp, lda, ldl, stop, cen, done, done_val);     // np <= 256
+    if (slots <= 2) return potrf_reg_launch<2>(e, s, n, np, A, Lp, lda, ldl, stop, cen, done, done_val, wq);       // np <= 64
+    if (slots <= 5) return potrf_reg_launch<5>(e, s, n, np, A, Lp, lda, ldl, stop, cen, done, done_val, wq);       // np <= 128
+    if (slots <= 10) return potrf_reg_launch<10>(e, s, n, np, A, Lp, lda, ldl, stop, cen, done, done_val, wq);     // np <= 192
+    if (slots <= 17) return potrf_reg_launch<17>(e, s, n, np, A, Lp, lda, ldl, stop, cen, done, done_val, wq);     // np <= 256
     e.err = "potrf: diagonal block too large for the register kernel";
     return CESX_EINVAL;
 }
@@ -1330,16 +1525,17 @@ static int trsm_reg(Engine& e, hipStream_t s, int nr, int nc, const double* A, i
 // completion signal (hipExtLaunchKernel: no separate marker packet on the stream -- a marker costs ~6 us before the
 // next kernel of the stream starts); the blocked path records it behind its last kernel.
 static int potrf(Engine& e, hipStream_t s, int n, const double* A, double* Lp, hipEvent_t stop = nullptr,
-                 unsigned long long* done = nullptr, unsigned long long done_val = 0) {      // done: stored by the chain's last kernel
+                 unsigned long long* done = nullptr, unsigned long long done_val = 0,      // done: stored by the chain's last kernel
+                 float* wq = nullptr) {                                                      // wq: the hk-free update's image (one-kernel factorisations)
     const int np = potrf_ld(n);
     if (np <= 256) {
         if (stop && !e.ext_events) {
-            int rc0 = potrf_reg_any(e, s, n, np, A, Lp, 0, 0, nullptr, PotrfCen(), done, done_val);
+            int rc0 = potrf_reg_any(e, s, n, np, A, Lp, 0, 0, nullptr, PotrfCen(), done, done_val, wq);
             if (rc0) return rc0;
             CESX_HIP(hipEventRecord(stop, s));
             return CESX_OK;
         }
-        return potrf_reg_any(e, s, n, np, A, Lp, 0, 0, stop, PotrfCen(), done, done_val);
+        return potrf_reg_any(e, s, n, np, A, Lp, 0, 0, stop, PotrfCen(), done, done_val, wq);
     }
     // Blocked right-looking factorisation with 256-wide diagonal blocks (p > 256): register
     // Cholesky of the diagonal block, register TRSM of the rows below it (64 rows per
@@ -1439,7 +1635,7 @@ bool stream_below_side(Engine& e, hipStream_t s) {
     return ok;
 }
 
-int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int phase, hipStream_t s) {
+int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int phase, hipStream_t s, bool upd2_ok) {
     const int p = e.p, n = e.n, mx = p > n ? p : n;
     const bool f32 = e.cfg.dtype == CESX_F32;
     int rc;
@@ -1462,6 +1658,39 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
     // (early, centring fused into the Cholesky's load: the U part is done HERE, with the G part, and leaves the
     //  status word alone -- the side stream carried nothing but the factorisation)
     const int what = !early ? 3 : e.chol_fused_center ? (3 | 4) : 2;
+    // hk kept out of the coefficient matrix (cesx_internal.h, Engine::d_Wq): the side stream wrote L, a I - M, M mu, M ubar
+    // for this factorisation, ONE launch adds the rest and the update kernel takes hk at run time
+    const bool img_ok = e.hkfree_ok && e.d_Wq != nullptr && f32 && e.update_v2 && e.diag_gamma && e.diag_sigma && potrf_ld(p) <= 256;
+    const bool hkfree = upd2_ok && fused_finish && prm.time_step == CESX_TS_DEFAULT && img_ok &&
+        (early ? e.side_img && !e.chol_fused_center : true);
+    e.last_hkfree = false;
+    if (hkfree) {
+        // the side stream is joined by the LAST workgroup of that launch (a polled word, under the conditions of the polled
+        // join below), else by the event in front of it; no factorisation in flight: the U part runs here, in line
+        const bool polled = early && e.poll_join_ok && e.chol_signals && e.J == e.Jg && s != e.side && stream_below_side(e, s);
+        if (!early) {
+            hipLaunchKernelGGL(center_kernel, dim3(NPB), dim3(DT), 0, s, mv, e.d_shift64, e.d_y, e.d_ustar,
+                               (const double*)e.d_gw, (const double*)e.d_sw, unbiased, 1, e.d_ubar, e.d_gbar,
+                               e.d_m, e.d_dg, e.d_C, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_M, e.d_part, e.d_scal, (double*)nullptr);
+            CESX_HIP(hipGetLastError());
+            if ((rc = potrf(e, s, p, e.d_C, e.d_L, nullptr, nullptr, 0, (float*)e.d_Wq))) return rc;
+        } else if (!polled) CESX_HIP(hipStreamWaitEvent(s, e.ev_b, 0));
+        hipLaunchKernelGGL(tail_aldi_kernel, dim3(NPB), dim3(DT), 0, s, mv, prm, (const double*)e.d_shift64, (const double*)e.d_y,
+                           (const double*)e.d_gw, e.d_gbar, e.d_m, e.d_dg, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_part, e.d_scal,
+                           e.d_lag, e.d_mv, mx, (const double*)e.d_sw, (const double*)e.d_mu, (const double*)e.d_ustar, (float*)e.d_Wq, e.ktot / 16, e.kp,
+                           e.kn, (float*)e.d_bias, (float*)e.d_shiftT, e.d_shift64, (float*)e.d_rowc, (float*)e.d_gbarT,
+                           e.d_ticket, polled ? (const unsigned long long*)e.d_cholflag : (const unsigned long long*)nullptr,
+                           (unsigned long long)e.chol_seq, e.d_cholflag + 1, e.poll_ticks);
+        CESX_HIP(hipGetLastError());
+        e.last_join_polled = polled;
+        if (early) {
+            e.evb_waited_seq = e.chol_seq;
+            e.evb_waited_stream = s;
+            e.chol_inflight = false;
+        }
+        e.last_hkfree = true;
+        return CESX_OK;
+    }
     // The side stream joined WITHOUT a barrier packet (6-8 us of the caller's stream even when the event completed long
     // before): workgroup 0 of the G-part centring launch -- the launch in front of the assembly launch -- ends only when
     // chol(C) has stored its sequence number, and the assembly launch reads what that stream wrote with agent-scope
@@ -1593,6 +1822,7 @@ int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s, b
     // (round 4: also measured at C4 -- p = 64, where the separate centring launch is a third of the side chain: 0.0844
     //  against 0.0805 ms/step with it fused, the one workgroup's load phase is the longer way; stays opt-in)
     e.chol_fused_center = e.fuse_center_ok && potrf_ld(p) <= 256;
+    e.side_img = false;
     if (e.chol_fused_center) {
         // p <= 256 (one register-resident factorisation): the covariance is formed while the kernel loads the raw
         // second moments -- no centring launch (13 us + a kernel boundary) in front of the 100-us Cholesky, which is
@@ -1607,6 +1837,11 @@ int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s, b
             CESX_HIP(hipEventRecord(e.ev_b, e.side));
         }
     } else {
+    // the hk-free update's share of the side stream (cesx_internal.h, Engine::d_Wq): whether the step takes that path is
+    // decided in cesx_apply (time-step rule, alignment of the ensembles); writing the images costs these kernels ~1 us
+    e.side_img = e.hkfree_ok && e.d_Wq != nullptr && e.cfg.dtype == CESX_F32 && update == CESX_UPDATE_ALDI && e.update_v2 &&
+        e.diag_gamma && e.diag_sigma && potrf_ld(p) <= 256;
+    float* wq = e.side_img ? (float*)e.d_Wq : (float*)nullptr;
     // (few workgroups -> 1024 threads each: 8 x 256 threads took 25 us for the 65 k elements of C, latency bound)
     hipLaunchKernelGGL(center_kernel, dim3(std::min(NPB, e.center_u_wgs)), dim3(e.center_u_wgs < NPB ? 1024 : DT), 0, e.side, mv, e.d_shift64, e.d_y, e.d_ustar,
                        e.diag_gamma ? e.d_gw : (const double*)nullptr,
@@ -1615,7 +1850,7 @@ int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s, b
     CESX_HIP(hipGetLastError());
     // (CESX_TEST_DROP_CHOL_SIGNAL=k, tests only: the k-th factorisation does not store its word -- the polled join of that step runs out)
     unsigned long long* flag = e.test_drop_signal_at == e.chol_seq + 1 ? nullptr : e.d_cholflag;
-    if ((rc = potrf(e, e.side, p, e.d_C, e.d_L, e.ev_b, flag, e.chol_seq + 1))) return rc;      // ev_b: C, M, ubar, L -- what K2's scalar and assemble kernels read
+    if ((rc = potrf(e, e.side, p, e.d_C, e.d_L, e.ev_b, flag, e.chol_seq + 1, wq))) return rc;      // ev_b: C, M, ubar, L -- what K2's scalar and assemble kernels read
     }
     e.chol_signals = true;      // (the one-kernel factorisation, or the last diagonal block of the blocked one, stores the word)
     ++e.chol_seq;
@@ -1627,6 +1862,7 @@ int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s, b
             CESX_HIP(hipEventRecord(e.ev_x[b], e.side));
             e.xi_step[b] = step;
             e.xi_seq[b] = e.chol_seq;
+            e.xi_stream[b] = nullptr;
             return CESX_OK;
         };
         int have = e.xi_step[0] == e.xi_want ? 0 : (e.d_xi[1] && e.xi_step[1] == e.xi_want) ? 1 : -1;
@@ -1634,7 +1870,17 @@ int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s, b
             have = 0;
             if ((rc = draw(e.xi_want, 0))) return rc;
         }
-        if (e.xi_lookahead && e.d_xi[1] && e.xi_step[have ^ 1] != e.xi_want + 1)
+        // (the lookahead block may be riding on the caller's reduce launches instead: Engine::xi_ride)
+        const bool riding = e.xi_ride.active && e.xi_ride.step == e.xi_want + 1;
+        if (riding && e.xi_ride_pct_side > 0) {
+            // the side stream's share of the riding block: behind chol(C), beside the tail of K2
+            const int b = e.xi_ride.buf;
+            const NoiseRide nr = ride_range(e, (unsigned)((unsigned long long)e.xi_ride.total * (unsigned)e.xi_ride_pct_side / 100));
+            if ((rc = launch_noise_range(e, nr, e.side))) return rc;
+            CESX_HIP(hipEventRecord(e.ev_x[b], e.side));
+            e.xi_seq[b] = e.chol_seq;
+        }
+        if (e.xi_lookahead && e.d_xi[1] && !riding && e.xi_step[have ^ 1] != e.xi_want + 1)
             if ((rc = draw(e.xi_want + 1, have ^ 1))) return rc;
         e.xi_want = -1;
     }

@@ -273,9 +273,15 @@ __global__ __launch_bounds__(RED_G * RED_S)
 void gram_reduce_kernel(const T* __restrict__ slabs, const int* __restrict__ blk_rc, const int* __restrict__ row_own,
                         int nblocks, int tile, MomLayout ml, long long J, int row_lo, int row_hi,
                         int write_N, const double* __restrict__ rowsum_part, const double* __restrict__ tail_src,
-                        double* __restrict__ mom, const MetricFin fin) {
+                        double* __restrict__ mom, const MetricFin fin, const NoiseRide ride, unsigned ride_first) {
     using vec_t = typename Mfma<T>::vec_t;
     constexpr int VEC = Mfma<T>::VEC;
+    // workgroups behind the reduce's own: a share of the next step's noise block (cesx_internal.h, NoiseRide)
+    if (blockIdx.x >= ride_first) {
+        const unsigned id = ride.wg0 + (blockIdx.x - ride_first);
+        noise_body<T, true>((T*)ride.xi, ride.p, ride.J, ride.j_offset, ride.seed_lo, ride.seed_hi, ride.step, id % ride.gx, id / ride.gx);
+        return;
+    }
     // the previous update's metric finalisation + publication, riding on this launch as one extra workgroup -- the
     // FIRST one: its chain of dependent loads, fences and the write to host memory (~8 us) starts with the launch and
     // ends inside it
@@ -693,36 +699,39 @@ static int launch_gram_t(Engine& e, int part, const void* U, const void* G, hipS
 }
 
 template <typename T>
-static int launch_gram_reduce_t(Engine& e, int part, double* mom, hipStream_t s, hipEvent_t stop, const MetricFin* fin) {
+static int launch_gram_reduce_t(Engine& e, int part, double* mom, hipStream_t s, hipEvent_t stop, const MetricFin* fin, const NoiseRide* ride) {
     GramPart& gp = e.gp[part];
     const GramPlan& pl = gp.plan;
     const long long ngroups = (long long)pl.nblocks * pl.tile * pl.tile / Mfma<T>::VEC;
     const int row_lo = std::min(pl.own_lo * pl.tile, e.p + e.n), row_hi = std::min(pl.own_hi * pl.tile, e.p + e.n);
     const long long wgs = (ngroups + RED_G - 1) / RED_G + std::max(1, (row_hi - row_lo + RED_G - 1) / RED_G) + (fin ? 1 : 0);
     const MetricFin f = fin ? *fin : MetricFin{};
+    const NoiseRide nr = ride ? *ride : NoiseRide{};
+    const unsigned ride_first = (unsigned)wgs;
+    const long long wgs_all = wgs + (nr.xi ? nr.nwg : 0);
     if (stop)
-        hipExtLaunchKernelGGL(gram_reduce_kernel<T>, dim3((unsigned)wgs), dim3(RED_G * RED_S), 0, s, nullptr, stop, 0,
+        hipExtLaunchKernelGGL(gram_reduce_kernel<T>, dim3((unsigned)wgs_all), dim3(RED_G * RED_S), 0, s, nullptr, stop, 0,
                               (const T*)gp.d_slabs, (const int*)gp.d_blk_rc, (const int*)gp.d_row_own, pl.nblocks, pl.tile, e.ml,
                               (long long)e.J, row_lo, row_hi, part == 0 ? 1 : 0, (const double*)gp.d_rowsum_part,
-                              part == 1 ? (const double*)e.d_metric_sums : (const double*)nullptr, mom, f);
+                              part == 1 ? (const double*)e.d_metric_sums : (const double*)nullptr, mom, f, nr, ride_first);
     else
-    hipLaunchKernelGGL(gram_reduce_kernel<T>, dim3((unsigned)wgs), dim3(RED_G * RED_S), 0, s,
+    hipLaunchKernelGGL(gram_reduce_kernel<T>, dim3((unsigned)wgs_all), dim3(RED_G * RED_S), 0, s,
                        (const T*)gp.d_slabs, gp.d_blk_rc, gp.d_row_own, pl.nblocks, pl.tile, e.ml,
                        (long long)e.J, row_lo, row_hi, part == 0 ? 1 : 0, gp.d_rowsum_part,
-                       part == 1 ? e.d_metric_sums : (const double*)nullptr, mom, f);
+                       part == 1 ? e.d_metric_sums : (const double*)nullptr, mom, f, nr, ride_first);
     CESX_HIP(hipGetLastError());
     return CESX_OK;
 }
 
-int launch_gram_reduce(Engine& e, int part, double* mom, hipStream_t s, hipEvent_t stop, const MetricFin* fin) {
-    return e.cfg.dtype == CESX_F32 ? launch_gram_reduce_t<float>(e, part, mom, s, stop, fin)
-                                   : launch_gram_reduce_t<double>(e, part, mom, s, stop, fin);
+int launch_gram_reduce(Engine& e, int part, double* mom, hipStream_t s, hipEvent_t stop, const MetricFin* fin, const NoiseRide* ride) {
+    return e.cfg.dtype == CESX_F32 ? launch_gram_reduce_t<float>(e, part, mom, s, stop, fin, ride)
+                                   : launch_gram_reduce_t<double>(e, part, mom, s, stop, fin, ride);
 }
 
-int launch_gram(Engine& e, int part, const void* U, const void* G, double* mom, hipStream_t s, bool no_reduce) {
+int launch_gram(Engine& e, int part, const void* U, const void* G, double* mom, hipStream_t s, bool no_reduce, const NoiseRide* ride) {
     int rc = e.cfg.dtype == CESX_F32 ? launch_gram_t<float>(e, part, U, G, s) : launch_gram_t<double>(e, part, U, G, s);
     if (rc != CESX_OK || no_reduce) return rc;
-    return launch_gram_reduce(e, part, mom, s);
+    return launch_gram_reduce(e, part, mom, s, nullptr, nullptr, ride);
 }
 
 int gram_nbw(int dtype) { return dtype == CESX_F32 ? GramCfg<float>::NBW : GramCfg<double>::NBW; }

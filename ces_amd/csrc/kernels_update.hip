@@ -380,28 +380,14 @@ template <typename T, bool VEC4>
 __global__ __launch_bounds__(256)
 void noise_kernel(T* __restrict__ xi, int p, long long J, long long j_offset, unsigned seed_lo,
                   unsigned seed_hi, unsigned step) {
-    constexpr int NP = VEC4 ? 4 : 1;
-    const long long j0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * NP;
-    const int q = blockIdx.y;
-    if (j0 >= J) return;
-    T z[NP][4];
-#pragma unroll
-    for (int c = 0; c < NP; ++c) {
-        const unsigned long long gj = (unsigned long long)(j_offset + j0 + c);
-        const uint4x r = philox4x32_10((uint32_t)gj, (uint32_t)(gj >> 32), (uint32_t)q, step, seed_lo, seed_hi);
-        normal4(r, z[c]);
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        if (4 * q + e >= p) break;
-        T* dst = xi + (size_t)(4 * q + e) * J + j0;
-        if (VEC4) {
-            typedef T v4 __attribute__((ext_vector_type(4)));
-            *reinterpret_cast<v4*>(dst) = v4{z[0][e], z[NP > 1 ? 1 : 0][e], z[NP > 2 ? 2 : 0][e], z[NP > 3 ? 3 : 0][e]};
-        } else {
-            dst[0] = z[0][e];
-        }
-    }
+    noise_body<T, VEC4>(xi, p, J, j_offset, seed_lo, seed_hi, step, blockIdx.x, blockIdx.y);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256)
+void noise_range_kernel(const NoiseRide r) {
+    const unsigned id = r.wg0 + blockIdx.x;
+    noise_body<T, true>((T*)r.xi, r.p, r.J, r.j_offset, r.seed_lo, r.seed_hi, r.step, id % r.gx, id / r.gx);
 }
 
 // ---------------------------------------------------------------------------
@@ -476,6 +462,7 @@ int launch_update(Engine& e, int out_rows, const void* W, int ktot, const void* 
                              absmax_part, metrics, opt, s);
         if (rc != -1) return rc;
     }
+    if (opt.hkp) { e.err = "update: the hk-free coefficient image has no fallback kernel"; return CESX_EINVAL; }
     return e.cfg.dtype == CESX_F32
         ? update_t<float>(e, out_rows, W, ktot, bias, src, nsrc, add1, c1, c1_imm, add2, c2, c2_imm, out, absmax_part, step_index, metrics, opt, s)
         : update_t<double>(e, out_rows, W, ktot, bias, src, nsrc, add1, c1, c1_imm, add2, c2, c2_imm, out, absmax_part, step_index, metrics, opt, s);
@@ -507,6 +494,14 @@ int launch_noise(Engine& e, uint64_t step_index, void* xi, hipStream_t s) {
     } else {
         if (vec4) go(noise_kernel<double, true>, (double*)xi); else go(noise_kernel<double, false>, (double*)xi);
     }
+    CESX_HIP(hipGetLastError());
+    return CESX_OK;
+}
+
+int launch_noise_range(Engine& e, const NoiseRide& r, hipStream_t s) {
+    if (r.nwg == 0) return CESX_OK;
+    if (e.cfg.dtype == CESX_F32) hipLaunchKernelGGL(noise_range_kernel<float>, dim3(r.nwg), dim3(256), 0, s, r);
+    else hipLaunchKernelGGL(noise_range_kernel<double>, dim3(r.nwg), dim3(256), 0, s, r);
     CESX_HIP(hipGetLastError());
     return CESX_OK;
 }

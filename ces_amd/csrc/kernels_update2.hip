@@ -51,6 +51,7 @@ struct Upd2Args {
     int stagger_n;        // ... by this many s_sleep(100) = 6.4k cycles each
     long long* clk;       // profiled launches only: wave 0 of workgroup (0, 0) writes its {s_memtime, s_memrealtime} ticks
     const unsigned long long* fault; unsigned long long fault_seq;   // fault != nullptr and *fault == fault_seq: leave `out` untouched (UpdateOpt)
+    const double* hkp; const double* s2p;      // HKF instantiations: the time step and sqrt(2 hk), read at run time (UpdateOpt)
 };
 
 // wait until at most `n` of this wave's DMAs are outstanding, retire its LDS traffic, barrier
@@ -111,8 +112,12 @@ __device__ __forceinline__ void noise_pair(uint32_t a, uint32_t b, float& z0, fl
 }
 
 // NOISE = false: every K segment is read from memory (xi injected or drawn ahead); the Philox stages and their
-// branches are compiled out of the K loop
-template <bool NOISE>
+// branches are compiled out of the K loop.
+// HKF: W carries no time step (Engine::d_Wq, segments [xi | U | G] = [L | a I - M + I/hk | -K]): behind the first
+// segment the accumulators hold L xi and are scaled once by sqrt(2 hk) / hk, the other segments add (a I - M + I/hk) U - K G,
+// and the epilogue multiplies (sum + b') by hk:  U_next = sqrt(2hk) L xi + U + hk ((a I - M) U - K G + b')
+// (ces/calibrate.py:484-488 with the step size factored out of the coefficient matrix).
+template <bool NOISE, bool HKF = false>
 __global__ __launch_bounds__(U2_THREADS, 2)
 void update2_kernel(const Upd2Args a) {
     // a polled join of the side stream that ran out in front of this launch (kernels_dense.hip): W is stale, the output stays as it was
@@ -135,6 +140,12 @@ void update2_kernel(const Upd2Args a) {
     if (a.clk != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0) {
         const long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
         if (lane == 0) { a.clk[0] = c0; a.clk[1] = r0; }
+    }
+    float hkf = 1.f, cres = 1.f;
+    if (HKF) {
+        const double hk = *a.hkp;
+        hkf = (float)hk;
+        cres = (float)(*a.s2p / hk);
     }
     const int li = lane & 31, lh = lane >> 5;
     const long long jt0 = (long long)blockIdx.x * U2_BN;
@@ -285,6 +296,14 @@ void update2_kernel(const Upd2Args a) {
         if (kt == a.kt1) clk_s1 = clock64();
         if (kt == a.kt2) clk_s2 = clock64();
 #endif
+        if (HKF && kt == a.kt1) {          // (wave-uniform, once per kernel: L xi -> sqrt(2/hk) L xi)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[r][c][e] *= cres;
+        }
         wt += 16 * 1024;
         const TileD d2 = make_tile<NOISE>(kt + 2, a);
         const bool intri = kt >= tri_t0 && kt < tri_t1;
@@ -415,6 +434,7 @@ void update2_kernel(const Upd2Args a) {
                     const float bi = a.bias ? a.bias[i] : 0.f;
                     const size_t o = (size_t)i * a.J + j;
                     f4 v = {acc[r][0][e] + bi, acc[r][1][e] + bi, acc[r][2][e] + bi, acc[r][3][e] + bi};
+                    if (HKF) v *= hkf;
                     if (a.add1) v += (float)c1 * *reinterpret_cast<const f4*>(a.add1 + o);
                     if (a.add2) v += (float)c2 * *reinterpret_cast<const f4*>(a.add2 + o);
                     // (non-temporal: the 67 MB of U_next are not read again by this kernel; the lines leave L2 as they
@@ -501,6 +521,14 @@ void update2_kernel(const Upd2Args a) {
 #undef U2_LDSP
 }
 
+bool update2_qualifies(const Engine& e, const void* U, const void* G, const void* xi, const void* Unext) {
+    if (e.cfg.dtype != CESX_F32 || !e.update_v2) return false;
+    if (e.J % 4 != 0 || e.J < 4 || e.ktot % U2_BK != 0) return false;
+    if (U2_RING * (U2_WSLOT + U2_XSLOT) + e.kn * 16 > 80 * 1024) return false;
+    auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    return U && G && Unext && al16(U) && al16(G) && al16(Unext) && (!xi || al16(xi));
+}
+
 int launch_update2(Engine& e, int out_rows, const void* Wf, int ktot, const void* bias,
                    const UpdateSrc* src, int nsrc,
                    const void* add1, const double* c1, double c1_imm,
@@ -541,13 +569,16 @@ int launch_update2(Engine& e, int out_rows, const void* Wf, int ktot, const void
     a.metric_part = metrics ? e.d_metric_part : nullptr;
     a.metric_seg = opt.metric_seg;
     a.fault = opt.fault; a.fault_seq = opt.fault_seq;
+    a.hkp = opt.hkp; a.s2p = opt.s2p;
+    if (opt.hkp && (!opt.s2p || nsrc != 3 || a.tri_seg != 0 || add1 || add2)) { e.err = "update: the hk-free form needs [xi | U | G] with the triangular segment first"; return CESX_EINVAL; }
     dim3 grid((unsigned)((e.J + U2_BN - 1) / U2_BN), (unsigned)((out_rows + U2_RC - 1) / U2_RC));
     // the dispatcher gives every CU one workgroup before any CU gets its second: from there on start late
     a.stagger_from = (long long)grid.x * grid.y > e.num_cus ? e.num_cus : 0x7fffffff;
     a.stagger_n = 2;
     if (const char* sv = std::getenv("CESX_U2_STAGGER")) a.stagger_n = std::atoi(sv);
     const bool noise = kind[0] != 0 || kind[1] != 0 || kind[2] != 0;
-    auto kern = noise ? update2_kernel<true> : update2_kernel<false>;
+    auto kern = opt.hkp ? (noise ? update2_kernel<true, true> : update2_kernel<false, true>)
+                        : (noise ? update2_kernel<true, false> : update2_kernel<false, false>);
     CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     e.last_update_grid_x = (int)grid.x;

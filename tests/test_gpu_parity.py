@@ -619,6 +619,9 @@ def test_single_device_fast_path_variants_match(eng_mod, monkeypatch, dtype):
     p, n, J = 128, 96, 8192
     d = _synthetic(p, n, J, seed=77)
     outs = []
+    # (the assembled form of the coefficient matrix on both sides: the hk-free form of the fused launch rounds differently,
+    #  test_hk_free_update_matches_the_assembled_form holds it to the assembled one)
+    monkeypatch.setenv("CESX_HKFREE", "0")
     for fast, pipelined in ((True, True), (True, False), (False, True), (False, False)):
         for k in ("CESX_EXT_EVENTS", "CESX_DEFER_PUBLISH", "CESX_NOISE_LOOKAHEAD"):
             monkeypatch.setenv(k, "1" if fast else "0")
@@ -728,6 +731,30 @@ def _aldi_chain(eng_mod, d, p, n, J, dtype, nsteps=4, pipelined=False, stream=No
     finally:
         if ctx is not None:
             ctx.__exit__(None, None, None)
+
+
+@pytest.mark.parametrize("p,n,J", [(256, 256, 16384), (128, 96, 8192), (96, 80, 4096), (40, 24, 2048)])
+def test_hk_free_update_matches_the_assembled_form(eng_mod, monkeypatch, p, n, J):
+    """fp32, ALDI, default time step, diagonal Gamma / Sigma: K2 keeps the time step OUT of the coefficient matrix
+    (tail_aldi_kernel: W = [L | a I - M + I/hk | -K], the factorisation stores L into the image itself) and K3 applies hk
+    and sqrt(2 hk) at run time (xi segment first, one rescale, result times hk).  Same numbers up to fp32 rounding as
+    the assembled form W = [(1 + hk a) I - hk M | -hk K | sqrt(2hk) L] (CESX_HKFREE=0), with bit-identical step sizes as
+    long as the ensembles agree (first step) and deterministic from run to run; pipelined and step by step, polled and
+    event-joined."""
+    d = _synthetic(p, n, J, seed=p + n)
+    monkeypatch.setenv("CESX_HKFREE", "0")
+    _, U0, c0, _ = _aldi_chain(eng_mod, d, p, n, J, "float32")
+    monkeypatch.setenv("CESX_HKFREE", "1")
+    _, U1, c1, _ = _aldi_chain(eng_mod, d, p, n, J, "float32")
+    _, U2, c2, _ = _aldi_chain(eng_mod, d, p, n, J, "float32", pipelined=True)
+    monkeypatch.setenv("CESX_POLL_JOIN", "0")
+    _, U3, c3, _ = _aldi_chain(eng_mod, d, p, n, J, "float32", pipelined=True)
+    assert np.array_equal(c1[0, :4], c0[0, :4])                      # hk, t, bias, self-bias of the first step: the same sums
+    scale = np.max(np.abs(U0))
+    assert np.max(np.abs(U1 - U0)) <= 2e-5 * scale, np.max(np.abs(U1 - U0)) / scale
+    assert np.allclose(c1, c0, rtol=2e-5, atol=0)
+    for U, c in ((U2, c2), (U3, c3)):                                 # the same launches on the same numbers
+        assert np.array_equal(U, U1) and np.array_equal(c, c1)
 
 
 def test_polled_join_that_runs_out_leaves_the_step_untouched_and_is_rerun(eng_mod, monkeypatch):
