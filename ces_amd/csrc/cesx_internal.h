@@ -110,12 +110,19 @@ __host__ __device__ __forceinline__ uint4x philox4x32_10(uint32_t c0, uint32_t c
     return {c0, c1, c2, c3};
 }
 
+// Box-Muller radius sqrt(-2 ln u), u in [2^-25, 1): the bare v_log_f32 / v_sqrt_f32 (1 ulp each; no denormal scaling,
+// no Newton step around the square root -- the library forms cost 14 % of the noise draw's vector instructions, and the
+// draw is paid for in full wherever it runs: round 4).  Shared by normal4 and the in-kernel draw of kernels_update2.hip.
+__device__ __forceinline__ float bm_radius(float u) {
+    return __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u));      // -2 ln 2 * log2(u)
+}
+
 // Four N(0,1) draws for rows 4q..4q+3 of one particle (Box-Muller on two pairs).
 __device__ __forceinline__ void normal4(uint4x r, float out[4]) {
     const float s = 5.9604644775390625e-08f;   // 2^-24
     float u0 = ((float)(r.x >> 8) + 0.5f) * s, u1 = ((float)(r.y >> 8) + 0.5f) * s;
     float u2 = ((float)(r.z >> 8) + 0.5f) * s, u3 = ((float)(r.w >> 8) + 0.5f) * s;
-    float ra = __builtin_sqrtf(-2.0f * __logf(u0)), rb = __builtin_sqrtf(-2.0f * __logf(u2));
+    float ra = bm_radius(u0), rb = bm_radius(u2);
     // v_sin_f32 / v_cos_f32 take their argument in revolutions
     out[0] = ra * __builtin_amdgcn_cosf(u1);
     out[1] = ra * __builtin_amdgcn_sinf(u1);

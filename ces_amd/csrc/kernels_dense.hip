@@ -1209,15 +1209,22 @@ void tail_aldi_kernel(MomView mv, cesx_step_params prm, const double* shift, con
     }
     __syncthreads();
     if (s_flag == 3) return;
-    const double tr = dblock_sum(ld_agent(part + tid * 4), red);
-    const double b2 = dblock_sum(ld_agent(part + tid * 4 + 1), red);
-    const double frs = dblock_sum(ld_agent(part + tid * 4 + 2), red);
+    // (every agent-scope load of this phase goes out before the first sum: one round trip, not four)
+    const double q0 = ld_agent(part + tid * 4), q1 = ld_agent(part + tid * 4 + 1), q2 = ld_agent(part + tid * 4 + 2);
+    const int i0 = tid < p ? tid : 0;
+    const double ky0 = ld_agent(mvs + i0), kg0 = ld_agent(mvs + (size_t)mx + i0), mm0 = ld_agent(mvs + (size_t)2 * mx + i0),
+                 mu0 = ld_agent(mvs + (size_t)3 * mx + i0), db0 = ld_agent(mvs + (size_t)4 * mx + i0);
+    const double tr = dblock_sum(q0, red);
+    const double b2 = dblock_sum(q1, red);
+    const double frs = dblock_sum(q2, red);
     const double hk = step_hk(prm, N, frs, 0.0), al = (p + 1.0) / N;
     if (tid == 0) write_scalars(prm, p, N, tr, b2, frs, sc);
     for (int i = tid; i < p; i += DT) {
         const double ub = shift[i] + sa[i] / N;
-        const double ky = ld_agent(mvs + i), kg = ld_agent(mvs + (size_t)mx + i);
-        const double mm = ld_agent(mvs + (size_t)2 * mx + i), mu_ = ld_agent(mvs + (size_t)3 * mx + i), db = ld_agent(mvs + (size_t)4 * mx + i);
+        const bool first = i == tid;
+        const double ky = first ? ky0 : ld_agent(mvs + i), kg = first ? kg0 : ld_agent(mvs + (size_t)mx + i);
+        const double mm = first ? mm0 : ld_agent(mvs + (size_t)2 * mx + i), mu_ = first ? mu0 : ld_agent(mvs + (size_t)3 * mx + i),
+                     db = first ? db0 : ld_agent(mvs + (size_t)4 * mx + i);
         bias[i] = (float)(ky + mm - al * ub);
         const float st = (float)(ub + (-hk * (mu_ - mm) - hk * (kg - ky)));
         shiftT[i] = st;

@@ -562,7 +562,7 @@ GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset, 
         w[t] = gram_tile_cost(tile, (int)types[t].size(), (int)rws.size());
         total += w[t];
     }
-    if (pl.ntypes <= 4 && !std::getenv("CESX_GRAM_PROPORTIONAL")) {
+    if ((pl.ntypes <= 4 || std::getenv("CESX_GRAM_LEVEL_ALL")) && !std::getenv("CESX_GRAM_PROPORTIONAL")) {
         // few types, many slices each: whole tiles per slice, levelled (gram_level_slices)
         gram_level_slices(w, std::max(wg_budget, pl.ntypes), ntiles, nsl);
     } else {

@@ -327,7 +327,16 @@ void gram2_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __r
             // (plain stores: the reduce launch right behind reads the slabs back; non-temporal stores, which drop
             //  the lines from L2, cost the step 1.6 % in round 3)
             vec_t* dst = reinterpret_cast<vec_t*>(out + (size_t)(q * 64 + lane) * VEC);
-            if (G2_OPT & 16) __builtin_nontemporal_store(v, dst); else *dst = v;
+            typedef float st4_t __attribute__((ext_vector_type(4)));
+            if (G2_OPT & 32) {          // write-through at agent scope: no dirty slab lines left for the kernel boundary to flush
+                st4_t sv;
+                __builtin_memcpy(&sv, &v, 16);
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(sv) : "memory");
+            } else if (G2_OPT & 64) {
+                st4_t sv;
+                __builtin_memcpy(&sv, &v, 16);
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dst), "v"(sv) : "memory");
+            } else if (G2_OPT & 16) __builtin_nontemporal_store(v, dst); else *dst = v;
         }
     };
     auto tile = [&](auto curc, int k) {

@@ -106,7 +106,7 @@ __device__ __forceinline__ void noise_rounds2(NoiseItem& s) {
 __device__ __forceinline__ void noise_pair(uint32_t a, uint32_t b, float& z0, float& z1) {
     const float sc = 5.9604644775390625e-08f;   // 2^-24
     const float u0 = ((float)(a >> 8) + 0.5f) * sc, u1 = ((float)(b >> 8) + 0.5f) * sc;
-    const float ra = __builtin_sqrtf(-2.0f * __logf(u0));
+    const float ra = bm_radius(u0);
     z0 = ra * __builtin_amdgcn_cosf(u1);
     z1 = ra * __builtin_amdgcn_sinf(u1);
 }
