@@ -1103,6 +1103,15 @@ void tail_aldi_kernel(MomView mv, cesx_step_params prm, const double* shift, con
     // dependent iterations in ~8 us), the four matvec sums keep finish_aldi_kernel's order (lane l adds its entries
     // c = l, l + 64, ... in turn, then the shuffle tree) through one LDS exchange per 256 columns.
     const double* Saa = mv.Saa();
+    // this thread's first S_ee / S_rr element: its operands are fetched HERE, beside the row's, and used behind the rows
+    // (two dependent round trips to L2 / HBM in a row cost this latency-bound launch ~1.5 us)
+    const unsigned nn = (unsigned)n * n;
+    double e_S = 0.0, e_sbi = 0.0, e_sbj = 0.0, e_shi = 0.0, e_shj = 0.0, e_yi = 0.0, e_yj = 0.0, e_gwi = 0.0, e_gwj = 0.0;
+    if (gid < nn) {
+        const unsigned i = gid / (unsigned)n, j = gid - i * (unsigned)n;
+        e_S = Sbb[gid]; e_sbi = sb[i]; e_sbj = sb[j]; e_shi = shift[p + i]; e_shj = shift[p + j];
+        e_yi = y[i]; e_yj = y[j]; e_gwi = gw[i]; e_gwj = gw[j];
+    }
     const double invN = 1.0 / N, invdiv = 1.0 / (N - 1.0), al0 = (p + 1.0) / N;
     __shared__ double xch[4][DT];
     const int wv = tid >> 6;
@@ -1150,8 +1159,15 @@ void tail_aldi_kernel(MomView mv, cesx_step_params prm, const double* shift, con
         }
     }
     double fr = 0.0;
-    const unsigned nn = (unsigned)n * n;
-    for (unsigned k = gid; k < nn; k += gsz) {
+    if (gid < nn) {
+        const double see = e_S - e_sbi * e_sbj / N;
+        const double mi = e_shi + e_sbi / N - e_yi, mj = e_shj + e_sbj / N - e_yj;
+        const double srr = see + N * mi * mj;
+        See[gid] = see;
+        Srr[gid] = srr;
+        fr += see * srr * e_gwi * e_gwj;
+    }
+    for (unsigned k = gid + gsz; k < nn; k += gsz) {          // (n^2 > 65 536 only: the first element of every thread went ahead of the rows)
         const unsigned i = k / (unsigned)n, j = k - i * (unsigned)n;
         const double see = Sbb[k] - sb[i] * sb[j] / N;
         const double mi = shift[p + i] + sb[i] / N - y[i], mj = shift[p + j] + sb[j] / N - y[j];

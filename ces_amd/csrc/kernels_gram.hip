@@ -531,20 +531,53 @@ GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset, 
             lo += n_;
         }
     } else {
-        // rectangles a x b of blocks with (a + b) * tile rows staged
-        int a = std::max(1, (int)std::floor(std::sqrt((double)cap)));
-        int b = std::max(1, cap / a);
-        while ((a + b) * tile > max_rows_lds && (a > 1 || b > 1)) {
-            if (a >= b) --a; else --b;
+        // rectangles a x b of blocks with (a + b) * tile rows staged.  Which a x b: every shape that fits the wave
+        // capacity and LDS is laid over the triangle and priced with the cost model (levelled busiest workgroup, then the
+        // rows the launch stages).  Round 4: the near-square 11 x 11 that sqrt(capacity) gives leaves C5's second launch
+        // (64 block rows) with 18 types, three of them 11-block leftovers -- busiest SIMD 12 % above the mean and 343 staged
+        // block rows; 16 x 8 divides the 64 rows evenly: 14 types, 3 % above the mean, 288 block rows.
+        auto build = [&](int a, int b) {
+            std::vector<std::vector<std::pair<int, int>>> ts;
+            for (int R0 = 0; R0 < pl.nbr; R0 += a)
+                for (int C0 = 0; C0 <= R0 + a - 1 && C0 < pl.nbr; C0 += b) {
+                    std::vector<std::pair<int, int>> v;
+                    for (int R = R0; R < std::min(R0 + a, pl.nbr); ++R)
+                        for (int C = C0; C < std::min(C0 + b, pl.nbr); ++C)
+                            if (C <= R && wanted(R, C)) v.push_back({R, C});
+                    if (!v.empty()) ts.push_back(v);
+                }
+            return ts;
+        };
+        int a0 = std::max(1, (int)std::floor(std::sqrt((double)cap)));
+        int b0 = std::max(1, cap / a0);
+        while ((a0 + b0) * tile > max_rows_lds && (a0 > 1 || b0 > 1)) {
+            if (a0 >= b0) --a0; else --b0;
         }
-        for (int R0 = 0; R0 < pl.nbr; R0 += a)
-            for (int C0 = 0; C0 <= R0 + a - 1 && C0 < pl.nbr; C0 += b) {
-                std::vector<std::pair<int, int>> v;
-                for (int R = R0; R < std::min(R0 + a, pl.nbr); ++R)
-                    for (int C = C0; C < std::min(C0 + b, pl.nbr); ++C)
-                        if (C <= R && wanted(R, C)) v.push_back({R, C});
-                if (!v.empty()) types.push_back(v);
+        int best_a = a0, best_b = b0;
+        if (!std::getenv("CESX_GRAM_SQUARE_RECTS")) {
+            double best_cost = 1e300, best_rows = 1e300;
+            for (int a = 1; a <= std::min(cap, pl.nbr); ++a) {
+                const int b = std::min(cap / a, pl.nbr);
+                if (b < 1 || (a + b) * tile > max_rows_lds) continue;
+                if (a * b * 2 < cap) continue;                      // (half-empty workgroups: not worth pricing)
+                const auto ts = build(a, b);
+                std::vector<double> w;
+                double rows = 0.0;
+                for (const auto& v : ts) {
+                    std::set<int> rws;
+                    for (auto& rc : v) { rws.insert(rc.first); rws.insert(rc.second); }
+                    w.push_back(gram_tile_cost(tile, (int)v.size(), (int)rws.size()));
+                    rows += (double)rws.size();
+                }
+                if ((int)ts.size() > wg_budget) continue;
+                std::vector<int> ns;
+                const double cost = gram_level_slices(w, std::max(wg_budget, (int)ts.size()), ntiles, ns);
+                // (the near-square default stays unless something is clearly better; then the lightest within 1 % of the fastest)
+                const bool better = cost < best_cost * 0.99 || (cost <= best_cost * 1.01 && rows < best_rows);
+                if (better) { best_cost = std::min(best_cost, cost); best_rows = rows; best_a = a; best_b = b; }
             }
+        }
+        types = build(best_a, best_b);
     }
     pl.ntypes = (int)types.size();
     pl.max_rb = 0;
@@ -562,7 +595,9 @@ GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset, 
         w[t] = gram_tile_cost(tile, (int)types[t].size(), (int)rws.size());
         total += w[t];
     }
-    if ((pl.ntypes <= 4 || std::getenv("CESX_GRAM_LEVEL_ALL")) && !std::getenv("CESX_GRAM_PROPORTIONAL")) {
+    // (many types -- the rectangles of a triangle that does not fit LDS: levelled as well since round 4, the proportional
+    //  rule below rounds 17.5 slices down to 16 for eight types at once; CESX_GRAM_PROPORTIONAL=1 switches back)
+    if ((pl.ntypes <= 4 || pl.nbr * tile > max_rows_lds || std::getenv("CESX_GRAM_LEVEL_ALL")) && !std::getenv("CESX_GRAM_PROPORTIONAL")) {
         // few types, many slices each: whole tiles per slice, levelled (gram_level_slices)
         gram_level_slices(w, std::max(wg_budget, pl.ntypes), ntiles, nsl);
     } else {

@@ -757,6 +757,26 @@ def test_hk_free_update_matches_the_assembled_form(eng_mod, monkeypatch, p, n, J
         assert np.array_equal(U, U1) and np.array_equal(c, c1)
 
 
+@pytest.mark.parametrize("split", ["30:40", "100:0", "0:0", "0:100"])
+def test_noise_block_riding_on_the_reduce_launches_is_the_same_block(eng_mod, monkeypatch, split):
+    """CESX_NOISE_RIDE_PCT=a:s: the lookahead noise block is drawn by extra workgroups of the two slab reduces (a % on the
+    first, the rest on the second) and s % by a kernel behind chol(C), instead of one kernel on the side stream.  Philox is
+    counter based: the same numbers wherever a workgroup of the block runs -- bit-identical chains, pipelined and step by
+    step (the second reduce completes the block; a driver that asks for it earlier gets the rest flushed)."""
+    p, n, J = 128, 96, 8192
+    d = _synthetic(p, n, J, seed=83)
+    _, U0, c0, _ = _aldi_chain(eng_mod, d, p, n, J, "float32", nsteps=5, pipelined=True)
+    monkeypatch.setenv("CESX_NOISE_RIDE_PCT", split)
+    _, U1, c1, _ = _aldi_chain(eng_mod, d, p, n, J, "float32", nsteps=5, pipelined=True)
+    _, U2, c2, _ = _aldi_chain(eng_mod, d, p, n, J, "float32", nsteps=5)
+    _, U3, c3, _ = _aldi_chain(eng_mod, d, p, n, J, "float64", nsteps=3, pipelined=True)
+    monkeypatch.delenv("CESX_NOISE_RIDE_PCT")
+    _, U4, c4, _ = _aldi_chain(eng_mod, d, p, n, J, "float64", nsteps=3, pipelined=True)
+    assert np.array_equal(U1, U0) and np.array_equal(c1, c0)
+    assert np.array_equal(U2, U0) and np.array_equal(c2, c0)
+    assert np.array_equal(U3, U4) and np.array_equal(c3, c4)
+
+
 def test_polled_join_that_runs_out_leaves_the_step_untouched_and_is_rerun(eng_mod, monkeypatch):
     """The polled join of the side stream (launch_dense) is bounded in wall time.  A factorisation that never stores its
     word (CESX_TEST_DROP_CHOL_SIGNAL: the second one) makes the poll of that step run out: the assembly and update
