@@ -279,7 +279,11 @@ void gram2_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __r
             return;
         }
         if constexpr (IMM) {
+            // (timing ablations of fragment sharing, results wrong: 32 = the c fragment of every odd block is the even block's,
+            //  64 = one pair of fragment reads per four blocks)
+            if ((G2_ABL & 64) && (b & 3) != 0) return;
             f.a = *reinterpret_cast<lds_cvec>(pa[b][g % NG0] + SLOT * SSTR + (g / NG0) * GSTR);
+            if ((G2_ABL & 32) && (b & 1) != 0) return;
             f.c = *reinterpret_cast<lds_cvec>(pc_[b][g % NG0] + SLOT * SSTR + (g / NG0) * GSTR);
         } else {        // (64-KiB slots: the slot does not fit the offset field, one address add per read)
             const char* base = smem + SLOT * SSTR;
