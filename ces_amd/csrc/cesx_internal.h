@@ -383,17 +383,16 @@ struct Engine {
     void* d_bias = nullptr;        // [rpad]
     // ---- ALDI with the time step kept OUT of the update coefficients (round 4; launch_dense, "hk-free") ----
     // U_next = hk ( sqrt(2/hk) L xi + (a I - M + I/hk) U - K G + b' ),  b' = K y + M mu - a ubar: the image
-    // Wq = [ L | a I - M (+ 1/hk on the diagonal) | -K ] needs hk in p diagonal entries only.  L and a I - M are written by
-    // the side stream's own kernels (the factorisation stores its panels into the image as it finishes them, the U-only
-    // centring writes a I - M and the two matvecs M mu, M ubar), the caller's stream adds -K, the diagonal and b' in ONE
-    // launch behind the second reduce (tail_aldi_kernel: its last workgroup, by ticket, sums the Frobenius partials, joins
-    // the side stream and writes hk), and K3 takes hk and sqrt(2hk) from the scalar block at run time: xi segment first,
-    // accumulators rescaled once by sqrt(2/hk), the result times hk in the epilogue.
+    // Wq = [ L | a I - M (+ 1/hk on the diagonal) | -K ] needs hk in p diagonal entries only.  L is written by the
+    // factorisation itself (it stores its panels into the image as it finishes them, on the side stream), everything else
+    // by ONE launch of the caller's stream behind the second reduce (tail_aldi_kernel: -K and a I - M rows straight from the
+    // moments, the four matvecs, the Frobenius partials; its last workgroup, by ticket, joins the side stream, sums the
+    // partials and writes hk, b', the diagonal and the next shift), and K3 takes hk and sqrt(2hk) from the scalar block at
+    // run time: xi segment first, accumulators rescaled once by sqrt(2/hk), the result times hk in the epilogue.
     void* d_Wq = nullptr;          // [rpad][ktot] fragment-major (wf_index), fp32; zero outside what the kernels above write
-    double* d_qv = nullptr;        // [3][p] M mu | M ubar | a - M_ii  (side stream)
     unsigned* d_ticket = nullptr;  // arrival counter of tail_aldi_kernel
     bool hkfree_ok = true;         // CESX_HKFREE=0 switches the path off
-    bool side_img = false;         // the factorisation in flight wrote its share of d_Wq / d_qv (launch_chol_async)
+    bool side_img = false;         // the factorisation in flight stores L into d_Wq (launch_chol_async)
     bool last_hkfree = false;      // the last launch_dense took the path: the update launch reads d_Wq in the order [xi; U; G]
     void* d_Wfwd = nullptr;        // forward-map staging [npad][kp]
     void* d_Wfwd_f = nullptr;      // the same map in the fragment-major order of the LDS-DMA update kernels (cesx_forward_set_lineal)

@@ -399,7 +399,7 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
     DM(e.d_absmax_part, (size_t)update_grid_blocks(e, p) * 8);
     DM(e.d_clk, 4 * 8);
     DM(e.d_cholflag, 128);
-    DM(e.d_qv, (size_t)3 * p * 8); DM(e.d_ticket, 64);
+    DM(e.d_ticket, 64);
     DM(e.d_lag, 3 * 8);
     DM(e.d_A64, (size_t)n * p * 8); DM(e.d_b64, n * 8); DM(e.d_lvec, 2 * n * 8);
 #undef DM
@@ -444,7 +444,7 @@ void cesx_destroy(cesx_handle h) {
                     e.gp[1].d_type_hdr, e.gp[1].d_rows, e.gp[1].d_wblk, e.gp[1].d_blk_rc, e.gp[1].d_row_own, e.gp[1].d_slabs, e.gp[1].d_rowsum_part, e.d_sums, e.d_ubar, e.d_gbar, e.d_m, e.d_dg,
                     e.d_wdel, e.d_C, e.d_L, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_Kp, e.d_M, e.d_P, e.d_PK,
                     e.d_t1, e.d_t2, e.d_t3, e.d_t4, e.d_Lp, e.d_lanczos, e.d_mv, e.d_part, e.d_scal, e.d_absmax,
-                    e.d_c0, e.d_absmax_part, e.d_clk, e.d_cholflag, e.d_lag, e.d_A64, e.d_b64, e.d_lvec, e.d_Wq, e.d_qv, e.d_ticket};
+                    e.d_c0, e.d_absmax_part, e.d_clk, e.d_cholflag, e.d_lag, e.d_A64, e.d_b64, e.d_lvec, e.d_Wq, e.d_ticket};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     for (int w = 0; w < 2; ++w)

@@ -1065,9 +1065,9 @@ void finish_aldi_kernel(MomView mv, cesx_step_params prm, const double* part, Sc
 // ALDI, default time step, fp32, diagonal Gamma / Sigma, the update through the LDS-DMA kernel: the G part of the
 // centring AND what is left of the assembly once hk is out of the coefficient matrix, as ONE launch behind the second
 // reduce (center_kernel(what = 2) + finish_aldi_kernel took two, 8 + 9-17 us beside the noise draw, with W rewritten
-// in full between them).  The side stream has already written L (potrf_reg_kernel), a I - M and M mu, M ubar
-// (center_kernel) into Engine::d_Wq / d_qv; here:
-//   every workgroup : rows of K = C_ug Gamma^{-1} (one wave per row: -K into the image, K_i . y, K_i . gbar),
+// in full between them).  The factorisation has stored (or is storing) L into Engine::d_Wq on the side stream; here:
+//   every workgroup : one row i of K = C_ug Gamma^{-1} and of M = C Sigma^{-1} (straight from the moments: nothing of it
+//                     waits for the side stream): -K_i and a I - M_i into the image, K_i . y, K_i . gbar, M_i . mu, M_i . ubar;
 //                     S_ee, S_rr and its partial of the Frobenius term, gbar and the data-metric constants;
 //   the LAST one to arrive (ticket): joins the side stream (polled word, as center_kernel did), sums the partials in the
 //                     fixed order of finish_aldi_kernel -> hk, t, metrics (bit-identical scalars), then b' = K y + M mu - a ubar,
@@ -1081,7 +1081,7 @@ void tail_aldi_kernel(MomView mv, cesx_step_params prm, const double* shift, con
                       double* __restrict__ dg, double* __restrict__ Cug, double* __restrict__ See,
                       double* __restrict__ Srr, double* __restrict__ K, double* part, Scalars* sc,
                       double* __restrict__ lag, double* mvs, int mx, const double* __restrict__ sw,
-                      const double* __restrict__ mu, const double* __restrict__ ustar,
+                      const double* __restrict__ mu,
                       float* wq, int nkt, int kp, int kn, float* __restrict__ bias, float* shiftT, double* shift64,
                       float* __restrict__ rowc, float* __restrict__ gbarT, unsigned* ticket,
                       const unsigned long long* join, unsigned long long join_want, unsigned long long* fault,
@@ -1700,7 +1700,7 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
         } else if (!polled) CESX_HIP(hipStreamWaitEvent(s, e.ev_b, 0));
         hipLaunchKernelGGL(tail_aldi_kernel, dim3(NPB), dim3(DT), 0, s, mv, prm, (const double*)e.d_shift64, (const double*)e.d_y,
                            (const double*)e.d_gw, e.d_gbar, e.d_m, e.d_dg, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_part, e.d_scal,
-                           e.d_lag, e.d_mv, mx, (const double*)e.d_sw, (const double*)e.d_mu, (const double*)e.d_ustar, (float*)e.d_Wq, e.ktot / 16, e.kp,
+                           e.d_lag, e.d_mv, mx, (const double*)e.d_sw, (const double*)e.d_mu, (float*)e.d_Wq, e.ktot / 16, e.kp,
                            e.kn, (float*)e.d_bias, (float*)e.d_shiftT, e.d_shift64, (float*)e.d_rowc, (float*)e.d_gbarT,
                            e.d_ticket, polled ? (const unsigned long long*)e.d_cholflag : (const unsigned long long*)nullptr,
                            (unsigned long long)e.chol_seq, e.d_cholflag + 1, e.poll_ticks);
