@@ -314,7 +314,9 @@ struct Engine {
     bool problem_set = false, shift_valid = false;
     bool chol_inflight = false;    // cesx_chol_async ran for the current moments; cesx_apply joins the side stream
     bool chol_fused_center = false;   // ... with the centring fused into the factorisation's load (no U-only centring launch on the side stream)
-    bool fuse_center_ok = false;      // CESX_FUSE_CENTER=1 switches that on.  Measured at C2 (round 3, row sums staged through LDS): the factorisation
+    bool fuse_center_ok = false;      // CESX_FUSE_CENTER=1 switches that on (round 4: also with the hk-free form -- the tail launch then forms C, M, ubar
+                                      // and the trace / bias sums itself; measured 0.3988 against 0.3952 ms/step at C2: the side chain ends 15 us
+                                      // earlier, the noise draw behind it meets the end of the second Gram launch, and the tail launch is longer).  Measured at C2 (round 3, row sums staged through LDS): the factorisation
                                       // takes 107 us instead of 13 + 99, the side chain ends 4.5 us earlier, the step gains 0.2-1 % over 400 steps and
                                       // nothing in the 20-step line (the caller's stream -- second Gram launch, reduce, centring -- is the critical path)
     bool overlap_chol = true;      // run chol(C) on the side stream beside the second (non U x U) part of the Gram

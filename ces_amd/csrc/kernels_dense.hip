@@ -1082,6 +1082,10 @@ void tail_aldi_kernel(MomView mv, cesx_step_params prm, const double* shift, con
                       double* __restrict__ Srr, double* __restrict__ K, double* part, Scalars* sc,
                       double* __restrict__ lag, double* mvs, int mx, const double* __restrict__ sw,
                       const double* __restrict__ mu,
+                      // self_u: no U-only centring ran for these moments (the factorisation formed C while it loaded S_aa):
+                      // C, M, ubar and the trace / bias sums are formed here
+                      int self_u, const double* __restrict__ ustar, double* __restrict__ ubar, double* __restrict__ Cm,
+                      double* __restrict__ Mm,
                       float* wq, int nkt, int kp, int kn, float* __restrict__ bias, float* shiftT, double* shift64,
                       float* __restrict__ rowc, float* __restrict__ gbarT, unsigned* ticket,
                       const unsigned long long* join, unsigned long long join_want, unsigned long long* fault,
@@ -1122,7 +1126,14 @@ void tail_aldi_kernel(MomView mv, cesx_step_params prm, const double* shift, con
             const int c = c0 + tid;
             double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
             if (c < p) {
-                const double m_ = cov_entry(Saa[(size_t)i * p + c], sa[i], sa[c], invN, invdiv, i == c, nullptr) * sw[c];
+                double suu;
+                const double c_ = cov_entry(Saa[(size_t)i * p + c], sa[i], sa[c], invN, invdiv, i == c, &suu);
+                const double m_ = c_ * sw[c];
+                if (self_u) {
+                    Cm[(size_t)i * p + c] = c_;
+                    Mm[(size_t)i * p + c] = m_;
+                    if (i == c) st_agent(mvs + (size_t)5 * mx + i, suu);
+                }
                 if (i == c) st_agent(mvs + (size_t)4 * mx + i, al0 - m_);      // (the diagonal entry gets 1/hk from the last workgroup)
                 else wq[wf_index(i, kp + c, nkt)] = (float)(-m_);
                 v2 = m_ * mu[c];
@@ -1230,8 +1241,19 @@ void tail_aldi_kernel(MomView mv, cesx_step_params prm, const double* shift, con
     const int i0 = tid < p ? tid : 0;
     const double ky0 = ld_agent(mvs + i0), kg0 = ld_agent(mvs + (size_t)mx + i0), mm0 = ld_agent(mvs + (size_t)2 * mx + i0),
                  mu0 = ld_agent(mvs + (size_t)3 * mx + i0), db0 = ld_agent(mvs + (size_t)4 * mx + i0);
-    const double tr = dblock_sum(q0, red);
-    const double b2 = dblock_sum(q1, red);
+    double t0 = q0, t1 = q1;
+    if (self_u) {          // the trace of S_uu and |ubar - u*|^2, a thread per row
+        t0 = 0.0; t1 = 0.0;
+        for (int i = tid; i < p; i += DT) {
+            const double ub = shift[i] + sa[i] / N, du = ub - ustar[i];
+            ubar[i] = ub;
+            t0 += ld_agent(mvs + (size_t)5 * mx + i);
+            t1 += du * du;
+        }
+        if (tid == 0) { sc->radspec = 0.0; sc->absmax = 0.0; }
+    }
+    const double tr = dblock_sum(t0, red);
+    const double b2 = dblock_sum(t1, red);
     const double frs = dblock_sum(q2, red);
     const double hk = step_hk(prm, N, frs, 0.0), al = (p + 1.0) / N;
     if (tid == 0) write_scalars(prm, p, N, tr, b2, frs, sc);
@@ -1684,14 +1706,19 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
     // hk kept out of the coefficient matrix (cesx_internal.h, Engine::d_Wq): the side stream wrote L, a I - M, M mu, M ubar
     // for this factorisation, ONE launch adds the rest and the update kernel takes hk at run time
     const bool img_ok = e.hkfree_ok && e.d_Wq != nullptr && f32 && e.update_v2 && e.diag_gamma && e.diag_sigma && potrf_ld(p) <= 256;
-    const bool hkfree = upd2_ok && fused_finish && prm.time_step == CESX_TS_DEFAULT && img_ok &&
-        (early ? e.side_img && !e.chol_fused_center : true);
+    const bool hkfree = upd2_ok && fused_finish && prm.time_step == CESX_TS_DEFAULT && img_ok && (early ? e.side_img : true);
     e.last_hkfree = false;
     if (hkfree) {
         // the side stream is joined by the LAST workgroup of that launch (a polled word, under the conditions of the polled
         // join below), else by the event in front of it; no factorisation in flight: the U part runs here, in line
         const bool polled = early && e.poll_join_ok && e.chol_signals && e.J == e.Jg && s != e.side && stream_below_side(e, s);
-        if (!early) {
+        // (no factorisation in flight: in line, the same kernels the side stream would have run -- with CESX_FUSE_CENTER=1 the
+        //  factorisation forms C while it loads S_aa and the tail launch forms the rest of the U part itself)
+        const int self_u = (early ? e.chol_fused_center : e.fuse_center_ok) ? 1 : 0;
+        if (!early && self_u) {
+            PotrfCen cen{mv.mom + e.ml.sa(), mv.mom, unbiased};
+            if ((rc = potrf_reg_any(e, s, p, potrf_ld(p), mv.mom + e.ml.Saa(), e.d_L, p, 0, nullptr, cen, nullptr, 0, (float*)e.d_Wq))) return rc;
+        } else if (!early) {
             hipLaunchKernelGGL(center_kernel, dim3(NPB), dim3(DT), 0, s, mv, e.d_shift64, e.d_y, e.d_ustar,
                                (const double*)e.d_gw, (const double*)e.d_sw, unbiased, 1, e.d_ubar, e.d_gbar,
                                e.d_m, e.d_dg, e.d_C, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_M, e.d_part, e.d_scal, (double*)nullptr);
@@ -1700,7 +1727,8 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
         } else if (!polled) CESX_HIP(hipStreamWaitEvent(s, e.ev_b, 0));
         hipLaunchKernelGGL(tail_aldi_kernel, dim3(NPB), dim3(DT), 0, s, mv, prm, (const double*)e.d_shift64, (const double*)e.d_y,
                            (const double*)e.d_gw, e.d_gbar, e.d_m, e.d_dg, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_part, e.d_scal,
-                           e.d_lag, e.d_mv, mx, (const double*)e.d_sw, (const double*)e.d_mu, (float*)e.d_Wq, e.ktot / 16, e.kp,
+                           e.d_lag, e.d_mv, mx, (const double*)e.d_sw, (const double*)e.d_mu, self_u, (const double*)e.d_ustar,
+                           e.d_ubar, e.d_C, e.d_M, (float*)e.d_Wq, e.ktot / 16, e.kp,
                            e.kn, (float*)e.d_bias, (float*)e.d_shiftT, e.d_shift64, (float*)e.d_rowc, (float*)e.d_gbarT,
                            e.d_ticket, polled ? (const unsigned long long*)e.d_cholflag : (const unsigned long long*)nullptr,
                            (unsigned long long)e.chol_seq, e.d_cholflag + 1, e.poll_ticks);
@@ -1844,26 +1872,31 @@ int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s, b
     int rc;
     // (round 4: also measured at C4 -- p = 64, where the separate centring launch is a third of the side chain: 0.0844
     //  against 0.0805 ms/step with it fused, the one workgroup's load phase is the longer way; stays opt-in)
-    e.chol_fused_center = e.fuse_center_ok && potrf_ld(p) <= 256;
+    // the hk-free update's share of the side stream (cesx_internal.h, Engine::d_Wq): whether the step takes that path is
+    // decided in cesx_apply (time-step rule, alignment of the ensembles); storing L into the image costs the factorisation ~1 us
+    const bool img = e.hkfree_ok && e.d_Wq != nullptr && e.cfg.dtype == CESX_F32 && update == CESX_UPDATE_ALDI && e.update_v2 &&
+        e.diag_gamma && e.diag_sigma && potrf_ld(p) <= 256;
+    e.chol_fused_center = potrf_ld(p) <= 256 && e.fuse_center_ok;
     e.side_img = false;
     if (e.chol_fused_center) {
+        e.side_img = img;
         // p <= 256 (one register-resident factorisation): the covariance is formed while the kernel loads the raw
         // second moments -- no centring launch (13 us + a kernel boundary) in front of the 100-us Cholesky, which is
         // what the caller's stream ends up waiting for; cesx_apply's own centring launch does the U part with the G
         // part (C, M, ubar, the trace / bias partials: nothing the factorisation needs)
         const int np = potrf_ld(p);
         PotrfCen cen{mv.mom + e.ml.sa(), mv.mom, unbiased};
+        float* wq = img ? (float*)e.d_Wq : (float*)nullptr;
+        // (CESX_TEST_DROP_CHOL_SIGNAL=k, tests only: the k-th factorisation does not store its word)
+        unsigned long long* flag = e.test_drop_signal_at == e.chol_seq + 1 ? nullptr : e.d_cholflag;
         if (e.ext_events) {
-            if ((rc = potrf_reg_any(e, e.side, p, np, mv.mom + e.ml.Saa(), e.d_L, p, 0, e.ev_b, cen, e.d_cholflag, e.chol_seq + 1))) return rc;
+            if ((rc = potrf_reg_any(e, e.side, p, np, mv.mom + e.ml.Saa(), e.d_L, p, 0, e.ev_b, cen, flag, e.chol_seq + 1, wq))) return rc;
         } else {
-            if ((rc = potrf_reg_any(e, e.side, p, np, mv.mom + e.ml.Saa(), e.d_L, p, 0, nullptr, cen, e.d_cholflag, e.chol_seq + 1))) return rc;
+            if ((rc = potrf_reg_any(e, e.side, p, np, mv.mom + e.ml.Saa(), e.d_L, p, 0, nullptr, cen, flag, e.chol_seq + 1, wq))) return rc;
             CESX_HIP(hipEventRecord(e.ev_b, e.side));
         }
     } else {
-    // the hk-free update's share of the side stream (cesx_internal.h, Engine::d_Wq): whether the step takes that path is
-    // decided in cesx_apply (time-step rule, alignment of the ensembles); writing the images costs these kernels ~1 us
-    e.side_img = e.hkfree_ok && e.d_Wq != nullptr && e.cfg.dtype == CESX_F32 && update == CESX_UPDATE_ALDI && e.update_v2 &&
-        e.diag_gamma && e.diag_sigma && potrf_ld(p) <= 256;
+    e.side_img = img;
     float* wq = e.side_img ? (float*)e.d_Wq : (float*)nullptr;
     // (few workgroups -> 1024 threads each: 8 x 256 threads took 25 us for the 65 k elements of C, latency bound)
     hipLaunchKernelGGL(center_kernel, dim3(std::min(NPB, e.center_u_wgs)), dim3(e.center_u_wgs < NPB ? 1024 : DT), 0, e.side, mv, e.d_shift64, e.d_y, e.d_ustar,

@@ -749,7 +749,8 @@ def test_hk_free_update_matches_the_assembled_form(eng_mod, monkeypatch, p, n, J
     _, U2, c2, _ = _aldi_chain(eng_mod, d, p, n, J, "float32", pipelined=True)
     monkeypatch.setenv("CESX_POLL_JOIN", "0")
     _, U3, c3, _ = _aldi_chain(eng_mod, d, p, n, J, "float32", pipelined=True)
-    assert np.array_equal(c1[0, :4], c0[0, :4])                      # hk, t, bias, self-bias of the first step: the same sums
+    assert np.array_equal(c1[0, :2], c0[0, :2])                      # hk, t of the first step: the same sums in the same order
+    assert np.allclose(c1[0, 2:4], c0[0, 2:4], rtol=1e-12, atol=0)   # bias, self-bias: the tail launch sums the trace row by row
     scale = np.max(np.abs(U0))
     assert np.max(np.abs(U1 - U0)) <= 2e-5 * scale, np.max(np.abs(U1 - U0)) / scale
     assert np.allclose(c1, c0, rtol=2e-5, atol=0)
