@@ -488,7 +488,11 @@ GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset, 
             for (size_t t = 0; t < sz.size(); ++t) c.rows += (double)nrw[t] * ns[t];
             return c;
         };
-        const bool search = sizes0.size() >= 2 && sizes0.size() <= 3 && !std::getenv("CESX_GRAM_EQUAL_RUNS");
+        // (fp64: equal runs.  The cost model was fitted to the tiles, not to what a workgroup does once per launch: for C2 in
+        //  fp64 the search cut the U x U launch's 136 blocks into 8 + 128 -- 228 workgroups of 18 tiles with 256 KB of slabs
+        //  each -- where 68 + 68 runs the two Gram launches in 0.362 instead of 0.408 ms, round 4; CESX_GRAM_SEARCH_F64=1)
+        const bool search = sizes0.size() >= 2 && sizes0.size() <= 3 && !std::getenv("CESX_GRAM_EQUAL_RUNS") &&
+                            (tile == 32 || std::getenv("CESX_GRAM_SEARCH_F64"));
         std::vector<Cand> cands;
         cands.push_back(eval(all_rm, sizes0));
         for (const auto* all : {&all_rm, &all_cm}) {
