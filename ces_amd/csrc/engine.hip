@@ -336,7 +336,7 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
             // (~22 us of the step for 51 MB at C2).  Three types (32 / 48 / 20 blocks over 82 / 114 / 52 slices) leave 37 MB
             // at 25 % more row traffic and a 4 % worse balance: 0.3944 -> 0.3924 ms/step (tools/ab_env.py, round 4); four
             // types 0.3990, two types for the U x U launch 0.4015 against 0.3956.  CESX_GRAM_B_TYPES overrides.
-            if (part == 1 && cfg->dtype == CESX_F32 && gp.plan.ntypes == 2 && !std::getenv("CESX_GRAM_B_TYPES"))
+            if (part == 1 && cfg->dtype == CESX_F32 && gp.plan.ntypes == 2 && !std::getenv("CESX_GRAM_B_TYPES") && !std::getenv("CESX_GRAM_SPLIT"))
                 gp.plan = make_gram_plan(P, tile, gram_nbw(cfg->dtype), gram_max_stage_rows(), part + 1, pbU, 3, budget, ntiles);
             if (gp.plan.max_rb * tile > gram_max_stage_rows()) { e.err = "gram plan exceeds LDS"; return fail(CESX_EINVAL); }
         }

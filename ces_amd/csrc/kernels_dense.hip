@@ -1119,6 +1119,11 @@ void tail_aldi_kernel(MomView mv, cesx_step_params prm, const double* shift, con
     const double invN = 1.0 / N, invdiv = 1.0 / (N - 1.0), al0 = (p + 1.0) / N;
     __shared__ double xch[4][DT];
     const int wv = tid >> 6;
+    // One row per workgroup and one column pass (p, n <= 256: the benchmark's shapes): the bulk stores of the row -- the
+    // image entries, the fp64 copies of C_ug / K (and C / M) -- go out BEHIND the ticket; only what the last workgroup reads
+    // (agent-scope stores below) stands between this workgroup's arithmetic and its arrival.
+    const bool defer = p <= (int)gridDim.x && p <= DT && n <= DT;
+    double d_c = 0.0, d_m = 0.0, d_cug = 0.0, d_kk = 0.0, d_see = 0.0, d_srr = 0.0;
     for (int i = blockIdx.x; i < p; i += gridDim.x) {
         double ky = 0.0, kg = 0.0, mm = 0.0, mu_ = 0.0;
         const int cmax = p > n ? p : n;
@@ -1129,13 +1134,13 @@ void tail_aldi_kernel(MomView mv, cesx_step_params prm, const double* shift, con
                 double suu;
                 const double c_ = cov_entry(Saa[(size_t)i * p + c], sa[i], sa[c], invN, invdiv, i == c, &suu);
                 const double m_ = c_ * sw[c];
-                if (self_u) {
-                    Cm[(size_t)i * p + c] = c_;
-                    Mm[(size_t)i * p + c] = m_;
-                    if (i == c) st_agent(mvs + (size_t)5 * mx + i, suu);
-                }
+                if (self_u && i == c) st_agent(mvs + (size_t)5 * mx + i, suu);
                 if (i == c) st_agent(mvs + (size_t)4 * mx + i, al0 - m_);      // (the diagonal entry gets 1/hk from the last workgroup)
-                else wq[wf_index(i, kp + c, nkt)] = (float)(-m_);
+                if (defer) { d_c = c_; d_m = m_; }
+                else {
+                    if (self_u) { Cm[(size_t)i * p + c] = c_; Mm[(size_t)i * p + c] = m_; }
+                    if (i != c) wq[wf_index(i, kp + c, nkt)] = (float)(-m_);
+                }
                 v2 = m_ * mu[c];
                 v3 = m_ * (shift[c] + sa[c] / N);
             }
@@ -1143,9 +1148,12 @@ void tail_aldi_kernel(MomView mv, cesx_step_params prm, const double* shift, con
                 const size_t k = (size_t)i * n + c;
                 const double cug = (Sab[k] - sa[i] * sb[c] / N) / N;
                 const double kk = cug * gw[c];
-                Cug[k] = cug;
-                K[k] = kk;
-                wq[wf_index(i, 2 * kp + c, nkt)] = (float)(-kk);
+                if (defer) { d_cug = cug; d_kk = kk; }
+                else {
+                    Cug[k] = cug;
+                    K[k] = kk;
+                    wq[wf_index(i, 2 * kp + c, nkt)] = (float)(-kk);
+                }
                 v0 = kk * y[c];
                 v1 = kk * (shift[p + c] + sb[c] / N);
             }
@@ -1174,8 +1182,7 @@ void tail_aldi_kernel(MomView mv, cesx_step_params prm, const double* shift, con
         const double see = e_S - e_sbi * e_sbj / N;
         const double mi = e_shi + e_sbi / N - e_yi, mj = e_shj + e_sbj / N - e_yj;
         const double srr = see + N * mi * mj;
-        See[gid] = see;
-        Srr[gid] = srr;
+        d_see = see; d_srr = srr;                 // (stored behind the ticket)
         fr += see * srr * e_gwi * e_gwj;
     }
     for (unsigned k = gid + gsz; k < nn; k += gsz) {          // (n^2 > 65 536 only: the first element of every thread went ahead of the rows)
@@ -1213,6 +1220,21 @@ void tail_aldi_kernel(MomView mv, cesx_step_params prm, const double* shift, con
     if (tid == 0) {
         const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_flag = t == gridDim.x - 1 ? 1 : 0;
+    }
+    // the bulk stores held back above: read by LATER launches only
+    if (gid < nn) { See[gid] = d_see; Srr[gid] = d_srr; }
+    if (defer && (int)blockIdx.x < p) {
+        const int i = blockIdx.x, c = tid;
+        if (c < p) {
+            if (self_u) { Cm[(size_t)i * p + c] = d_c; Mm[(size_t)i * p + c] = d_m; }
+            if (i != c) wq[wf_index(i, kp + c, nkt)] = (float)(-d_m);
+        }
+        if (c < n) {
+            const size_t k = (size_t)i * n + c;
+            Cug[k] = d_cug;
+            K[k] = d_kk;
+            wq[wf_index(i, 2 * kp + c, nkt)] = (float)(-d_kk);
+        }
     }
     __syncthreads();
     if (s_flag == 0) return;

@@ -16,6 +16,7 @@
 //     fp64 in a fixed order (deterministic, no float atomics).
 // Bound: MFMA (f32 MFMA issues at the f32 vector rate on gfx950).
 #include "cesx_internal.h"
+#include <cstring>
 #include <hip/hip_ext.h>
 #include <algorithm>
 #include <cmath>
@@ -513,6 +514,16 @@ GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset, 
                     }
                 }
             }
+        }
+        // dev: CESX_GRAM_SPLIT="c:32,48,20" (second launch) / CESX_GRAM_UU_SPLIT=... pins the listing (r / c) and the run sizes
+        if (const char* sv = std::getenv(subset == 1 ? "CESX_GRAM_UU_SPLIT" : "CESX_GRAM_SPLIT")) {
+            std::vector<int> sz;
+            const bool cm = sv[0] == 'c';
+            int tot = 0;
+            for (const char* q = std::strchr(sv, ':'); q && *q; q = std::strpbrk(q + 1, ",/")) { sz.push_back(std::atoi(q + 1)); tot += sz.back(); }
+            bool ok = tot == nb_all && !sz.empty();
+            for (int v : sz) ok = ok && v >= 1 && v <= cap;
+            if (ok) { cands.clear(); cands.push_back(eval(cm ? all_cm : all_rm, sz)); }
         }
         size_t pick = 0;
         {
