@@ -49,7 +49,7 @@ int run(int subset, int budget, int p, int n, long long J) {
         for (int i = 0; i < 13; ++i) {
             if (i == 3) hipEventRecord(e0);
             if (which == 0) hipLaunchKernelGGL(k1, grid, block, lds1, 0, U, G, shift, p, n, J, th, pl.ntypes, rows, wblk, slabs, rsp);
-            else if (which == 1) hipLaunchKernelGGL(k2, grid, block, lds2, 0, U, G, shift, p, n, J, th, pl.ntypes, rows, wblk, slabs2, rsp2, PreRed{});
+            else if (which == 1) hipLaunchKernelGGL(k2, grid, block, lds2, 0, U, G, shift, p, n, J, th, pl.ntypes, rows, wblk, slabs2, rsp2);
             else hipLaunchKernelGGL(k3, grid, block, lds3, 0, U, G, shift, p, n, J, th, pl.ntypes, rows, wblk, slabs2, rsp2);
         }
         hipEventRecord(e1); hipEventSynchronize(e1);
@@ -59,7 +59,7 @@ int run(int subset, int budget, int p, int n, long long J) {
     }
     // (the compared slabs are the CURRENT kernel's: its launch is the last writer of slabs2 / rsp2)
     hipMemset(slabs2, 0, slab_elems * sizeof(T)); hipMemset(rsp2, 0, (size_t)pl.total_rs * P * 8);
-    hipLaunchKernelGGL(k2, grid, block, lds2, 0, U, G, shift, p, n, J, th, pl.ntypes, rows, wblk, slabs2, rsp2, PreRed{});
+    hipLaunchKernelGGL(k2, grid, block, lds2, 0, U, G, shift, p, n, J, th, pl.ntypes, rows, wblk, slabs2, rsp2);
     if (hipDeviceSynchronize() != hipSuccess) { printf("HIP error\n"); return 1; }
     std::vector<T> a(slab_elems), b(slab_elems);
     hipMemcpy(a.data(), slabs, slab_elems * sizeof(T), hipMemcpyDeviceToHost);
