@@ -402,6 +402,10 @@ struct Engine {
     bool pub_side_ok = true;       // CESX_PUB_SIDE=0: the publication rides on the next U x U reduce / runs behind the update (UpdateOpt::done_flag)
     unsigned long long k3_seq = 0; // update launches that signalled so far
     bool last_update_signals = false;
+    MetricFin pub_fin{};           // the publication in flight on the side stream (cesx_result re-issues it on the caller's stream
+    bool pub_pending = false;      //  when the waiter gave up: kernels of the two streams were not running side by side)
+    hipStream_t pub_stream = nullptr;
+    unsigned long long test_drop_pub_at = 0;      // CESX_TEST_DROP_PUB_SIGNAL (tests): that update launch does not store its word
     bool side_img = false;         // the factorisation in flight stores L into d_Wq (launch_chol_async)
     bool last_hkfree = false;      // the last launch_dense took the path: the update launch reads d_Wq in the order [xi; U; G]
     void* d_Wfwd = nullptr;        // forward-map staging [npad][kp]
@@ -567,6 +571,7 @@ __host__ __device__ inline size_t wd_index(int i, int k, int nkt) {
 int launch_data_metrics(Engine& e, const void* G, hipStream_t s);   // dense Gamma: separate pass
 int launch_metric_final(Engine& e, const double* mom, bool publish, hipStream_t s);
 int launch_metric_poll(Engine& e, unsigned long long want, hipStream_t s);    // the same behind the update kernel's word (d_cholflag[4])
+int launch_metric_republish(Engine& e, hipStream_t s);
 MetricFin metric_fin_args(Engine& e, const double* mom, bool publish);     // (publish: takes the next sequence number; mom == nullptr: the engine's own copy d_lag)
 int launch_publish(Engine& e, hipStream_t s);
 int launch_absmax_final(Engine& e, int nparts, double* absmax_out, hipStream_t s);
