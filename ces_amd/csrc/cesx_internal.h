@@ -257,12 +257,7 @@ struct MetricFin {
     const double* part; int nparts; const double* mom; size_t tail_off; double* sums; Scalars* sc;
     Scalars* host; unsigned long long seq;
     double N;            // > 0: the global ensemble size (else read from mom[0])
-    int agent = 0;       // the partials and the lagged sums were written by a kernel this one is not ordered behind at queue level
-                         // (metric_final_poll_kernel waits for the update kernel's word): read them at agent scope
 };
-__device__ __forceinline__ double mf_load(const double* q, int agent) {
-    return agent ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
-}
 __device__ __forceinline__ void metric_final_body(const MetricFin& f) {
     __shared__ double mf_red[2][4];
     __shared__ double mf_out[4];
@@ -278,11 +273,11 @@ __device__ __forceinline__ void metric_final_body(const MetricFin& f) {
         mine = __hip_atomic_load(reinterpret_cast<const double*>(f.sc) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     double lag0 = 0.0, lag1 = 0.0, Nm = f.N;          // (thread 0's inputs from the moment buffer: also up front)
     if (threadIdx.x == 0) {
-        lag0 = mf_load(f.mom + f.tail_off, f.agent); lag1 = mf_load(f.mom + f.tail_off + 1, f.agent);
-        if (!(Nm > 0.0)) Nm = mf_load(f.mom, f.agent);
+        lag0 = f.mom[f.tail_off]; lag1 = f.mom[f.tail_off + 1];
+        if (!(Nm > 0.0)) Nm = f.mom[0];
     }
     double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < f.nparts; i += MF_THREADS) { a += mf_load(f.part + (size_t)i * 2, f.agent); b += mf_load(f.part + (size_t)i * 2 + 1, f.agent); }
+    for (int i = threadIdx.x; i < f.nparts; i += MF_THREADS) { a += f.part[(size_t)i * 2]; b += f.part[(size_t)i * 2 + 1]; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b += __shfl_down(b, o, 64); }
     if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 4) { mf_red[0][threadIdx.x >> 6] = a; mf_red[1][threadIdx.x >> 6] = b; }
@@ -399,13 +394,6 @@ struct Engine {
     void* d_Wq = nullptr;          // [rpad][ktot] fragment-major (wf_index), fp32; zero outside what the kernels above write
     unsigned* d_ticket = nullptr;  // arrival counter of tail_aldi_kernel
     bool hkfree_ok = true;         // CESX_HKFREE=0 switches the path off
-    bool pub_side_ok = true;       // CESX_PUB_SIDE=0: the publication rides on the next U x U reduce / runs behind the update (UpdateOpt::done_flag)
-    unsigned long long k3_seq = 0; // update launches that signalled so far
-    bool last_update_signals = false;
-    MetricFin pub_fin{};           // the publication in flight on the side stream (cesx_result re-issues it on the caller's stream
-    bool pub_pending = false;      //  when the waiter gave up: kernels of the two streams were not running side by side)
-    hipStream_t pub_stream = nullptr;
-    unsigned long long test_drop_pub_at = 0;      // CESX_TEST_DROP_PUB_SIGNAL (tests): that update launch does not store its word
     bool side_img = false;         // the factorisation in flight stores L into d_Wq (launch_chol_async)
     bool last_hkfree = false;      // the last launch_dense took the path: the update launch reads d_Wq in the order [xi; U; G]
     void* d_Wfwd = nullptr;        // forward-map staging [npad][kp]
@@ -522,10 +510,6 @@ struct UpdateOpt {
     const unsigned long long* fault = nullptr;   // != nullptr: the launch leaves `out` untouched when *fault == fault_seq (a polled join that ran out)
     unsigned long long fault_seq = 0;
     int ldw = 0;          // row stride of W (0: = ktot)
-    // done_flag != nullptr (LDS-DMA fp32 kernel): every workgroup takes a ticket at its end, the last one stores done_val -- the
-    // metric finalisation + publication of the step then runs on the SIDE stream behind a polled word (metric_final_poll_kernel)
-    // instead of riding on the next step's first reduce launch or running as a kernel of its own behind the update
-    unsigned long long* done_flag = nullptr; unsigned* done_ticket = nullptr; unsigned long long done_val = 0;
     const double* hkp = nullptr;   // != nullptr (LDS-DMA fp32 kernel, triangular segment FIRST): W carries no time step -- the accumulators
     const double* s2p = nullptr;   // are scaled by *s2p / *hkp behind the first segment and the result (+ bias) by *hkp in the epilogue
     int metric_seg = 1;   // K-segment that holds G (data metrics)
@@ -570,8 +554,6 @@ __host__ __device__ inline size_t wd_index(int i, int k, int nkt) {
 }
 int launch_data_metrics(Engine& e, const void* G, hipStream_t s);   // dense Gamma: separate pass
 int launch_metric_final(Engine& e, const double* mom, bool publish, hipStream_t s);
-int launch_metric_poll(Engine& e, unsigned long long want, hipStream_t s);    // the same behind the update kernel's word (d_cholflag[4])
-int launch_metric_republish(Engine& e, hipStream_t s);
 MetricFin metric_fin_args(Engine& e, const double* mom, bool publish);     // (publish: takes the next sequence number; mom == nullptr: the engine's own copy d_lag)
 int launch_publish(Engine& e, hipStream_t s);
 int launch_absmax_final(Engine& e, int nparts, double* absmax_out, hipStream_t s);

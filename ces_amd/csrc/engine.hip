@@ -163,20 +163,8 @@ int run_update_main(Engine& e, const cesx_step_params& prm, const void* U, const
         opt.hkp = &e.d_scal->hk;
         opt.s2p = &e.d_scal->sqrt2hk;
     }
-    // the publication of this step on the side stream, behind the update launch's own word (one device, the LDS-DMA kernel,
-    // a caller's stream that may be waited for from the side stream's kernels: cesx_apply launches the waiter)
-    e.last_update_signals = false;
-    if (e.pub_side_ok && e.poll_join_ok && e.J == e.Jg && e.diag_gamma && e.overlap_chol && e.cfg.dtype == CESX_F32 && e.update_v2 &&
-        update2_qualifies(e, U, G, xi, Unext) && s != e.side && stream_below_side(e, s)) {
-        opt.done_flag = e.d_cholflag + 4;
-        opt.done_ticket = reinterpret_cast<unsigned*>(e.d_cholflag + 5);
-        opt.done_val = ++e.k3_seq;
-    }
-    const bool pub_side = opt.done_flag != nullptr;
-    if (pub_side && e.test_drop_pub_at == e.k3_seq) opt.done_flag = nullptr;      // (tests: the waiter of this step runs out)
     int rc = launch_update(e, e.p, e.d_W, e.ktot, e.d_bias, src, 3, nullptr, nullptr, 0.0, nullptr, nullptr, 0.0,
                            Unext, nullptr, prm.step_index, e.diag_gamma, opt, s);
-    if (pub_side) e.last_update_signals = true;
     e.last_metric_parts = e.last_update_grid_x;
     return rc;
 }
@@ -295,8 +283,6 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
     if (const char* fv = std::getenv("CESX_FUSE_CENTER")) e.fuse_center_ok = fv[0] != '0';
     if (const char* pv = std::getenv("CESX_POLL_JOIN")) e.poll_join_ok = pv[0] != '0';
     if (const char* hv = std::getenv("CESX_HKFREE")) e.hkfree_ok = hv[0] != '0';
-    if (const char* pv = std::getenv("CESX_PUB_SIDE")) e.pub_side_ok = pv[0] != '0';
-    if (const char* dv = std::getenv("CESX_TEST_DROP_PUB_SIGNAL")) e.test_drop_pub_at = (unsigned long long)std::max(0, std::atoi(dv));
     if (const char* rv = std::getenv("CESX_NOISE_RIDE")) e.xi_ride_ok = rv[0] != '0';
     if (const char* rv = std::getenv("CESX_NOISE_RIDE_PCT")) {
         e.xi_ride_ok = true;
@@ -722,10 +708,7 @@ int cesx_apply(cesx_handle h, const cesx_step_params* prm, const double* mom, co
     TRY(run_update_main(e, *prm, U, G, xi, Unext, s));
     // (Moving this last small kernel to the side stream was tried: the event record + wait pair costs
     //  as much GPU idle time as the 7 us kernel itself.)
-    if (e.last_update_signals) {
-        TRY(launch_metric_poll(e, e.k3_seq, e.side));
-        e.pub_stream = s;
-    } else if (e.met_defer_ok && e.ext_events && e.overlap_chol && e.diag_gamma) {
+    if (e.met_defer_ok && e.ext_events && e.overlap_chol && e.diag_gamma) {
         // the finalisation rides on the next step's U x U reduce launch (cesx_moments_uu_chol / _handover on this
         // stream) -- no one-workgroup kernel (7 us) between this update and the next Gram launch; anything else flushes it
         e.met_deferred = true; e.met_stream = s;      // (reads the engine's own d_lag, not `mom`)
@@ -782,18 +765,10 @@ int cesx_result(cesx_handle h, cesx_step_result* out) {
             if (waited < std::chrono::microseconds(100)) continue;
             if (waited < std::chrono::milliseconds(2)) { sched_yield(); continue; }
             if (hipPeekAtLastError() != hipSuccess) { e.err = "HIP error while waiting for the step"; return CESX_EHIP; }
-            // the side stream's waiter gave up (kernels_stats.hip): the publication from the caller's stream, behind the update
-            if (e.pub_pending && waited > std::chrono::microseconds((long long)(e.poll_ticks / 100) + 50000)) {
-                SET_DEVICE(e);
-                e.pub_pending = false;
-                e.pub_side_ok = false;
-                TRY(launch_metric_republish(e, e.pub_stream));
-            }
             if (waited > std::chrono::seconds(120)) { e.err = "timed out waiting for the step result"; return CESX_EHIP; }
             std::this_thread::sleep_for(std::chrono::microseconds(100));
         }
     }
-    e.pub_pending = false;
     const Scalars& sc = *e.h_scal;
     out->hk = sc.hk; out->t_new = sc.t_new;
     out->self_bias = sc.self_bias; out->self_bias_data = sc.self_bias_data;

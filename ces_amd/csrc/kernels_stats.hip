@@ -134,29 +134,6 @@ __global__ void dense_shift_terms_kernel(const double* __restrict__ shift_g, con
 // all-reduced moment buffer, the previous step's global values (multi-device runs)
 __global__ void metric_final_kernel(MetricFin f) { metric_final_body(f); }
 
-// The same on the SIDE stream, behind a word the update launch's last workgroup stores (UpdateOpt::done_flag) instead of a
-// queue-level dependency: the step's publication needs no kernel of the caller's stream -- neither one behind the update
-// (7 us in front of the next Gram launch) nor a workgroup of the next step's first reduce.  Bounded like every device-side
-// wait of the library; a wait that runs out publishes CESX_EHIP.
-__global__ __launch_bounds__(256)
-void metric_final_poll_kernel(MetricFin f, const unsigned long long* flag, unsigned long long want, unsigned long long ticks) {
-    __shared__ int s_ok;
-    if (threadIdx.x == 0) {
-        const unsigned long long t0 = wall_clock64();
-        int ok = 1;
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-            __builtin_amdgcn_s_sleep(32);
-            if (wall_clock64() - t0 > ticks) { ok = 0; break; }
-        }
-        s_ok = ok;
-    }
-    __syncthreads();
-    // a wait that runs out (the two streams' kernels did not run side by side: a profiler that serialises them) publishes
-    // NOTHING: cesx_result notices, publishes from the caller's stream and switches the engine back (Engine::pub_fin)
-    if (s_ok == 0) return;
-    metric_final_body(f);
-}
-
 // ---------------------------------------------------------------------------
 template <typename T>
 static int colsum_t(Engine& e, const void* U, const void* G, double* sums, hipStream_t s) {
@@ -234,26 +211,6 @@ MetricFin metric_fin_args(Engine& e, const double* mom, bool publish) {
     // mom == nullptr: {N, lag0, lag1} as K2's centring kernel copied them into the engine's d_lag
     return MetricFin{e.d_metric_part, nparts, mom ? mom : e.d_lag, mom ? e.ml.tail() : (size_t)1, e.d_metric_sums, e.d_scal,
                      publish ? e.h_scal_dev : (Scalars*)nullptr, publish ? ++e.seq : 0ull, 0.0};
-}
-
-int launch_metric_poll(Engine& e, unsigned long long want, hipStream_t s) {
-    MetricFin f = metric_fin_args(e, nullptr, true);
-    f.N = (double)e.Jg;
-    f.agent = 1;
-    e.pub_fin = f; e.pub_pending = true;
-    hipLaunchKernelGGL(metric_final_poll_kernel, dim3(1), dim3(ST_THREADS), 0, s, f, (const unsigned long long*)(e.d_cholflag + 4), want,
-                       e.poll_ticks);
-    CESX_HIP(hipGetLastError());
-    return CESX_OK;
-}
-
-// the fall-back of launch_metric_poll: the same finalisation as a kernel of the caller's stream, ordered behind the update
-int launch_metric_republish(Engine& e, hipStream_t s) {
-    MetricFin f = e.pub_fin;
-    f.agent = 0;
-    hipLaunchKernelGGL(metric_final_kernel, dim3(1), dim3(ST_THREADS), 0, s, f);
-    CESX_HIP(hipGetLastError());
-    return CESX_OK;
 }
 
 int launch_metric_final(Engine& e, const double* mom, bool publish, hipStream_t s) {

@@ -52,19 +52,7 @@ struct Upd2Args {
     long long* clk;       // profiled launches only: wave 0 of workgroup (0, 0) writes its {s_memtime, s_memrealtime} ticks
     const unsigned long long* fault; unsigned long long fault_seq;   // fault != nullptr and *fault == fault_seq: leave `out` untouched (UpdateOpt)
     const double* hkp; const double* s2p;      // HKF instantiations: the time step and sqrt(2 hk), read at run time (UpdateOpt)
-    unsigned long long* done_flag; unsigned* done_ticket; unsigned long long done_val;   // UpdateOpt::done_flag
 };
-
-// this workgroup's arrival at the end of the launch (UpdateOpt::done_flag): the last one signals.  What the waiter reads of the
-// launch -- the metric partials -- was stored at agent scope by the calling thread and is acknowledged here.
-__device__ __forceinline__ void upd2_arrive(const Upd2Args& a) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned t = __hip_atomic_fetch_add(a.done_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t == gridDim.x * gridDim.y - 1) {
-        __hip_atomic_store(a.done_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(a.done_flag, a.done_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
 
 // wait until at most `n` of this wave's DMAs are outstanding, retire its LDS traffic, barrier
 __device__ __forceinline__ void ring_barrier(int n) {
@@ -133,10 +121,7 @@ template <bool NOISE, bool HKF = false>
 __global__ __launch_bounds__(U2_THREADS, 2)
 void update2_kernel(const Upd2Args a) {
     // a polled join of the side stream that ran out in front of this launch (kernels_dense.hip): W is stale, the output stays as it was
-    if (a.fault != nullptr && __hip_atomic_load(a.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.fault_seq) {
-        if (a.done_flag != nullptr && threadIdx.x == 0) upd2_arrive(a);
-        return;
-    }
+    if (a.fault != nullptr && __hip_atomic_load(a.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.fault_seq) return;
     using acc_t = Mfma<float>::acc_t;
     typedef float f4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -491,14 +476,8 @@ void update2_kernel(const Upd2Args a) {
         if (lane == 0) { redm[wave] = sr; redm[4 + wave] = se; }
         __syncthreads();
         if (tid == 0) {
-            const double m0 = redm[0] + redm[1] + redm[2] + redm[3], m1 = redm[4] + redm[5] + redm[6] + redm[7];
-            if (a.done_flag != nullptr) {
-                __hip_atomic_store(a.metric_part + blockIdx.x * 2 + 0, m0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(a.metric_part + blockIdx.x * 2 + 1, m1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                a.metric_part[blockIdx.x * 2 + 0] = m0;
-                a.metric_part[blockIdx.x * 2 + 1] = m1;
-            }
+            a.metric_part[blockIdx.x * 2 + 0] = redm[0] + redm[1] + redm[2] + redm[3];
+            a.metric_part[blockIdx.x * 2 + 1] = redm[4] + redm[5] + redm[6] + redm[7];
         }
         __syncthreads();
     }
@@ -520,11 +499,6 @@ void update2_kernel(const Upd2Args a) {
     if (a.clk != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0) {
         const long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
         if (lane == 0) { a.clk[2] = c1; a.clk[3] = r1; }
-    }
-    if (a.done_flag != nullptr) {          // (every store of this workgroup acknowledged before its arrival counts)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) upd2_arrive(a);
     }
 #ifdef U2_CLOCKS
     if (tid == 0 && a.metric_part) {      // dev instrumentation: core-clock and 100 MHz wall-clock ticks of this workgroup
@@ -596,8 +570,6 @@ int launch_update2(Engine& e, int out_rows, const void* Wf, int ktot, const void
     a.metric_seg = opt.metric_seg;
     a.fault = opt.fault; a.fault_seq = opt.fault_seq;
     a.hkp = opt.hkp; a.s2p = opt.s2p;
-    a.done_flag = opt.done_flag; a.done_ticket = opt.done_ticket; a.done_val = opt.done_val;
-    e.last_update_signals = opt.done_flag != nullptr;
     if (opt.hkp && (!opt.s2p || nsrc != 3 || a.tri_seg != 0 || add1 || add2)) { e.err = "update: the hk-free form needs [xi | U | G] with the triangular segment first"; return CESX_EINVAL; }
     dim3 grid((unsigned)((e.J + U2_BN - 1) / U2_BN), (unsigned)((out_rows + U2_RC - 1) / U2_RC));
     // the dispatcher gives every CU one workgroup before any CU gets its second: from there on start late

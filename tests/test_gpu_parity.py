@@ -799,25 +799,6 @@ def test_polled_join_that_runs_out_leaves_the_step_untouched_and_is_rerun(eng_mo
     assert np.array_equal(U2, U0) and np.array_equal(c2, c0)
 
 
-def test_publication_on_the_side_stream_falls_back_when_its_wait_runs_out(eng_mod, monkeypatch):
-    """A step's result block is written by a kernel of the side stream that waits for a word the update launch stores at
-    its end (metric_final_poll_kernel).  If the two streams' kernels do not run side by side (a profiler that serialises them)
-    the bounded wait runs out and publishes nothing: cesx_result then publishes from the caller's stream, behind the update,
-    and the engine goes back to the deferred publication -- the same chain, bit for bit, as with CESX_PUB_SIDE=0."""
-    p, n, J = 128, 96, 8192
-    d = _synthetic(p, n, J, seed=84)
-    monkeypatch.setenv("CESX_PUB_SIDE", "0")
-    _, U0, c0, _ = _aldi_chain(eng_mod, d, p, n, J, "float32", nsteps=5, pipelined=True)
-    monkeypatch.setenv("CESX_PUB_SIDE", "1")
-    _, U1, c1, _ = _aldi_chain(eng_mod, d, p, n, J, "float32", nsteps=5, pipelined=True)
-    monkeypatch.setenv("CESX_POLL_TIMEOUT_MS", "20")
-    monkeypatch.setenv("CESX_TEST_DROP_PUB_SIGNAL", "2")
-    _, U2, c2, _ = _aldi_chain(eng_mod, d, p, n, J, "float32", nsteps=5, pipelined=True)
-    _, U3, c3, _ = _aldi_chain(eng_mod, d, p, n, J, "float32", nsteps=5)
-    for U, c in ((U1, c1), (U2, c2), (U3, c3)):
-        assert np.array_equal(U, U0) and np.array_equal(c, c0)
-
-
 def test_polled_join_only_below_the_side_streams_priority(eng_mod, monkeypatch):
     """A waiter in front of what it waits for in one hardware queue never ends, and streams of one priority level may
     share a queue: the caller's stream polls the factorisation's word only when its priority is strictly lower than the
