@@ -314,6 +314,10 @@ struct Engine {
     bool problem_set = false, shift_valid = false;
     bool chol_inflight = false;    // cesx_chol_async ran for the current moments; cesx_apply joins the side stream
     bool chol_fused_center = false;   // ... with the centring fused into the factorisation's load (no U-only centring launch on the side stream)
+    bool fuse_center_auto = true;     // no CESX_FUSE_CENTER given: fused where the step takes the hk-free form AND the second Gram launch is
+                                      // short (Engine::gram_b_short: small ensembles -- the side chain is then the step's critical path and
+                                      // the host's launches its floor; C4 0.0790 -> 0.0728 ms/step, round 4), not at C2 (see below)
+    bool gram_b_short = false;        // the second Gram launch's MFMA time is below ~60 us (cesx_create)
     bool fuse_center_ok = false;      // CESX_FUSE_CENTER=1 switches that on (round 4: also with the hk-free form -- the tail launch then forms C, M, ubar
                                       // and the trace / bias sums itself; measured 0.3988 against 0.3952 ms/step at C2: the side chain ends 15 us
                                       // earlier, the noise draw behind it meets the end of the second Gram launch, and the tail launch is longer).  Measured at C2 (round 3, row sums staged through LDS): the factorisation

@@ -280,7 +280,7 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
     if (const char* kv = std::getenv("CESX_K2_SPLIT")) e.k2_fused = kv[0] == '0';
     if (const char* xv = std::getenv("CESX_EXT_EVENTS")) e.ext_events = xv[0] != '0';
     if (const char* dv = std::getenv("CESX_DEFER_PUBLISH")) e.met_defer_ok = dv[0] != '0';
-    if (const char* fv = std::getenv("CESX_FUSE_CENTER")) e.fuse_center_ok = fv[0] != '0';
+    if (const char* fv = std::getenv("CESX_FUSE_CENTER")) { e.fuse_center_ok = fv[0] != '0'; e.fuse_center_auto = false; }
     if (const char* pv = std::getenv("CESX_POLL_JOIN")) e.poll_join_ok = pv[0] != '0';
     if (const char* hv = std::getenv("CESX_HKFREE")) e.hkfree_ok = hv[0] != '0';
     if (const char* rv = std::getenv("CESX_NOISE_RIDE")) e.xi_ride_ok = rv[0] != '0';
@@ -340,6 +340,14 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
                 gp.plan = make_gram_plan(P, tile, gram_nbw(cfg->dtype), gram_max_stage_rows(), part + 1, pbU, 3, budget, ntiles);
             if (gp.plan.max_rb * tile > gram_max_stage_rows()) { e.err = "gram plan exceeds LDS"; return fail(CESX_EINVAL); }
         }
+    }
+    {
+        // MFMA cycles of the second Gram launch's busiest SIMD, roughly: blocks x tiles x MFMAs per block and tile x 64 / SIMDs
+        const GramPlan& pb = e.gp[1].plan;
+        const int kt = gram_kt(cfg->dtype);
+        const double cyc = (double)pb.nblocks * (double)((e.J + kt - 1) / kt) * (cfg->dtype == CESX_F32 ? 16.0 : 4.0) * 64.0 /
+                           (4.0 * std::max(1, e.num_cus));
+        e.gram_b_short = cyc < 60e-6 * 2.3e9;
     }
     e.colsum_slices = (int)std::min<long long>(16, (e.J + 1023) / 1024);
     if (e.colsum_slices < 1) e.colsum_slices = 1;

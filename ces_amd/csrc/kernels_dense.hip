@@ -1736,7 +1736,7 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
         const bool polled = early && e.poll_join_ok && e.chol_signals && e.J == e.Jg && s != e.side && stream_below_side(e, s);
         // (no factorisation in flight: in line, the same kernels the side stream would have run -- with CESX_FUSE_CENTER=1 the
         //  factorisation forms C while it loads S_aa and the tail launch forms the rest of the U part itself)
-        const int self_u = (early ? e.chol_fused_center : e.fuse_center_ok) ? 1 : 0;
+        const int self_u = (early ? e.chol_fused_center : (e.fuse_center_ok || (e.fuse_center_auto && e.gram_b_short))) ? 1 : 0;
         if (!early && self_u) {
             PotrfCen cen{mv.mom + e.ml.sa(), mv.mom, unbiased};
             if ((rc = potrf_reg_any(e, s, p, potrf_ld(p), mv.mom + e.ml.Saa(), e.d_L, p, 0, nullptr, cen, nullptr, 0, (float*)e.d_Wq))) return rc;
@@ -1898,7 +1898,7 @@ int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s, b
     // decided in cesx_apply (time-step rule, alignment of the ensembles); storing L into the image costs the factorisation ~1 us
     const bool img = e.hkfree_ok && e.d_Wq != nullptr && e.cfg.dtype == CESX_F32 && update == CESX_UPDATE_ALDI && e.update_v2 &&
         e.diag_gamma && e.diag_sigma && potrf_ld(p) <= 256;
-    e.chol_fused_center = potrf_ld(p) <= 256 && e.fuse_center_ok;
+    e.chol_fused_center = potrf_ld(p) <= 256 && (e.fuse_center_ok || (e.fuse_center_auto && img && e.gram_b_short));
     e.side_img = false;
     if (e.chol_fused_center) {
         e.side_img = img;

@@ -80,6 +80,7 @@ class ShardedUpdate:
                           os.environ.get("CESX_SIDE_GRAM", "0") != "0")
         self._cs = None
         self._moms, self._mom_idx = None, 0
+        self._nuu = None
         # one-rank rehearsal of the multi-GPU path: issue the collectives even though world == 1
         self._force_collectives = dist.is_initialized() and os.environ.get("CESX_FORCE_COLLECTIVES") == "1"
         # The exchange step behind the C ABI (include/cesx.h, cesx_comm_* / cesx_allreduce_*): on GPUs with the "nccl"
@@ -178,7 +179,9 @@ class ShardedUpdate:
             self.recenter(U, G)
         if noise_step is not None and hasattr(eng, "prefetch_noise") and not self.single_allreduce:
             eng.prefetch_noise(noise_step)       # (drawn behind chol(C) on the side stream: the single-collective mode has none)
-        nuu = eng.moments_uu_len()
+        nuu = self._nuu
+        if nuu is None:                          # (constant for the engine's lifetime: one C call, not one per step)
+            nuu = self._nuu = eng.moments_uu_len()
         mom = self._moment_buffer()
         if self.single_allreduce:
             # the whole Gram, ONE all-reduce of the whole buffer; cesx_apply then finds no chol(C) in flight and
@@ -219,7 +222,8 @@ class ShardedUpdate:
             self._all_reduce(mom[:nuu], tag="head", mom=mom)
             eng.chol_async(prm, mom)                 # C, then L = chol(C) on the side stream ...
             eng.moments_rest(U, G, mom)              # ... beside the rest of the Gram
-        self._all_reduce(mom[nuu:], tag="tail", mom=mom)      # apply() joins the side stream before K2 reads the head
+        if self.world > 1 or self._force_collectives:          # (one device: not even the tensor view is made)
+            self._all_reduce(mom[nuu:], tag="tail", mom=mom)      # apply() joins the side stream before K2 reads the head
         self._mom = mom
         return mom
 
