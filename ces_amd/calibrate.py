@@ -335,6 +335,15 @@ class sampling(enka):
         sh.begin(prm0, U, G, recenter=True, noise_step=None if xis is not None else self._step_counter)
         fast = sh.lineal_fast_ok(model)       # linear map on the device: G's moments follow from U's (no second Gram launch)
         G_next = None
+
+        def fwd(u, out=None):                 # (``out``: a redo after a re-run step refreshes G in place, ShardedUpdate.result)
+            if out is None:
+                return model.forward_device(eng, u)
+            try:
+                return model.forward_device(eng, u, out=out)
+            except TypeError:                 # a hook without ``out=``
+                out.copy_(model.forward_device(eng, u))
+                return out
         for i in range(self.T):
             if trace and (i % stride == 0):                        # :356-358 (a copy: the device buffers are reused)
                 self.Uall.append(U0 if i == 0 and isinstance(U0, np.ndarray) else eng.to_host(U))
@@ -352,10 +361,10 @@ class sampling(enka):
             if i + 1 < self.T:                                     # first half of the next iteration, ahead of the read
                 ns = None if xis is not None else self._step_counter
                 if fast:
-                    _, G_next = sh.begin_lineal(prm0, U_new, lambda u: model.forward_device(eng, u), noise_step=ns, model=model)
+                    _, G_next = sh.begin_lineal(prm0, U_new, fwd, noise_step=ns, model=model)
                 else:
                     G_next = model.forward_device(eng, U_new)
-                    sh.begin(prm0, U_new, G_next, noise_step=ns)
+                    sh.begin(prm0, U_new, G_next, noise_step=ns, forward=fwd)
             res = sh.result()
             self._append_result(rule, res, kwargs)
             U, G = U_new, G_next

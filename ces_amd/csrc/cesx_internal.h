@@ -456,8 +456,6 @@ struct Engine {
     hipStream_t evb_waited_stream = nullptr;      // and that stream
     // ---- the polled join made safe (round 4) ----
     int side_prio = 0; bool side_has_prio = false;   // priority of the side stream (cesx_create)
-    bool prio_checked = false, prio_ok = false;   // ... against the last caller's stream asked about (stream_below_side)
-    hipStream_t prio_stream = nullptr;
     unsigned long long poll_ticks = 200000000ull; // bound of the poll in 100-MHz wall-clock ticks (2 s; CESX_POLL_TIMEOUT_MS)
     bool last_join_polled = false;                // the last launch_dense joined the side stream through the polled word
     unsigned long long poll_recoveries = 0;       // steps whose poll ran out and that cesx_result re-ran with chol(C) in line
@@ -465,7 +463,9 @@ struct Engine {
     unsigned long long test_drop_signal_at = 0;   // CESX_TEST_DROP_CHOL_SIGNAL (tests): that factorisation does not store its word
     unsigned long long moments_calls = 0;         // cesx_moments* calls so far (a re-run step tells whether a later one read an unwritten ensemble)
     struct LastApply { bool valid = false; cesx_step_params prm{}; const double* mom = nullptr; const void *U = nullptr, *G = nullptr, *xi = nullptr;
-                       void* Unext = nullptr; hipStream_t s = nullptr; unsigned long long moments_calls = 0; } last_apply;
+                       void* Unext = nullptr; hipStream_t s = nullptr; unsigned long long moments_calls = 0;
+                       bool mom_reused = false;      // a later cesx_moments* call was given the same buffer before the result was read: no re-run
+                     } last_apply;
     // ---- RCCL communicator of a sharded ensemble (comm.hip; nullptr: none) ----
     void* comm = nullptr;
     int comm_nranks = 0, comm_rank = 0;
@@ -595,6 +595,9 @@ struct ProfScope {
         e.prof_tag[which].push_back(e.prof_step * 2 + (which == 0 ? (unsigned long long)e.prof_part : 1ull));
     }
 };
+
+// the message cesx_last_error(NULL) returns (per thread): entry points that have no handle (cesx_create, cesx_comm_unique_id)
+void set_global_error(const std::string& msg);
 
 #define CESX_HIP(call)                                                              \
     do {                                                                            \

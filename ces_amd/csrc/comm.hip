@@ -28,16 +28,21 @@ struct Rccl {
     bool ok = false;
 };
 
+void rccl_load(Rccl& r);
+
+// (bound once per process, whichever thread asks first: a function-local static's initialiser runs under the
+//  language's own lock)
 Rccl& rccl() {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return r;
-    tried = true;
+    static Rccl r = [] { Rccl q; rccl_load(q); return q; }();
+    return r;
+}
+
+void rccl_load(Rccl& r) {
     const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
     for (const char* nm : names) { r.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD); if (r.lib) break; }
     if (!r.lib)
         for (const char* nm : names) { r.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (r.lib) break; }
-    if (!r.lib) { r.err = "librccl.so not found (dlopen)"; return r; }
+    if (!r.lib) { const char* de = dlerror(); r.err = std::string("librccl.so not found (dlopen") + (de ? std::string(": ") + de : std::string()) + ")"; return; }
     auto sym = [&](const char* nm) { void* p = dlsym(r.lib, nm); if (!p && r.err.empty()) r.err = std::string("librccl: missing symbol ") + nm; return p; };
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
@@ -45,7 +50,6 @@ Rccl& rccl() {
     r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
     r.ok = r.err.empty();
-    return r;
 }
 
 constexpr int NCCL_DOUBLE = 8, NCCL_SUM = 0, NCCL_MAX = 2;      // ncclDataType_t / ncclRedOp_t (rccl.h)
@@ -78,9 +82,14 @@ extern "C" {
 int cesx_comm_unique_id(void* id_out) {
     if (!id_out) return CESX_EINVAL;
     Rccl& r = rccl();
-    if (!r.ok) return CESX_ERCCL;
+    // (no handle to hang the message on: cesx_last_error(NULL) returns it, as for cesx_create)
+    if (!r.ok) { cesx::set_global_error("cesx_comm_unique_id: " + r.err); return CESX_ERCCL; }
     Rccl::unique_id id;
-    if (r.GetUniqueId(&id) != 0) return CESX_ERCCL;
+    const int res = r.GetUniqueId(&id);
+    if (res != 0) {
+        cesx::set_global_error(std::string("ncclGetUniqueId: ") + (r.GetErrorString ? r.GetErrorString(res) : "RCCL error"));
+        return CESX_ERCCL;
+    }
     std::memcpy(id_out, id.internal, CESX_COMM_ID_BYTES);
     return CESX_OK;
 }

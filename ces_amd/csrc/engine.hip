@@ -178,6 +178,7 @@ int finish_metrics(Engine& e, const double* mom, const void* G, bool publish, hi
 // ---- the lookahead noise block riding on the reduce launches (cesx_internal.h, NoiseRide / Engine::xi_ride) ----
 }  // namespace
 namespace cesx {
+void set_global_error(const std::string& msg) { try { g_create_err = msg; } catch (...) {} }
 NoiseRide ride_range(Engine& e, unsigned n) {
     Engine::XiRide& r = e.xi_ride;
     NoiseRide nr;
@@ -536,6 +537,11 @@ int cesx_set_shift(cesx_handle h, const double* sums, void* stream) {
 
 static int moments_check(Engine& e, const void* U, const void* G, double* mom) {
     ++e.moments_calls;
+    // A step whose polled join runs out is re-run by cesx_result FROM ITS OWN moment buffer (include/cesx.h, lifetime
+    // rules).  A caller that hands the same buffer to the next step's moments before it has read that result gives the
+    // buffer up: the re-run is then not attempted (cesx_result reports CESX_EHIP for such a step instead of computing it
+    // from the next step's moments).
+    if (e.last_apply.valid && e.pending && mom != nullptr && mom == e.last_apply.mom) e.last_apply.mom_reused = true;
     if (!U || !G || !mom) { e.err = "cesx_moments: null pointer"; return CESX_EINVAL; }
     if (!e.problem_set) { e.err = "cesx_set_problem has not been called"; return CESX_ESTATE; }
     if (!e.shift_valid) { e.err = "no centring shift: call cesx_colsum + cesx_set_shift (or cesx_step with recenter) first"; return CESX_ESTATE; }
@@ -792,7 +798,7 @@ int cesx_result(cesx_handle h, cesx_step_result* out) {
         // From here on this engine joins its side stream with the event, and the step is re-run once with chol(C)
         // in line on the caller's stream (correct whatever the side stream is doing).
         e.poll_join_ok = false;
-        if (e.last_apply.valid && !e.in_retry && e.last_join_polled) {
+        if (e.last_apply.valid && !e.in_retry && e.last_join_polled && !e.last_apply.mom_reused) {
             const Engine::LastApply la = e.last_apply;
             e.in_retry = true;
             // whatever a pipelined driver put on the side stream behind the failed step (the centring + chol(C) of moments of
@@ -814,7 +820,10 @@ int cesx_result(cesx_handle h, cesx_step_result* out) {
             }
             return CESX_OK;
         }
-        e.err = "the side stream's factorisation never signalled its completion (the polled join timed out)";
+        e.err = e.last_apply.valid && e.last_apply.mom_reused
+            ? "the side stream's factorisation never signalled its completion (the polled join timed out), and the step's moment "
+              "buffer had already been handed to a later cesx_moments* call: not re-run (include/cesx.h, lifetime rules)"
+            : "the side stream's factorisation never signalled its completion (the polled join timed out)";
         return CESX_EHIP;
     }
     if (sc.status == CESX_ENOCONV) {

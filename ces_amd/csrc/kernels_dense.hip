@@ -1695,11 +1695,10 @@ static int assemble(Engine& e, hipStream_t s, int mode, int ktot, double sw) {
 // phase 2: aldi_constant noise coefficients after hk is known.
 bool stream_below_side(Engine& e, hipStream_t s) {
     if (!e.side_has_prio || s == e.side) return false;
-    if (e.prio_checked && s == e.prio_stream) return e.prio_ok;
+    // asked of the runtime at every cesx_apply (a cheap host call): a verdict cached by stream HANDLE would be inherited by
+    // another stream created at the same address with another priority (torch's stream pools, tests)
     int pr = 0;
-    const bool ok = hipStreamGetPriority(s, &pr) == hipSuccess && pr > e.side_prio;
-    e.prio_checked = true; e.prio_stream = s; e.prio_ok = ok;
-    return ok;
+    return hipStreamGetPriority(s, &pr) == hipSuccess && pr > e.side_prio;
 }
 
 int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int phase, hipStream_t s, bool upd2_ok) {

@@ -66,6 +66,9 @@ constexpr int G2_SLOT_IMM = 60 * 1024;                   // ... of launches whos
 #define G2_OPT 15   // 2 = row sums only where the type reports them, 4 = scalar DMA addressing, 8 = a block's partial sums stored
                     // as soon as its last MFMA of the slice is issued (no barrier behind the last tile), 16 = those stores non-temporal
 #endif
+#ifndef G2_OPQ      // dev A/B: which wave-uniform tests are re-evaluated at their use (1: DMA issue, 2: shift pass, 4: tile body)
+#define G2_OPQ 7
+#endif
 #ifdef G2_CLOCKS
 __device__ long long g_gram2_clk[4096 * 4];
 __device__ long long g_gram2_bar[4096 * 16];      // per wave: cycles spent in the per-tile barrier
@@ -165,16 +168,24 @@ void gram2_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __r
         rs[i] = 0;
         if ((ent >> 16) != 0) ownmask |= 1 << i;
     }
+    // Wave-uniform values the tile loop tests (np, nb, more) are made OPAQUE where they are used (an empty asm with a "+s"
+    // operand): the compiler otherwise evaluates every comparison once, in front of the loop, and keeps each result as a
+    // 64-bit lane mask -- seventeen SGPR pairs at the last count, which pushed the DMA bases and LDS addresses out of the
+    // scalar file and back in through v_readlane inside the loop (23 - 75 spilled SGPRs per instantiation, round 4's ISA).
+    // Re-evaluated at the use, a condition is one s_cmp + s_cbranch_scc and holds no register.
+    auto opaque_if = [](bool on, int v) { if (on) { v = __builtin_amdgcn_readfirstlane(v); asm volatile("" : "+s"(v)); } return v; };
+    auto opaque = [&](int v) { return opaque_if(true, v); };
     auto issue_tile = [&](int slot) {
+        const int npo = opaque_if(G2_OPQ & 1, np);
+        const unsigned l0 = (unsigned)opaque_if(G2_OPQ & 1, (int)lds0) + (unsigned)(slot * SSTR) + (unsigned)(wave * 1024);
 #pragma unroll
         for (int i = 0; i < G2_MAXP; ++i) {
-            const int pc = wave + G2_WAVES * i;
-            if (i < np) {
+            if (i < npo) {
                 if constexpr (SGA) {
-                    if (!(G2_ABL & 1)) glds16s(sbase[i], voff[i], lds0 + slot * SSTR + pc * 1024);
+                    if (!(G2_ABL & 1)) glds16s(sbase[i], voff[i], l0 + i * (G2_WAVES * 1024));
                     sbase[i] += G2_ROWB;
                 } else {
-                    if (!(G2_ABL & 1)) glds16(gsrc[i], lds0 + slot * SSTR + pc * 1024);
+                    if (!(G2_ABL & 1)) glds16(gsrc[i], l0 + i * (G2_WAVES * 1024));
                     gsrc[i] += KT;
                 }
             }
@@ -214,27 +225,32 @@ void gram2_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __r
     char* const sb0 = smem + lane * 16 + wave * 1024;
     auto shift_tile = [&](auto slotc) {
         constexpr int SLOT = decltype(slotc)::value;
-        // (two pieces at a time: 8 registers of temporaries beside the 64 accumulators and the 16 fragment addresses;
-        //  every branch is self-contained -- no value defined under one condition and used under another)
+        // (two pieces at a time: 8 registers of temporaries beside the 64 accumulators and the 16 fragment addresses.
+        //  ONE copy of the code of every piece: with a second copy in an else-branch the compiler merged the tails of the
+        //  two, indexed rs[] with a register and moved the row sums to scratch -- a scratch_load / s_waitcnt vmcnt(0) /
+        //  scratch_store round trip per piece pair and tile, round 4's ISA)
         auto one = [&](int i, vec_t v) {
 #pragma unroll
             for (int c = 0; c < VEC; ++c) v[c] -= psh[i];
-            if (((ownmask >> i) & 1) || !(G2_OPT & 2)) {
-                asm volatile("" ::: "memory");          // (keeps the branch: no select around four adds)
+            if (((opaque_if(G2_OPQ & 2, ownmask) >> i) & 1) || !(G2_OPT & 2)) {
+                T r = rs[i];
 #pragma unroll
-                for (int c = 0; c < VEC; ++c) rs[i] += v[c];
+                for (int c = 0; c < VEC; ++c) r += v[c];
+                asm volatile("" : "+v"(r));             // (keeps the branch: no select around the adds)
+                rs[i] = r;
             }
             *reinterpret_cast<vec_t*>(sb0 + SLOT * SSTR + i * (G2_WAVES * 1024)) = v;
         };
+        const int npo = opaque_if(G2_OPQ & 2, np);
 #pragma unroll
         for (int i0 = 0; i0 < G2_MAXP; i0 += 2) {
-            if (i0 + 1 < np) {
+            if (i0 < npo) {
+                const bool two = i0 + 1 < npo;
                 const vec_t v0 = *reinterpret_cast<const vec_t*>(sb0 + SLOT * SSTR + i0 * (G2_WAVES * 1024));
-                const vec_t v1 = *reinterpret_cast<const vec_t*>(sb0 + SLOT * SSTR + (i0 + 1) * (G2_WAVES * 1024));
+                vec_t v1 = v0;
+                if (two) v1 = *reinterpret_cast<const vec_t*>(sb0 + SLOT * SSTR + (i0 + 1) * (G2_WAVES * 1024));
                 one(i0, v0);
-                one(i0 + 1, v1);
-            } else if (i0 < np) {
-                one(i0, *reinterpret_cast<const vec_t*>(sb0 + SLOT * SSTR + i0 * (G2_WAVES * 1024)));
+                if (two) one(i0 + 1, v1);
             }
         }
     };
@@ -322,7 +338,9 @@ void gram2_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __r
     auto store_block = [&](int b) {
         int sl = slice;
         asm volatile("" : "+s"(sl));        // (opaque: the addresses are formed here, once, not hoisted into registers that stay live through the K loop)
-        T* out = slabs + ((size_t)slab0 + (size_t)sl * nblk_t + ((iab[b] >> 16) & 0xff)) * (TILE * TILE);
+        // (the lane offset is formed here, from mbcnt: not a 64-bit register pair held through the tile loop)
+        const unsigned lane_s = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        T* out = slabs + ((size_t)slab0 + (size_t)sl * nblk_t + ((iab[b] >> 16) & 0xff)) * (TILE * TILE) + (size_t)lane_s * VEC;
 #pragma unroll
         for (int q = 0; q < M::NACC / VEC; ++q) {
             vec_t v;
@@ -330,7 +348,7 @@ void gram2_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __r
             for (int c = 0; c < VEC; ++c) v[c] = acc[b][q * VEC + c];
             // (plain stores: the reduce launch right behind reads the slabs back; non-temporal stores, which drop
             //  the lines from L2, cost the step 1.6 % in round 3)
-            vec_t* dst = reinterpret_cast<vec_t*>(out + (size_t)(q * 64 + lane) * VEC);
+            vec_t* dst = reinterpret_cast<vec_t*>(out + (size_t)(q * 64) * VEC);
             typedef float st4_t __attribute__((ext_vector_type(4)));
             if (G2_OPT & 32) {          // write-through at agent scope: no dirty slab lines left for the kernel boundary to flush
                 st4_t sv;
@@ -345,26 +363,27 @@ void gram2_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __r
     };
     auto tile = [&](auto curc, int k) {
         constexpr int CUR = decltype(curc)::value;
-        const int more = nt - 1 - k;                           // > 0: a next tile exists
+        const int more = opaque_if(G2_OPQ & 4, nt - 1 - k);    // > 0: a next tile exists
+        const int nbo = opaque_if(G2_OPQ & 4, nb), sat = opaque_if(G2_OPQ & 4, shift_at);
         const std::integral_constant<int, CUR> cur;
         const std::integral_constant<int, CUR ^ 1> nxt;
         // the next tile's pieces: behind this wave's first MFMA group (the matrix pipe restarts right behind the barrier,
         // the DMA issue -- 16 waves x 4 pieces through one address unit -- runs under those MFMAs)
-        if (more > 0 && (!(G2_OPT & 1) || nb == 0)) issue_tile(CUR ^ 1);
+        if (more > 0 && (!(G2_OPT & 1) || nbo == 0)) issue_tile(CUR ^ 1);
         Frag f0, f1;
-        if (nb > 0) load_frag(f0, cur, 0, 0);
+        if (nbo > 0) load_frag(f0, cur, 0, 0);
 #pragma unroll
         for (int b = 0; b < NBW; ++b) {
             // This wave's pieces of tile t+1 (issued at the top of the tile, landed long since) are shifted in
             // place BETWEEN two of its blocks, at a different point for each of the 4 waves of a SIMD: the
             // LDS round trip of one wave's shift pass is covered by the MFMAs of the other three, instead of
             // all 16 waves running it together behind their last MFMA with the matrix pipes idle.
-            if (b == shift_at && more > 0) {
+            if (b == sat && more > 0) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (!(G2_ABL & 8)) shift_tile(nxt);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (b < nb) {
+            if (b < nbo) {
 #pragma unroll
                 for (int g = 0; g < NGROUP; ++g) {
                     Frag& fc = (g & 1) ? f1 : f0;
@@ -373,7 +392,7 @@ void gram2_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __r
                     if (g + 1 < NGROUP) {
                         load_frag(fn, cur, b, g + 1);
                     } else if (b + 1 < NBW) {
-                        if (b + 1 < nb) load_frag(fn, cur, b + 1, 0);
+                        if (b + 1 < nbo) load_frag(fn, cur, b + 1, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -384,7 +403,7 @@ void gram2_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __r
                 if ((G2_OPT & 8) && more <= 0) { store_block(b); __builtin_amdgcn_sched_barrier(0); }
             }
         }
-        if (shift_at == NBW && more > 0) {
+        if (sat == NBW && more > 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (!(G2_ABL & 8)) shift_tile(nxt);
         }
@@ -409,6 +428,9 @@ void gram2_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __r
 
     // first moments of this slice: the 8 cells of a row sit in the 8 lanes of this wave that share lane bits 2-4 --
     // summed in a fixed order (xor 1, 2, 32).  Only the type that owns a block row reports it.
+    // (the lane index is formed again here, from mbcnt: nothing derived from threadIdx stays live across the tile loop for this)
+    const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int r8_e = ((lane_e >> 4) & 1) * 4 + ((lane_e >> 2) & 3);
 #pragma unroll
     for (int i = 0; i < G2_MAXP; ++i) {
         double v = (double)rs[i];
@@ -417,8 +439,8 @@ void gram2_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __r
         v += __shfl_xor(v, 32, 64);
         const int pc = wave + G2_WAVES * i;
         const int ent = __builtin_amdgcn_readfirstlane(rows_tab[rows_off + (pc < npieces ? pc / PPB : 0)]);
-        const int gr = (ent & 0xffff) * TILE + (pc % PPB) * 8 + r8;
-        if ((lane & 0x23) == 0 && pc < npieces && (ent >> 16) != 0 && gr < P) rowsum_part[(size_t)(rs0 + slice) * P + gr] = v;
+        const int gr = (ent & 0xffff) * TILE + (pc % PPB) * 8 + r8_e;
+        if ((lane_e & 0x23) == 0 && pc < npieces && (ent >> 16) != 0 && gr < P) rowsum_part[(size_t)(rs0 + slice) * P + gr] = v;
     }
 
     // (an empty slice -- more workgroups than tiles -- still writes its zeros: the reduce sums every slice)

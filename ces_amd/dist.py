@@ -160,7 +160,7 @@ class ShardedUpdate:
         self._mom_idx ^= 1
         return self._moms[self._mom_idx]
 
-    def begin(self, prm, U, G, recenter=False, noise_step=None):
+    def begin(self, prm, U, G, recenter=False, noise_step=None, forward=None):
         """First half of a step: everything that does not need the pseudo-time of the previous
         step -- the moments, their all-reduce and chol(C).  Only ``prm.update`` is read, so a
         driver may enqueue ``begin`` of step i+1 BEFORE it reads the result of step i: the
@@ -172,9 +172,19 @@ class ShardedUpdate:
         Whether the head all-reduce runs on the side stream is decided ONCE, at construction
         (``overlap_comm``): a collective that may already have been enqueued is never retried,
         and an error raised here (HIP, RCCL) propagates, so that all ranks fail together instead
-        of one rank issuing an extra collective."""
+        of one rank issuing an extra collective.
+
+        ``forward``: ``forward(U, out=G)`` re-evaluates the forward map INTO ``G`` (a pipelined driver that computed
+        ``G = forward(U)`` from an ensemble the previous step was still to write passes it): should ``result()`` find
+        that the previous step had to be re-run, ``G`` was computed from an unwritten ``U`` -- the redo of this
+        ``begin`` then refreshes ``G`` in place first, so the driver's ``finish(prm, U, G)`` reads the right one."""
         eng = self.engine
-        self._last_begin = lambda: self.begin(prm, U, G, recenter=False, noise_step=noise_step)
+
+        def redo():
+            if forward is not None:
+                forward(U, out=G)
+            self.begin(prm, U, G, recenter=False, noise_step=noise_step, forward=forward)
+        self._last_begin = redo
         if recenter or not self._recentered:
             self.recenter(U, G)
         if noise_step is not None and hasattr(eng, "prefetch_noise") and not self.single_allreduce:
@@ -236,14 +246,15 @@ class ShardedUpdate:
                 and self.world == 1 and not self._force_collectives and not self.single_allreduce
                 and os.environ.get("CESX_LINEAL_FAST", "1") != "0")
 
-    def begin_lineal(self, prm, U, forward, noise_step=None, model=None):
+    def begin_lineal(self, prm, U, forward, noise_step=None, model=None, out=None):
         """``begin`` for a linear forward map the engine evaluates itself: only the U x U Gram
         runs; G = forward(U) is evaluated on the caller's stream BESIDE chol(C), and every G-dependent moment
         follows from the U-only head (cesx_moments_rest_lineal: two small fp64 products instead of the second Gram
         launch and its reduce -- 100 of the 136 blocks at p = n_obs = 256).  The centring shift must be valid (a
-        first step goes through ``begin`` with ``recenter``).  Returns (mom, G)."""
+        first step goes through ``begin`` with ``recenter``).  Returns (mom, G).  ``forward(U, out=None)``: a redo
+        (``result()``: the previous step was re-run) evaluates it INTO the tensor this call returned, which the driver
+        already holds."""
         eng = self.engine
-        self._last_begin = lambda: self.begin_lineal(prm, U, forward, noise_step=noise_step, model=model)
         if model is not None and hasattr(model, "ensure_installed"):
             model.ensure_installed(eng)              # the moment kernels below read the INSTALLED map: this model's, as of now
         if noise_step is not None:
@@ -255,8 +266,9 @@ class ShardedUpdate:
         # 512 workgroups, two on every CU -- the factorisation (8 waves x 256 registers: a CU to itself) started when the
         # GEMM had drained: 0.477 against 0.457 ms/step at C2
         eng.moments_rest_lineal(mom)
-        G = forward(U)
+        G = forward(U) if out is None else forward(U, out=out)
         self._mom = mom
+        self._last_begin = lambda: self.begin_lineal(prm, U, forward, noise_step=noise_step, model=model, out=G)
         return mom, G
 
     def finish(self, prm, U, G, xi=None, out=None):
@@ -321,12 +333,22 @@ class ShardedSampler:
         self.radspec = []
         self._steps_done = 0           # Philox step counter: a resumed run() draws fresh noise
 
-    def _forward(self, model, U):
+    def _forward(self, model, U, out=None):
         if hasattr(model, "forward_device"):
-            return model.forward_device(self.engine, U)
+            if out is None:
+                return model.forward_device(self.engine, U)
+            try:
+                return model.forward_device(self.engine, U, out=out)
+            except TypeError:                                       # a hook without ``out=``
+                out.copy_(model.forward_device(self.engine, U))
+                return out
         Uh = U.cpu().numpy().astype(np.float64)
         Gh = np.stack([np.asarray(model(u)) for u in Uh.T], axis=1)
-        return self.engine.to_device(Gh[: self.n_obs])
+        G = self.engine.to_device(Gh[: self.n_obs])
+        if out is not None:
+            out.copy_(G)
+            return out
+        return G
 
     def run(self, y_obs, U_shard, model, Gamma, mu, sigma, ustar, update="aldi", xis=None, **kwargs):
         """Returns the final shard (a device tensor of the engine)."""
@@ -356,12 +378,13 @@ class ShardedSampler:
             if pipelined:
                 U = self.sh.finish(prm, U, G, xi=xi)
                 if i + 1 < self.T:
+                    fwd = lambda u, out=None: self._forward(model, u, out=out)       # noqa: E731
                     if fast:
-                        _, G = self.sh.begin_lineal(prm0, U, lambda u: self._forward(model, u), model=model,
+                        _, G = self.sh.begin_lineal(prm0, U, fwd, model=model,
                                                     noise_step=self._steps_done if draw else None)
                     else:
                         G = self._forward(model, U)
-                        self.sh.begin(prm0, U, G, noise_step=self._steps_done if draw else None)
+                        self.sh.begin(prm0, U, G, noise_step=self._steps_done if draw else None, forward=fwd)
             else:
                 U = self.sh.step(prm, U, G, xi=xi, recenter=(i == 0))
             res = self.sh.result()

@@ -164,9 +164,15 @@ int cesx_step(cesx_handle h, const cesx_step_params* prm, const void* U_dev, con
    the first half of step i+1 before it reads the result of step i, or not: same numbers.
    Lifetime rule that follows: the held-back kernel is enqueued on the `stream` that was passed to
    cesx_apply / cesx_step, so that stream must stay valid until cesx_result (or any other entry
-   point of this handle) has been called; the moment buffer passed to cesx_apply is NOT read again
-   after cesx_apply returns and its kernels have run -- what the held-back kernel needs of it is
-   copied into engine-owned memory by cesx_apply's own kernels.) */
+   point of this handle) has been called; what the held-back kernel needs of the moment buffer is
+   copied into engine-owned memory by cesx_apply's own kernels.
+   Buffers of a step: U_dev, G_dev, xi_dev and U_next_dev must stay valid (and U, G, xi unchanged)
+   until cesx_result has returned for that step -- the step is not complete before, and the one
+   recovery path below launches its kernels again.  The moment buffer is read by cesx_apply's own
+   kernels and, in that recovery alone, once more by cesx_result; a caller may hand it to the next
+   step's cesx_moments* before it has read the result (one buffer, pipelined) -- the engine notices,
+   and a step whose recovery would need the overwritten buffer reports CESX_EHIP instead of being
+   re-run.  ces_amd/dist.py alternates two buffers.) */
 int cesx_result(cesx_handle h, cesx_step_result* out);
 
 /* How the caller's stream joins the engine's side stream (centring + chol(C)), and what happens when that goes wrong.
@@ -176,9 +182,12 @@ int cesx_result(cesx_handle h, cesx_step_result* out);
    ends); any other stream is joined with an event.  The poll is bounded in wall time (2 s; CESX_POLL_TIMEOUT_MS).  A poll
    that runs out marks the step: its assembly and update launches write NOTHING (U_next, the centring shift and the
    scalars stay as they were), cesx_result switches the engine to the event join for the rest of its life and re-runs
-   the step once with chol(C) in line on the caller's stream.  It then returns CESX_OK -- or CESX_ESTATE when
-   cesx_moments* calls were enqueued after the failed step (a pipelined driver): the re-run step's result and U_next
-   are valid, those moments were taken of an ensemble that had not been written and must be redone.
+   the step once with chol(C) in line on the caller's stream, from the step's own moment buffer and U / G / xi (see the
+   lifetime rules at cesx_result; a moment buffer that a later cesx_moments* call was given in the meantime: no re-run,
+   CESX_EHIP).  It then returns CESX_OK -- or CESX_ESTATE when cesx_moments* calls were enqueued after the failed step
+   (a pipelined driver): the re-run step's result and U_next are valid, those moments -- and whatever the driver derived
+   from the unwritten U_next before, its forward map G first of all -- must be redone (ces_amd/dist.py re-evaluates the
+   forward map into the caller's G tensor, then the moments).
    cesx_debug_poll_recoveries: how many steps of this handle were re-run that way. */
 unsigned long long cesx_debug_poll_recoveries(cesx_handle h);
 

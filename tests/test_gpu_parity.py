@@ -799,6 +799,40 @@ def test_polled_join_that_runs_out_leaves_the_step_untouched_and_is_rerun(eng_mo
     assert np.array_equal(U2, U0) and np.array_equal(c2, c0)
 
 
+@pytest.mark.parametrize("fast", ["0", "1"])
+def test_recovery_refreshes_the_forward_map_of_the_pipelined_begin(eng_mod, monkeypatch, fast):
+    """A pipelined driver evaluates G = forward(U_next) and enqueues the next step's moments BEFORE it reads the result
+    of the step that writes U_next.  When that step's polled join runs out it wrote nothing, cesx_result re-runs it --
+    and the G the driver holds was computed from an unwritten ensemble: the redo of the pipelined ``begin`` must
+    re-evaluate the forward map INTO that tensor (ShardedUpdate.begin(forward=) / begin_lineal(out=)), or the next
+    ``finish`` subtracts K G for a stale G.  With a real forward map (G = A U, the device hook of utils.lineal; with and
+    without the linear-map shortcut) the chain must equal the event-joined one bit for bit."""
+    import torch
+    from ces_amd.dist import ShardedSampler
+    from ces_amd.utils import lineal
+    p, n, J, T = 128, 96, 8192, 5
+    d = _synthetic(p, n, J, seed=83)
+    monkeypatch.setenv("CESX_LINEAL_FAST", fast)
+
+    def chain():
+        eng = eng_mod.Engine(p, n, J, dtype="float32", seed=11)
+        smp = ShardedSampler(eng, p, n, J)
+        smp.T = T
+        U = smp.run(d["y"], d["U0"], lineal(d["A"]), d["Gamma"], d["mu"], d["sigma"], d["ustar"], update="aldi", t_tol=1e30)
+        torch.cuda.synchronize()
+        return eng, U.cpu().numpy().copy(), {k: np.array(v) for k, v in smp.metrics.items()}, smp
+    monkeypatch.setenv("CESX_POLL_JOIN", "0")
+    _, U0, m0, _ = chain()
+    monkeypatch.setenv("CESX_POLL_JOIN", "1")
+    monkeypatch.setenv("CESX_POLL_TIMEOUT_MS", "20")
+    monkeypatch.setenv("CESX_TEST_DROP_CHOL_SIGNAL", "2")
+    e1, U1, m1, s1 = chain()
+    assert e1.poll_recoveries() == 1 and s1.sh.redone_begins == 1
+    assert np.array_equal(U1, U0)
+    for k in m0:
+        assert np.array_equal(m1[k], m0[k]), k
+
+
 def test_polled_join_only_below_the_side_streams_priority(eng_mod, monkeypatch):
     """A waiter in front of what it waits for in one hardware queue never ends, and streams of one priority level may
     share a queue: the caller's stream polls the factorisation's word only when its priority is strictly lower than the

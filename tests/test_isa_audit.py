@@ -1,0 +1,46 @@
+"""The hot kernels' register budget, checked on the ISA hipcc emits for gfx950 (no GPU needed).
+
+Round 4's Gram kernel kept its row sums in scratch (a scratch_load / s_waitcnt vmcnt(0) / scratch_store round trip
+per piece pair and tile) and reloaded 10 - 74 spilled SGPRs through v_readlane inside its tile loop; nobody had looked.
+tools/isa_audit.py compiles the translation units with -Rpass-analysis=kernel-resource-usage and walks the -S output;
+this test fails when a hot kernel gains scratch, spills, or spill traffic inside a loop.
+"""
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.fixture(scope="module")
+def table():
+    import isa_audit
+    t = isa_audit.collect(["kernels_gram2.hip", "kernels_update2.hip", "kernels_update3.hip"])
+    names = isa_audit.demangle(sorted(t))
+    return {re.sub(r"\(.*", "", names[k]).replace("cesx::", "").replace("void ", ""): v for k, v in t.items()}
+
+
+def test_gram_kernel_has_no_scratch_and_no_spills(table):
+    rows = {k: v for k, v in table.items() if k.startswith("gram2_kernel<")}
+    assert len(rows) == 8                                  # {float, double} x {scalar, per-lane DMA addressing} x {60-, 64-KiB slots}
+    for name, r in rows.items():
+        assert r["ScratchSize [bytes/lane]"] == 0, name
+        assert r["SGPRs Spill"] == 0 and r["VGPRs Spill"] == 0, name
+        assert r["scratch_total"] == 0 and r["spill_in_loop"] == 0, name
+        assert r["Occupancy [waves/SIMD]"] == 4, name      # 16 waves per workgroup, one workgroup per CU
+        assert r["mfma_in_loop"] == r["mfma"] > 0, name
+
+
+def test_update_kernels_keep_their_loops_free_of_scratch(table):
+    for name in ("update2_kernel<false, true>", "update2_kernel<false, false>", "update3_kernel"):
+        r = table[name]
+        assert r["scratch_in_loop"] == 0 and r["VGPRs Spill"] == 0 or name == "update3_kernel", name
+        assert r["scratch_in_loop"] == 0, name
+        assert r["Occupancy [waves/SIMD]"] == 2, name      # two workgroups of four waves per CU
+    # the benchmark's instantiation (every K segment from memory, hk applied at run time): the few SGPR reloads its
+    # k-tile loop still has (round 5 count; the Philox instantiations, which nothing on the hot path launches, have 36 - 40)
+    assert table["update2_kernel<false, true>"]["spill_in_loop"] <= 6
+    assert table["update2_kernel<false, true>"]["ScratchSize [bytes/lane]"] == 0
