@@ -88,6 +88,19 @@ class enka(object):
             print(r"NOTE: EKS has not been run!")
         return str()
 
+    # -- the base class's placeholders (ces/calibrate.py:50-93): no-ops there, no-ops here; ``sampling`` overrides them --
+    def run(self, y_obs, U0, model, Gamma, Jnoise):
+        """ces/calibrate.py:50-67: the driver loop's slot in the base class; does nothing, returns None."""
+        pass
+
+    def run_sde(self, y_obs, U0, model, Gamma, Jnoise):
+        """ces/calibrate.py:69-87: likewise."""
+        pass
+
+    def eks_update(self, Geval):
+        """ces/calibrate.py:89-93: likewise."""
+        pass
+
     # -- forward map: stays on the host (ces/calibrate.py:95-168) ------------
     def G(self, theta, model):
         return model(theta)

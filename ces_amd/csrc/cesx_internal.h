@@ -142,8 +142,7 @@ __device__ __forceinline__ void normal4(uint4x r, double out[4]) {
 }
 
 // One workgroup's share of a noise block xi[p][J] (256 threads; thread = rows 4 by .. 4 by + 3 of NP consecutive
-// particles of column block bx): the body of noise_kernel (kernels_update.hip) and of the workgroups that draw the
-// NEXT step's block while riding on the Gram's reduce launches (NoiseRide below).
+// particles of column block bx): the body of noise_kernel (kernels_update.hip).
 template <typename T, bool VEC4>
 __device__ __forceinline__ void noise_body(T* __restrict__ xi, int p, long long J, long long j_offset, unsigned seed_lo,
                                            unsigned seed_hi, unsigned step, unsigned bx, unsigned by) {
@@ -170,15 +169,6 @@ __device__ __forceinline__ void noise_body(T* __restrict__ xi, int p, long long 
         }
     }
 }
-
-// A range [wg0, wg0 + nwg) of the gx x gy workgroups of a noise block, drawn by extra workgroups of another launch
-// (xi == nullptr: none).  The two slab reduces of a step are latency / HBM bound with the vector ALUs idle: the next
-// step's block rides on them, half each, instead of running as a kernel of its own beside K2's latency-bound chain,
-// which it stretched by 10 - 20 us (round 4).
-struct NoiseRide {
-    void* xi = nullptr; int p = 0; long long J = 0, j_offset = 0; unsigned seed_lo = 0, seed_hi = 0, step = 0;
-    unsigned gx = 1, wg0 = 0, nwg = 0;
-};
 
 // ---------------------------------------------------------------------------
 // Packed fp64 moment buffer (the only data that crosses GPUs).  The part that
@@ -383,7 +373,6 @@ struct Engine {
     bool update_v2 = true;         // fp32 K3 through the LDS-DMA kernel (CESX_UPDATE_V1=1 switches back)
     int  center_u_wgs = 256;       // workgroups of the U-only centring on the side stream (see cesx_create)
     bool ext_events = true;        // hand-over events bound to kernels' own completion signals (CESX_EXT_EVENTS=0: separate markers)
-    bool k2_fused = true;          // ALDI, default / spectral time step: scalar + assemble kernels as one launch (CESX_K2_SPLIT=1 switches back)
     bool gram_v2 = true;           // K1 through the LDS-DMA kernel when the shapes allow (CESX_GRAM_V1=1 switches back)
     int num_cus = 256;
     void* d_bias = nullptr;        // [rpad]
@@ -435,17 +424,6 @@ struct Engine {
     long long xi_step[2] = {-1, -1};                 // step index block b holds (-1: none)
     unsigned long long xi_seq[2] = {0, 0};           // chol_seq of the cesx_chol_async call that drew block b
     long long xi_want = -1;          // step index asked for by cesx_prefetch_noise, drawn behind the next chol(C)
-    // the lookahead block riding on the reduce launches of the caller's stream (NoiseRide): planned by the U x U reduce,
-    // completed by the second reduce (or flushed as a launch of its own by whatever needs the block first)
-    struct XiRide { bool active = false; long long step = -1; int buf = 0; unsigned done = 0, total = 0, gx = 1; hipStream_t stream = nullptr; } xi_ride;
-    bool xi_ride_ok = false;         // CESX_NOISE_RIDE=1 switches the ride on (default: the lookahead block is drawn by a kernel on the
-                                     // side stream, behind chol(C)).  Measured at C2 (round 4, tools/ab_env.py): the reduces are HBM bound, not
-                                     // idle -- 30 % of the block on each takes them from 11.8 / 12.1 to 14.6 / 15.4 us; step 0.3973 (30:40:30),
-                                     // 0.3984 (20:50:30), 0.4010 (25:25:50), 0.3996 (40:20:40) against 0.3944-0.3950 with the whole draw behind chol(C)
-    int  xi_ride_pct = 30;           // share of the block that rides on the first reduce, and the share the side stream draws
-    int  xi_ride_pct_side = 40;      // behind chol(C) (beside the tail of K2); the rest rides on the second reduce (CESX_NOISE_RIDE_PCT=a,s)
-    hipEvent_t ev_r[2] = {nullptr, nullptr};         // block b's ride shares are complete on xi_stream[b] (another stream asked for the block)
-    hipStream_t xi_stream[2] = {nullptr, nullptr};   // != nullptr: block b was drawn on that stream (ordered for kernels enqueued there later)
     bool xi_lookahead = true;        // CESX_NOISE_LOOKAHEAD=0 switches the second draw off
     unsigned long long chol_seq = 0;              // cesx_chol_async calls so far
     // ---- the side stream joined through a polled word instead of a barrier packet (round 3, launch_dense) ----
@@ -493,12 +471,8 @@ struct UpdateSrc {            // one K-segment of the update GEMM
 
 int launch_colsum(Engine& e, const void* U, const void* G, double* sums, hipStream_t s);
 int launch_set_shift(Engine& e, const double* sums, hipStream_t s);
-int launch_gram(Engine& e, int part, const void* U, const void* G, double* mom, hipStream_t s, bool no_reduce = false,
-                const NoiseRide* ride = nullptr);   // part 0 / 1
-int launch_gram_reduce(Engine& e, int part, double* mom, hipStream_t s, hipEvent_t stop = nullptr, const MetricFin* fin = nullptr,
-                       const NoiseRide* ride = nullptr);   // the fp64 slab reduce of that launch (stop: bound to its completion)
-int launch_noise_range(Engine& e, const NoiseRide& r, hipStream_t s);      // the same range as a launch of its own
-NoiseRide ride_range(Engine& e, unsigned n);                                 // the next n workgroups of the ride in flight (engine.hip)
+int launch_gram(Engine& e, int part, const void* U, const void* G, double* mom, hipStream_t s, bool no_reduce = false);   // part 0 / 1
+int launch_gram_reduce(Engine& e, int part, double* mom, hipStream_t s, hipEvent_t stop = nullptr, const MetricFin* fin = nullptr);   // the fp64 slab reduce of that launch (stop: bound to its completion)
 // kernels_gram2.hip (LDS-DMA Gram): CESX_OK, an error, or -1 when the launch does not qualify (caller falls back)
 int launch_gram2(Engine& e, int part, const void* U, const void* G, hipStream_t s);
 int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int phase, hipStream_t s, bool upd2_ok = false);

@@ -120,22 +120,12 @@ int finish_step(Engine& e, const cesx_step_params& prm, hipStream_t s) {
     return CESX_OK;
 }
 
-int ride_flush(Engine& e);
-
 // the noise block of this step drawn ahead by cesx_prefetch_noise (nullptr: draw inside the update kernel)
 const void* prefetched_noise(Engine& e, const cesx_step_params& prm, hipStream_t s) {
     // drawn on the side stream behind chol(C); its own event, waited for HERE (right before the update kernel):
     // K2's scalar and assemble kernels do not need the block and run beside the draw
-    if (e.xi_ride.active && e.xi_ride.step == (long long)prm.step_index && ride_flush(e) != CESX_OK) return nullptr;
     for (int b = 0; b < 2; ++b) {
         if (!e.d_xi[b] || e.xi_step[b] != (long long)prm.step_index) continue;
-        if (e.xi_stream[b] != nullptr) {          // shares drawn on a caller's stream (the ride): ordered for that stream's later kernels
-            if (e.xi_stream[b] != s) {
-                if (!e.ev_r[b] && hipEventCreateWithFlags(&e.ev_r[b], hipEventDisableTiming) != hipSuccess) return nullptr;
-                if (hipEventRecord(e.ev_r[b], e.xi_stream[b]) != hipSuccess || hipStreamWaitEvent(s, e.ev_r[b], 0) != hipSuccess) return nullptr;
-            }
-            if (e.xi_seq[b] == 0) return e.d_xi[b];      // (no share on the side stream)
-        }
         // a block drawn behind an EARLIER chol(C) precedes this step's chol(C) on the side stream: a stream that has
         // waited for this step's ev_b is already ordered behind the draw
         const bool ordered = e.xi_seq[b] < e.evb_waited_seq && s == e.evb_waited_stream;
@@ -175,53 +165,11 @@ int finish_metrics(Engine& e, const double* mom, const void* G, bool publish, hi
     return launch_metric_final(e, mom, publish, s);
 }
 
-// ---- the lookahead noise block riding on the reduce launches (cesx_internal.h, NoiseRide / Engine::xi_ride) ----
 }  // namespace
 namespace cesx {
 void set_global_error(const std::string& msg) { try { g_create_err = msg; } catch (...) {} }
-NoiseRide ride_range(Engine& e, unsigned n) {
-    Engine::XiRide& r = e.xi_ride;
-    NoiseRide nr;
-    n = std::min(n, r.total - r.done);
-    nr.xi = e.d_xi[r.buf]; nr.p = e.p; nr.J = e.J; nr.j_offset = e.cfg.j_offset;
-    nr.seed_lo = (unsigned)e.cfg.seed; nr.seed_hi = (unsigned)(e.cfg.seed >> 32); nr.step = (unsigned)r.step;
-    nr.gx = r.gx; nr.wg0 = r.done; nr.nwg = n;
-    r.done += n;
-    if (r.done == r.total) {         // every workgroup of the block is enqueued (r.stream; the side stream's share: xi_seq)
-        e.xi_step[r.buf] = r.step;
-        e.xi_stream[r.buf] = r.stream;
-        r.active = false;
-    }
-    return nr;
-}
 }  // namespace cesx
 namespace {
-// plan the ride of block (xi_want + 1) and return its first share (nothing to ride: xi == nullptr)
-NoiseRide ride_begin(Engine& e, hipStream_t s) {
-    NoiseRide none;
-    if (e.xi_ride.active && e.xi_ride.step != e.xi_want + 1) e.xi_ride.active = false;      // (a ride nobody completed: its buffer stays marked empty)
-    if (!e.xi_ride_ok || e.xi_ride.active || e.xi_want < 0 || !e.xi_lookahead || !e.d_xi[0] || !e.d_xi[1]) return none;
-    if (e.J % 4 != 0 || ((uintptr_t)e.d_xi[0] % (4 * e.esz)) || ((uintptr_t)e.d_xi[1] % (4 * e.esz))) return none;
-    const int have = e.xi_step[0] == e.xi_want ? 0 : e.xi_step[1] == e.xi_want ? 1 : -1;
-    const int lb = have < 0 ? 1 : have ^ 1;      // (have < 0: launch_chol_async draws block xi_want into buffer 0)
-    if (e.xi_step[lb] == e.xi_want + 1) return none;
-    Engine::XiRide& r = e.xi_ride;
-    r.active = true; r.step = e.xi_want + 1; r.buf = lb; r.done = 0; r.stream = s;
-    r.gx = (unsigned)((e.J / 4 + 255) / 256);
-    r.total = r.gx * (unsigned)((e.p + 3) / 4);
-    e.xi_step[lb] = -1;
-    e.xi_stream[lb] = nullptr;
-    e.xi_seq[lb] = 0;
-    return ride_range(e, (unsigned)((unsigned long long)r.total * (unsigned)e.xi_ride_pct / 100));
-}
-// what is left of a ride, as a launch of its own on the ride's stream (the second reduce never came)
-int ride_flush(Engine& e) {
-    if (!e.xi_ride.active) return CESX_OK;
-    hipStream_t s = e.xi_ride.stream;
-    const NoiseRide nr = ride_range(e, e.xi_ride.total);
-    return launch_noise_range(e, nr, s);
-}
-
 // the deferred metric finalisation + publication of the last update (Engine::met_deferred), as a kernel of its own
 int flush_metrics(Engine& e) {
     if (!e.met_deferred) return CESX_OK;
@@ -278,19 +226,11 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
     if (const char* ov = std::getenv("CESX_OVERLAP")) e.overlap_chol = ov[0] != '0';
     if (const char* uv = std::getenv("CESX_UPDATE_V1")) e.update_v2 = uv[0] == '0';
     if (const char* gv = std::getenv("CESX_GRAM_V1")) e.gram_v2 = gv[0] == '0';
-    if (const char* kv = std::getenv("CESX_K2_SPLIT")) e.k2_fused = kv[0] == '0';
     if (const char* xv = std::getenv("CESX_EXT_EVENTS")) e.ext_events = xv[0] != '0';
     if (const char* dv = std::getenv("CESX_DEFER_PUBLISH")) e.met_defer_ok = dv[0] != '0';
     if (const char* fv = std::getenv("CESX_FUSE_CENTER")) { e.fuse_center_ok = fv[0] != '0'; e.fuse_center_auto = false; }
     if (const char* pv = std::getenv("CESX_POLL_JOIN")) e.poll_join_ok = pv[0] != '0';
     if (const char* hv = std::getenv("CESX_HKFREE")) e.hkfree_ok = hv[0] != '0';
-    if (const char* rv = std::getenv("CESX_NOISE_RIDE")) e.xi_ride_ok = rv[0] != '0';
-    if (const char* rv = std::getenv("CESX_NOISE_RIDE_PCT")) {
-        e.xi_ride_ok = true;
-        e.xi_ride_pct = std::max(0, std::min(100, std::atoi(rv)));
-        const char* c = std::strpbrk(rv, ",:");
-        e.xi_ride_pct_side = c ? std::max(0, std::min(100 - e.xi_ride_pct, std::atoi(c + 1))) : 0;
-    }
     if (const char* dv = std::getenv("CESX_TEST_DROP_CHOL_SIGNAL")) e.test_drop_signal_at = (unsigned long long)std::max(0, std::atoi(dv));
     if (const char* tv = std::getenv("CESX_POLL_TIMEOUT_MS")) e.poll_ticks = (unsigned long long)std::max(1, std::atoi(tv)) * 100000ull;
     auto fail = [&](int rc) { g_create_err = e.err; cesx_destroy(reinterpret_cast<cesx_handle>(ep)); return rc; };
@@ -315,9 +255,7 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
         const long long ntiles = (e.J + kt - 1) / kt;
         for (int part = 0; part < 2; ++part) {
             GramPart& gp = e.gp[part];
-            int min_types = 1;
-            if (part == 0) if (const char* gv = std::getenv("CESX_GRAM_UU_TYPES")) min_types = std::atoi(gv);
-            if (part == 1) if (const char* gv = std::getenv("CESX_GRAM_B_TYPES")) min_types = std::atoi(gv);
+            const int min_types = 1;
             // part 1: 7 workgroups per shader engine (8 CUs), so that the Cholesky always finds a free CU
             // Part 1 runs beside what the side stream carries, and a kernel on another stream is only placed
             // while it needs no more whole CUs than are free (tools/place_probe.hip: beside 248 one-per-CU
@@ -328,16 +266,15 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
             //     GEMM launches of tens of workgroups) -> 1 CU in 8 stays free (224).
             const bool slim_side = e.J == e.Jg && potrf_ld(p) <= 256;
             e.center_u_wgs = slim_side ? 8 : 256;       // (16 x 1024 threads do NOT get placed on the 8 free CUs: measured)
-            int budget = part == 0 ? e.num_cus : e.num_cus - (slim_side ? e.num_cus / 32 : e.num_cus / 8);
-            if (part == 1) if (const char* bv = std::getenv("CESX_GRAM_B_WGS")) budget = std::max(8, std::atoi(bv));
+            const int budget = part == 0 ? e.num_cus : e.num_cus - (slim_side ? e.num_cus / 32 : e.num_cus / 8);
             gp.plan = make_gram_plan(P, tile, gram_nbw(cfg->dtype), gram_max_stage_rows(), part + 1, pbU, min_types,
                                      budget, ntiles);
             // fp32, second launch, two types by capacity: three lighter ones.  The planner's cost model prices the tiles, not
             // the partial slabs a launch leaves behind -- written in a burst behind the last tile and read back by the reduce
             // (~22 us of the step for 51 MB at C2).  Three types (32 / 48 / 20 blocks over 82 / 114 / 52 slices) leave 37 MB
             // at 25 % more row traffic and a 4 % worse balance: 0.3944 -> 0.3924 ms/step (tools/ab_env.py, round 4); four
-            // types 0.3990, two types for the U x U launch 0.4015 against 0.3956.  CESX_GRAM_B_TYPES overrides.
-            if (part == 1 && cfg->dtype == CESX_F32 && gp.plan.ntypes == 2 && !std::getenv("CESX_GRAM_B_TYPES") && !std::getenv("CESX_GRAM_SPLIT"))
+            // types 0.3990, two types for the U x U launch 0.4015 against 0.3956.
+            if (part == 1 && cfg->dtype == CESX_F32 && gp.plan.ntypes == 2)
                 gp.plan = make_gram_plan(P, tile, gram_nbw(cfg->dtype), gram_max_stage_rows(), part + 1, pbU, 3, budget, ntiles);
             if (gp.plan.max_rb * tile > gram_max_stage_rows()) { e.err = "gram plan exceeds LDS"; return fail(CESX_EINVAL); }
         }
@@ -469,7 +406,7 @@ void cesx_destroy(cesx_handle h) {
     if (e.h_scal) (void)hipHostFree(e.h_scal);
     if (e.ev_a) (void)hipEventDestroy(e.ev_a);
     if (e.ev_b) (void)hipEventDestroy(e.ev_b);
-    for (hipEvent_t ev : {e.ev_x[0], e.ev_x[1], e.ev_r[0], e.ev_r[1]})
+    for (hipEvent_t ev : {e.ev_x[0], e.ev_x[1]})
         if (ev) (void)hipEventDestroy(ev);
     if (e.side) (void)hipStreamDestroy(e.side);
     if (e.comm) (void)cesx_comm_destroy(h);
@@ -576,15 +513,13 @@ static int moments_uu_handover(Engine& e, const void* U, const void* G, double* 
     ++e.prof_step;
     if (e.met_deferred && e.met_stream != s) FLUSH(e);
     TRY(launch_gram(e, 0, U, G, mom, s, true));
-    // (the next step's noise block: its first share rides on this reduce launch, the rest on the second one)
-    const NoiseRide nr = ride_begin(e, s);
     if (e.met_deferred) {
         MetricFin f = metric_fin_args(e, nullptr, true);
         f.N = (double)e.Jg;
         e.met_deferred = false;
-        TRY(launch_gram_reduce(e, 0, mom, s, e.ev_a, &f, &nr));
+        TRY(launch_gram_reduce(e, 0, mom, s, e.ev_a, &f));
     } else {
-        TRY(launch_gram_reduce(e, 0, mom, s, e.ev_a, nullptr, &nr));
+        TRY(launch_gram_reduce(e, 0, mom, s, e.ev_a, nullptr));
     }
     CESX_HIP(hipStreamWaitEvent(e.side, e.ev_a, 0));
     return CESX_OK;
@@ -635,10 +570,6 @@ int cesx_moments_rest(cesx_handle h, const void* U, const void* G, double* mom, 
     FLUSH(e);
     // (the reduce kernel of this launch also copies this shard's data-metric sums of the PREVIOUS
     //  apply to the tail of the buffer: they ride on this step's all-reduce)
-    if (e.xi_ride.active && e.xi_ride.stream == (hipStream_t)stream) {
-        const NoiseRide nr = ride_range(e, e.xi_ride.total);
-        return launch_gram(e, 1, U, G, mom, (hipStream_t)stream, false, &nr);
-    }
     return launch_gram(e, 1, U, G, mom, (hipStream_t)stream);
 }
 
@@ -651,7 +582,6 @@ int cesx_moments_rest_lineal(cesx_handle h, double* mom, void* stream) {
     if (!e.fwd_set) { e.err = "cesx_moments_rest_lineal: cesx_forward_set_lineal has not been called"; return CESX_ESTATE; }
     SET_DEVICE(e);
     FLUSH(e);
-    TRY(ride_flush(e));          // (no second reduce launch on this path)
     return launch_moments_lineal(e, mom, (hipStream_t)stream);
 }
 

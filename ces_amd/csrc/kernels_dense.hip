@@ -1719,7 +1719,7 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
     // read what the side stream wrote (trace / bias partials, later L).  One event each way per step -- every
     // record / wait pair costs ~6 us of idle GPU.
     const bool early = e.chol_inflight;
-    const bool fused_finish = phase == 0 && prm.update == CESX_UPDATE_ALDI && e.k2_fused &&
+    const bool fused_finish = phase == 0 && prm.update == CESX_UPDATE_ALDI &&
         (prm.time_step == CESX_TS_DEFAULT || prm.time_step == CESX_TS_SPECTRAL);
     // (early, centring fused into the Cholesky's load: the U part is done HERE, with the G part, and leaves the
     //  status word alone -- the side stream carried nothing but the factorisation)
@@ -1939,7 +1939,6 @@ int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s, b
             CESX_HIP(hipEventRecord(e.ev_x[b], e.side));
             e.xi_step[b] = step;
             e.xi_seq[b] = e.chol_seq;
-            e.xi_stream[b] = nullptr;
             return CESX_OK;
         };
         int have = e.xi_step[0] == e.xi_want ? 0 : (e.d_xi[1] && e.xi_step[1] == e.xi_want) ? 1 : -1;
@@ -1947,17 +1946,7 @@ int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s, b
             have = 0;
             if ((rc = draw(e.xi_want, 0))) return rc;
         }
-        // (the lookahead block may be riding on the caller's reduce launches instead: Engine::xi_ride)
-        const bool riding = e.xi_ride.active && e.xi_ride.step == e.xi_want + 1;
-        if (riding && e.xi_ride_pct_side > 0) {
-            // the side stream's share of the riding block: behind chol(C), beside the tail of K2
-            const int b = e.xi_ride.buf;
-            const NoiseRide nr = ride_range(e, (unsigned)((unsigned long long)e.xi_ride.total * (unsigned)e.xi_ride_pct_side / 100));
-            if ((rc = launch_noise_range(e, nr, e.side))) return rc;
-            CESX_HIP(hipEventRecord(e.ev_x[b], e.side));
-            e.xi_seq[b] = e.chol_seq;
-        }
-        if (e.xi_lookahead && e.d_xi[1] && !riding && e.xi_step[have ^ 1] != e.xi_want + 1)
+        if (e.xi_lookahead && e.d_xi[1] && e.xi_step[have ^ 1] != e.xi_want + 1)
             if ((rc = draw(e.xi_want + 1, have ^ 1))) return rc;
         e.xi_want = -1;
     }

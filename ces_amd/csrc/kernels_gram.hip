@@ -274,15 +274,9 @@ __global__ __launch_bounds__(RED_G * RED_S)
 void gram_reduce_kernel(const T* __restrict__ slabs, const int* __restrict__ blk_rc, const int* __restrict__ row_own,
                         int nblocks, int tile, MomLayout ml, long long J, int row_lo, int row_hi,
                         int write_N, const double* __restrict__ rowsum_part, const double* __restrict__ tail_src,
-                        double* __restrict__ mom, const MetricFin fin, const NoiseRide ride, unsigned ride_first) {
+                        double* __restrict__ mom, const MetricFin fin) {
     using vec_t = typename Mfma<T>::vec_t;
     constexpr int VEC = Mfma<T>::VEC;
-    // workgroups behind the reduce's own: a share of the next step's noise block (cesx_internal.h, NoiseRide)
-    if (blockIdx.x >= ride_first) {
-        const unsigned id = ride.wg0 + (blockIdx.x - ride_first);
-        noise_body<T, true>((T*)ride.xi, ride.p, ride.J, ride.j_offset, ride.seed_lo, ride.seed_hi, ride.step, id % ride.gx, id / ride.gx);
-        return;
-    }
     // the previous update's metric finalisation + publication, riding on this launch as one extra workgroup -- the
     // FIRST one: its chain of dependent loads, fences and the write to host memory (~8 us) starts with the launch and
     // ends inside it
@@ -491,13 +485,12 @@ GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset, 
         };
         // (fp64: equal runs.  The cost model was fitted to the tiles, not to what a workgroup does once per launch: for C2 in
         //  fp64 the search cut the U x U launch's 136 blocks into 8 + 128 -- 228 workgroups of 18 tiles with 256 KB of slabs
-        //  each -- where 68 + 68 runs the two Gram launches in 0.362 instead of 0.408 ms, round 4; CESX_GRAM_SEARCH_F64=1)
-        const bool search = sizes0.size() >= 2 && sizes0.size() <= 3 && !std::getenv("CESX_GRAM_EQUAL_RUNS") &&
-                            (tile == 32 || std::getenv("CESX_GRAM_SEARCH_F64"));
+        //  each -- where 68 + 68 runs the two Gram launches in 0.362 instead of 0.408 ms, round 4)
+        const bool search = sizes0.size() >= 2 && sizes0.size() <= 3 && tile == 32;
         std::vector<Cand> cands;
         cands.push_back(eval(all_rm, sizes0));
         for (const auto* all : {&all_rm, &all_cm}) {
-            if (all == &all_cm && (sizes0.size() < 2 || std::getenv("CESX_GRAM_ROW_MAJOR"))) break;
+            if (all == &all_cm && sizes0.size() < 2) break;
             if (all == &all_cm) cands.push_back(eval(*all, sizes0));
             if (!search) continue;
             std::vector<int> cand(sizes0.size());
@@ -514,16 +507,6 @@ GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset, 
                     }
                 }
             }
-        }
-        // dev: CESX_GRAM_SPLIT="c:32,48,20" (second launch) / CESX_GRAM_UU_SPLIT=... pins the listing (r / c) and the run sizes
-        if (const char* sv = std::getenv(subset == 1 ? "CESX_GRAM_UU_SPLIT" : "CESX_GRAM_SPLIT")) {
-            std::vector<int> sz;
-            const bool cm = sv[0] == 'c';
-            int tot = 0;
-            for (const char* q = std::strchr(sv, ':'); q && *q; q = std::strpbrk(q + 1, ",/")) { sz.push_back(std::atoi(q + 1)); tot += sz.back(); }
-            bool ok = tot == nb_all && !sz.empty();
-            for (int v : sz) ok = ok && v >= 1 && v <= cap;
-            if (ok) { cands.clear(); cands.push_back(eval(cm ? all_cm : all_rm, sz)); }
         }
         size_t pick = 0;
         {
@@ -569,7 +552,7 @@ GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset, 
             if (a0 >= b0) --a0; else --b0;
         }
         int best_a = a0, best_b = b0;
-        if (!std::getenv("CESX_GRAM_SQUARE_RECTS")) {
+        {
             double best_cost = 1e300, best_rows = 1e300;
             for (int a = 1; a <= std::min(cap, pl.nbr); ++a) {
                 const int b = std::min(cap / a, pl.nbr);
@@ -611,8 +594,8 @@ GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset, 
         total += w[t];
     }
     // (many types -- the rectangles of a triangle that does not fit LDS: levelled as well since round 4, the proportional
-    //  rule below rounds 17.5 slices down to 16 for eight types at once; CESX_GRAM_PROPORTIONAL=1 switches back)
-    if ((pl.ntypes <= 4 || pl.nbr * tile > max_rows_lds || std::getenv("CESX_GRAM_LEVEL_ALL")) && !std::getenv("CESX_GRAM_PROPORTIONAL")) {
+    //  rule below rounds 17.5 slices down to 16 for eight types at once; round 4)
+    if (pl.ntypes <= 4 || pl.nbr * tile > max_rows_lds) {
         // few types, many slices each: whole tiles per slice, levelled (gram_level_slices)
         gram_level_slices(w, std::max(wg_budget, pl.ntypes), ntiles, nsl);
     } else {
@@ -623,9 +606,7 @@ GramPlan make_gram_plan(int P, int tile, int nbw, int max_rows_lds, int subset, 
         // types of the second launch read 131 MB instead of 238 MB).
         // ... unless there are many types with few slices each: rounding 17.5 down to 16 then costs more (the
         // busiest workgroup sets the launch time) than the shared fetches save
-        int align_from = 16;
-        if (const char* av = std::getenv("CESX_GRAM_ALIGN_FROM")) align_from = std::max(8, std::atoi(av));
-        else if (pl.ntypes > 4) align_from = 64;
+        const int align_from = pl.ntypes > 4 ? 64 : 16;
         std::vector<double> want(pl.ntypes);
         for (int t = 0; t < pl.ntypes; ++t) want[t] = total > 0 ? (double)budget * w[t] / total : 1.0;
         std::vector<int> order(pl.ntypes);
@@ -749,39 +730,37 @@ static int launch_gram_t(Engine& e, int part, const void* U, const void* G, hipS
 }
 
 template <typename T>
-static int launch_gram_reduce_t(Engine& e, int part, double* mom, hipStream_t s, hipEvent_t stop, const MetricFin* fin, const NoiseRide* ride) {
+static int launch_gram_reduce_t(Engine& e, int part, double* mom, hipStream_t s, hipEvent_t stop, const MetricFin* fin) {
     GramPart& gp = e.gp[part];
     const GramPlan& pl = gp.plan;
     const long long ngroups = (long long)pl.nblocks * pl.tile * pl.tile / Mfma<T>::VEC;
     const int row_lo = std::min(pl.own_lo * pl.tile, e.p + e.n), row_hi = std::min(pl.own_hi * pl.tile, e.p + e.n);
     const long long wgs = (ngroups + RED_G - 1) / RED_G + std::max(1, (row_hi - row_lo + RED_G - 1) / RED_G) + (fin ? 1 : 0);
     const MetricFin f = fin ? *fin : MetricFin{};
-    const NoiseRide nr = ride ? *ride : NoiseRide{};
-    const unsigned ride_first = (unsigned)wgs;
-    const long long wgs_all = wgs + (nr.xi ? nr.nwg : 0);
+    const long long wgs_all = wgs;
     if (stop)
         hipExtLaunchKernelGGL(gram_reduce_kernel<T>, dim3((unsigned)wgs_all), dim3(RED_G * RED_S), 0, s, nullptr, stop, 0,
                               (const T*)gp.d_slabs, (const int*)gp.d_blk_rc, (const int*)gp.d_row_own, pl.nblocks, pl.tile, e.ml,
                               (long long)e.J, row_lo, row_hi, part == 0 ? 1 : 0, (const double*)gp.d_rowsum_part,
-                              part == 1 ? (const double*)e.d_metric_sums : (const double*)nullptr, mom, f, nr, ride_first);
+                              part == 1 ? (const double*)e.d_metric_sums : (const double*)nullptr, mom, f);
     else
     hipLaunchKernelGGL(gram_reduce_kernel<T>, dim3((unsigned)wgs_all), dim3(RED_G * RED_S), 0, s,
                        (const T*)gp.d_slabs, gp.d_blk_rc, gp.d_row_own, pl.nblocks, pl.tile, e.ml,
                        (long long)e.J, row_lo, row_hi, part == 0 ? 1 : 0, gp.d_rowsum_part,
-                       part == 1 ? e.d_metric_sums : (const double*)nullptr, mom, f, nr, ride_first);
+                       part == 1 ? e.d_metric_sums : (const double*)nullptr, mom, f);
     CESX_HIP(hipGetLastError());
     return CESX_OK;
 }
 
-int launch_gram_reduce(Engine& e, int part, double* mom, hipStream_t s, hipEvent_t stop, const MetricFin* fin, const NoiseRide* ride) {
-    return e.cfg.dtype == CESX_F32 ? launch_gram_reduce_t<float>(e, part, mom, s, stop, fin, ride)
-                                   : launch_gram_reduce_t<double>(e, part, mom, s, stop, fin, ride);
+int launch_gram_reduce(Engine& e, int part, double* mom, hipStream_t s, hipEvent_t stop, const MetricFin* fin) {
+    return e.cfg.dtype == CESX_F32 ? launch_gram_reduce_t<float>(e, part, mom, s, stop, fin)
+                                   : launch_gram_reduce_t<double>(e, part, mom, s, stop, fin);
 }
 
-int launch_gram(Engine& e, int part, const void* U, const void* G, double* mom, hipStream_t s, bool no_reduce, const NoiseRide* ride) {
+int launch_gram(Engine& e, int part, const void* U, const void* G, double* mom, hipStream_t s, bool no_reduce) {
     int rc = e.cfg.dtype == CESX_F32 ? launch_gram_t<float>(e, part, U, G, s) : launch_gram_t<double>(e, part, U, G, s);
     if (rc != CESX_OK || no_reduce) return rc;
-    return launch_gram_reduce(e, part, mom, s, nullptr, nullptr, ride);
+    return launch_gram_reduce(e, part, mom, s, nullptr, nullptr);
 }
 
 int gram_nbw(int dtype) { return dtype == CESX_F32 ? GramCfg<float>::NBW : GramCfg<double>::NBW; }

@@ -383,13 +383,6 @@ void noise_kernel(T* __restrict__ xi, int p, long long J, long long j_offset, un
     noise_body<T, VEC4>(xi, p, J, j_offset, seed_lo, seed_hi, step, blockIdx.x, blockIdx.y);
 }
 
-template <typename T>
-__global__ __launch_bounds__(256)
-void noise_range_kernel(const NoiseRide r) {
-    const unsigned id = r.wg0 + blockIdx.x;
-    noise_body<T, true>((T*)r.xi, r.p, r.J, r.j_offset, r.seed_lo, r.seed_hi, r.step, id % r.gx, id / r.gx);
-}
-
 // ---------------------------------------------------------------------------
 // opt.ldw    row stride of W (0: = ktot)
 template <typename T, int WCT>
@@ -494,14 +487,6 @@ int launch_noise(Engine& e, uint64_t step_index, void* xi, hipStream_t s) {
     } else {
         if (vec4) go(noise_kernel<double, true>, (double*)xi); else go(noise_kernel<double, false>, (double*)xi);
     }
-    CESX_HIP(hipGetLastError());
-    return CESX_OK;
-}
-
-int launch_noise_range(Engine& e, const NoiseRide& r, hipStream_t s) {
-    if (r.nwg == 0) return CESX_OK;
-    if (e.cfg.dtype == CESX_F32) hipLaunchKernelGGL(noise_range_kernel<float>, dim3(r.nwg), dim3(256), 0, s, r);
-    else hipLaunchKernelGGL(noise_range_kernel<double>, dim3(r.nwg), dim3(256), 0, s, r);
     CESX_HIP(hipGetLastError());
     return CESX_OK;
 }

@@ -575,7 +575,6 @@ int launch_update2(Engine& e, int out_rows, const void* Wf, int ktot, const void
     // the dispatcher gives every CU one workgroup before any CU gets its second: from there on start late
     a.stagger_from = (long long)grid.x * grid.y > e.num_cus ? e.num_cus : 0x7fffffff;
     a.stagger_n = 2;
-    if (const char* sv = std::getenv("CESX_U2_STAGGER")) a.stagger_n = std::atoi(sv);
     const bool noise = kind[0] != 0 || kind[1] != 0 || kind[2] != 0;
     auto kern = opt.hkp ? (noise ? update2_kernel<true, true> : update2_kernel<false, true>)
                         : (noise ? update2_kernel<true, false> : update2_kernel<false, false>);

@@ -72,12 +72,7 @@ class ShardedUpdate:
             overlap_comm = (isinstance(dev, torch.device) and dev.type == "cuda" and
                             (self.world > 1 or os.environ.get("CESX_FORCE_COMM_OVERLAP") == "1"))
         self.overlap_comm = bool(overlap_comm)
-        # CESX_SIDE_GRAM=1: the U x U Gram launch itself also goes to the side stream.  Measured slower at C2
-        # (0.54 against 0.49 ms/step): stream priority does not keep the second launch's workgroups off the
-        # CUs, the U x U launch finishes later and chol(C), which is on the critical path, starts later.
         dev = getattr(engine, "device", None)
-        self.side_gram = (isinstance(dev, torch.device) and dev.type == "cuda" and
-                          os.environ.get("CESX_SIDE_GRAM", "0") != "0")
         self._cs = None
         self._moms, self._mom_idx = None, 0
         self._nuu = None
@@ -201,9 +196,11 @@ class ShardedUpdate:
             self._all_reduce(mom, tag="whole", mom=mom)
             self._mom = mom
             return mom
-        if self.overlap_comm and not self.side_gram and hasattr(eng, "moments_uu_handover"):
+        if self.overlap_comm and hasattr(eng, "moments_uu_handover"):
             # main stream: U x U Gram (the device to itself) -> hand-over -> the rest of the Gram;
             # side stream (high priority), beside the rest of the Gram: all-reduce of the head -> C, L = chol(C)
+            # (the U x U launch itself on the side stream was measured slower -- 0.54 against 0.49 ms/step at C2, round 2: the
+            #  two Gram launches fight for the CUs, the U x U one finishes late and chol(C) starts late -- and is gone)
             if self._cs is None:        # the engine's own side stream: no third stream to share a hardware queue
                 self._cs = eng.side_stream()
             eng.moments_uu_handover(U, G, out=mom)
@@ -211,19 +208,6 @@ class ShardedUpdate:
                 self._all_reduce(mom[:nuu], tag="head", mom=mom)  # N, sum(u - s), S_aa: all chol(C) needs
                 eng.chol_async(prm, mom)
             eng.moments_rest(U, G, mom)
-        elif self.overlap_comm or self.side_gram:
-            cur = torch.cuda.current_stream(eng.device)
-            if self._cs is None:        # the engine's own side stream: no third stream to share a hardware queue
-                self._cs = eng.side_stream() if hasattr(eng, "side_stream") else torch.cuda.Stream(device=eng.device)
-            self._cs.wait_stream(cur)                # U, G and the centring shift are ready
-            # CESX_SIDE_GRAM=1 (measured slower: the two Gram launches fight for the CUs, the U x U one finishes late):
-            # side stream: U x U Gram -> all-reduce of the head -> C, L = chol(C); main stream: the rest of the Gram
-            with torch.cuda.stream(self._cs):
-                eng.moments_uu(U, G, out=mom)
-            eng.moments_rest(U, G, mom)
-            with torch.cuda.stream(self._cs):
-                self._all_reduce(mom[:nuu], tag="head", mom=mom)  # N, sum(u - s), S_aa: all chol(C) needs
-                eng.chol_async(prm, mom)
         elif self.world == 1 and not self._force_collectives and hasattr(eng, "moments_uu_chol"):
             eng.moments_uu_chol(prm, U, G, out=mom)  # no collective between the two: one call, no marker packet
             eng.moments_rest(U, G, mom)

@@ -84,6 +84,13 @@ def test_host_mirror_keeps_reference_interface():
     assert list(inspect.signature(sampling.timestep_method).parameters)[:6] == \
         ["self", "D", "Geval", "y_obs", "Gamma", "Jnoise"]
     assert sampling.run_eks is sampling.run
+    # the base class's placeholders (ces/calibrate.py:50-93): same signatures, no-ops that return None
+    e = enka(p=2, n_obs=10, J=40)
+    assert list(inspect.signature(enka.run).parameters) == ["self", "y_obs", "U0", "model", "Gamma", "Jnoise"]
+    assert list(inspect.signature(enka.run_sde).parameters) == ["self", "y_obs", "U0", "model", "Gamma", "Jnoise"]
+    assert list(inspect.signature(enka.eks_update).parameters) == ["self", "Geval"]
+    assert e.run(None, None, None, None, None) is None and e.run_sde(None, None, None, None, None) is None
+    assert e.eks_update(None) is None
 
 
 def test_g_ens_matches_reference_loop():

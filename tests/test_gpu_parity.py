@@ -611,8 +611,8 @@ def test_comm_overlap_stream_path_matches(eng_mod):
 
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
 def test_single_device_fast_path_variants_match(eng_mod, monkeypatch, dtype):
-    """The single-device fast path -- hand-over events bound to kernels (cesx_moments_uu_chol), the scalar and assemble
-    kernels as one launch, the noise block drawn one step ahead, the metric finalisation + publication riding on the
+    """The single-device fast path -- hand-over events bound to kernels (cesx_moments_uu_chol), the noise block drawn one
+    step ahead, the metric finalisation + publication riding on the
     NEXT step's U x U reduce launch -- gives bit-identical chains to the plain path (separate markers, kernels and a
     metric_final kernel per step), in a pipelined loop (begin(i+1) before result(i)) and in a step-by-step one."""
     from ces_amd.dist import ShardedUpdate
@@ -625,7 +625,6 @@ def test_single_device_fast_path_variants_match(eng_mod, monkeypatch, dtype):
     for fast, pipelined in ((True, True), (True, False), (False, True), (False, False)):
         for k in ("CESX_EXT_EVENTS", "CESX_DEFER_PUBLISH", "CESX_NOISE_LOOKAHEAD"):
             monkeypatch.setenv(k, "1" if fast else "0")
-        monkeypatch.setenv("CESX_K2_SPLIT", "0" if fast else "1")
         eng = eng_mod.Engine(p, n, J, dtype=dtype, seed=9)
         eng.set_problem(d["y"], d["Gamma"], d["mu"], d["sigma"], d["ustar"])
         sh = ShardedUpdate(eng)
@@ -756,26 +755,6 @@ def test_hk_free_update_matches_the_assembled_form(eng_mod, monkeypatch, p, n, J
     assert np.allclose(c1, c0, rtol=2e-5, atol=0)
     for U, c in ((U2, c2), (U3, c3)):                                 # the same launches on the same numbers
         assert np.array_equal(U, U1) and np.array_equal(c, c1)
-
-
-@pytest.mark.parametrize("split", ["30:40", "100:0", "0:0", "0:100"])
-def test_noise_block_riding_on_the_reduce_launches_is_the_same_block(eng_mod, monkeypatch, split):
-    """CESX_NOISE_RIDE_PCT=a:s: the lookahead noise block is drawn by extra workgroups of the two slab reduces (a % on the
-    first, the rest on the second) and s % by a kernel behind chol(C), instead of one kernel on the side stream.  Philox is
-    counter based: the same numbers wherever a workgroup of the block runs -- bit-identical chains, pipelined and step by
-    step (the second reduce completes the block; a driver that asks for it earlier gets the rest flushed)."""
-    p, n, J = 128, 96, 8192
-    d = _synthetic(p, n, J, seed=83)
-    _, U0, c0, _ = _aldi_chain(eng_mod, d, p, n, J, "float32", nsteps=5, pipelined=True)
-    monkeypatch.setenv("CESX_NOISE_RIDE_PCT", split)
-    _, U1, c1, _ = _aldi_chain(eng_mod, d, p, n, J, "float32", nsteps=5, pipelined=True)
-    _, U2, c2, _ = _aldi_chain(eng_mod, d, p, n, J, "float32", nsteps=5)
-    _, U3, c3, _ = _aldi_chain(eng_mod, d, p, n, J, "float64", nsteps=3, pipelined=True)
-    monkeypatch.delenv("CESX_NOISE_RIDE_PCT")
-    _, U4, c4, _ = _aldi_chain(eng_mod, d, p, n, J, "float64", nsteps=3, pipelined=True)
-    assert np.array_equal(U1, U0) and np.array_equal(c1, c0)
-    assert np.array_equal(U2, U0) and np.array_equal(c2, c0)
-    assert np.array_equal(U3, U4) and np.array_equal(c3, c4)
 
 
 def test_polled_join_that_runs_out_leaves_the_step_untouched_and_is_rerun(eng_mod, monkeypatch):

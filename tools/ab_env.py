@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """dev tool: A/B of engine build-time switches (environment variables read by cesx_create) in ONE process.
 
-    python tools/ab_env.py "CESX_POLL_JOIN=0" "" "CESX_NOISE_LOOKAHEAD=0,CESX_K2_SPLIT=1" [--rounds 3 --steps 400]
+    python tools/ab_env.py "CESX_POLL_JOIN=0" "" "CESX_NOISE_LOOKAHEAD=0,CESX_HKFREE=0" [--rounds 3 --steps 400]
 
 One engine per configuration (the variables are set only while that engine is created), the C2 step driven as in
 bench.py (pipelined begin / finish / result over a ring of 4 resident batches), the configurations interleaved
