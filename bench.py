@@ -74,14 +74,23 @@ def sysfs_sclk():
     return None
 
 
-def synthetic_problem(p, n, seed=20240):
-    """SURVEY.md 8(d) [decision]: A ~ N(0,1)/sqrt(p), Gamma = 0.01 I, mu = 0, Sigma = 100 I."""
+def synthetic_problem(p, n, seed=20240, dense_gamma=False, dense_sigma=False):
+    """SURVEY.md 8(d) [decision]: A ~ N(0,1)/sqrt(p), Gamma = 0.01 I, mu = 0, Sigma = 100 I; the dense variants
+    ("Gamma = L L^T + n I", scaled to the same size: 0.01 (B B^T / n + I), 100 (B B^T / p + I)) take the general path."""
     rng = np.random.default_rng(seed)
     A = rng.standard_normal((n, p)) / np.sqrt(p)
     ustar = rng.standard_normal((p, 1))
     Gamma = 0.01 * np.eye(n)
     y = (A @ ustar).ravel() + 0.1 * rng.standard_normal(n)
-    return dict(A=A, ustar=ustar, Gamma=Gamma, y=y, mu=np.zeros((p, 1)), sigma=100.0 * np.eye(p))
+    sigma = 100.0 * np.eye(p)
+    rng2 = np.random.default_rng(seed + 1)          # (the diagonal problem's numbers do not move)
+    if dense_gamma:
+        B = rng2.standard_normal((n, n))
+        Gamma = 0.01 * (B @ B.T / n + np.eye(n))
+    if dense_sigma:
+        B = rng2.standard_normal((p, p))
+        sigma = 100.0 * (B @ B.T / p + np.eye(p))
+    return dict(A=A, ustar=ustar, Gamma=Gamma, y=y, mu=np.zeros((p, 1)), sigma=sigma)
 
 
 def _cpu_model():
@@ -283,13 +292,26 @@ def e2e_block(engine, prob, p, n, J, dtype, update, dev_index):
     return out
 
 
-def engine_leg(engine, name, p, n, J, dtype, steps, dev_index, prewarm_s=0.6, update="aldi"):
+def flops_executed(p, n, J, dtype):
+    """MFMA flops a step really issues (what SQ_VALU_MFMA_BUSY_CYCLES counts), next to the algorithmic ones of SURVEY.md
+    8(d): K1 computes whole 32 x 32 (fp32) / 16 x 16 (fp64) blocks of the lower triangle of Z Z^T -- the diagonal blocks'
+    upper halves are computed and thrown away --, K3 skips the zero blocks of its lower-triangular sqrt(2hk) L segment at
+    the granularity of a row block (32 / 16 rows): 2 p J (p + n) + p J (p + row block)."""
+    tile = 32 if np.dtype(dtype) == np.dtype(np.float32) else 16
+    nbr = -(-(p + n) // tile)
+    k1 = 2.0 * (nbr * (nbr + 1) // 2) * tile * tile * J
+    k3 = 2.0 * p * J * (p + n) + 1.0 * p * J * (p + tile)
+    return k1, k3
+
+
+def engine_leg(engine, name, p, n, J, dtype, steps, dev_index, prewarm_s=0.6, update="aldi", time_step=None,
+               dense_gamma=False, dense_sigma=False, t_start=0.0, sample=True):
     """A short engine-only leg of another BASELINE.json configuration on one GPU, measured like the headline (ring of 4
     resident batches, pipelined begin / finish / result, continuous stepping up to the timed region, one
     HIP-event-sampled step in its middle): ms/step, particle-updates/s and the K1 / K3 roofline fractions."""
     from ces_amd.dist import ShardedUpdate
     dev = torch.device("cuda", dev_index)
-    prob = synthetic_problem(p, n)
+    prob = synthetic_problem(p, n, dense_gamma=dense_gamma, dense_sigma=dense_sigma)
     eng = engine.Engine(p, n, J, dtype=dtype, device=dev_index, seed=1234)
     eng.set_problem(prob["y"], prob["Gamma"], prob["mu"], prob["sigma"], prob["ustar"])
     sh = ShardedUpdate(eng)
@@ -302,7 +324,7 @@ def engine_leg(engine, name, p, n, J, dtype, steps, dev_index, prewarm_s=0.6, up
         batches.append((U, eng.forward_lineal(prob["A"], U)))
     out = eng.empty(p)
     prm0 = engine.step_params(update=update)
-    t_hist, at = [0.0], [-1]
+    t_hist, at = [t_start], [-1]
     eng.profile_enable(True)
     eng.profile_enable(False)
 
@@ -314,7 +336,10 @@ def engine_leg(engine, name, p, n, J, dtype, steps, dev_index, prewarm_s=0.6, up
     def finish(i):
         U, G = batches[i % 4]
         eng.profile_enable(i == at[0])
-        prm = engine.step_params(update=update, first_step=(i == 0), t_len=min(i, 1), t_last=t_hist[0], step_index=i)
+        # (t_start > 0: a run that is already past its spin-up -- time_step='mix' then takes delta_t and recomputes the gain)
+        first = i == 0 and t_start == 0.0
+        prm = engine.step_params(update=update, time_step=time_step, first_step=first, t_len=0 if first else 1,
+                                 t_last=t_hist[0], step_index=i)
         sh.finish(prm, U, G, xi=None, out=out)
 
     def run_steps(first, count):
@@ -323,8 +348,9 @@ def engine_leg(engine, name, p, n, J, dtype, steps, dev_index, prewarm_s=0.6, up
             finish(i)
             if i + 1 < first + count:
                 begin(i + 1)
-            t_hist[0] = eng.result().t_new
-    at[0] = 4                                    # first time-stamped launches: outside the timed region
+            # (the pseudo-time restarts where it began every 64 steps: a leg is thousands of steps of ONE ring of batches)
+            t_hist[0] = eng.result().t_new if (i + 1) % 64 else t_start
+    at[0] = 4 if sample else -1                  # first time-stamped launches: outside the timed region
     run_steps(0, 16)
     eng.profile_read(0), eng.profile_read(1)
     at[0] = -1
@@ -332,7 +358,7 @@ def engine_leg(engine, name, p, n, J, dtype, steps, dev_index, prewarm_s=0.6, up
     while time.perf_counter() - t0 < prewarm_s:
         run_steps(0, 64)
     torch.cuda.synchronize()
-    at[0] = 3 + steps // 2
+    at[0] = 3 + steps // 2 if sample else -1
     t0 = time.perf_counter()
     run_steps(3, steps)
     torch.cuda.synchronize()
@@ -343,15 +369,20 @@ def engine_leg(engine, name, p, n, J, dtype, steps, dev_index, prewarm_s=0.6, up
     u_ms, u_cnt = eng.profile_read(1)
     peak = MFMA_PEAK_TF[np.dtype(dtype).name]
     k1f, k3f = float(p + n) ** 2 * J, 2.0 * p * (2 * p + n) * J
+    k1x, k3x = flops_executed(p, n, J, dtype)
     kern = {"gram_kernel(K1)": dict(avg_launch_ms=round(g_ms, 4), launches_per_step=g_cnt,
                                     tflops=round(k1f / (g_ms * 1e-3) / 1e12, 2) if g_ms > 0 else None,
-                                    frac=round(k1f / (g_ms * 1e-3) / 1e12 / peak, 4) if g_ms > 0 else None),
+                                    frac=round(k1f / (g_ms * 1e-3) / 1e12 / peak, 4) if g_ms > 0 else None,
+                                    frac_executed=round(k1x / (g_ms * 1e-3) / 1e12 / peak, 4) if g_ms > 0 else None),
             "update_kernel(K3)": dict(avg_launch_ms=round(u_ms, 4), launches_per_step=u_cnt,
                                       tflops=round(k3f / (u_ms * 1e-3) / 1e12, 2) if u_ms > 0 else None,
-                                      frac=round(k3f / (u_ms * 1e-3) / 1e12 / peak, 4) if u_ms > 0 else None)}
+                                      frac=round(k3f / (u_ms * 1e-3) / 1e12 / peak, 4) if u_ms > 0 else None,
+                                      frac_executed=round(k3x / (u_ms * 1e-3) / 1e12 / peak, 4) if u_ms > 0 else None)}
     esz = np.dtype(dtype).itemsize
-    rec = dict(workload="%s: J=%d, d=p=%d, n_obs=%d, %s, update=%s, synthetic linear-Gaussian inputs resident in HBM, "
-                        "on-device noise, engine only" % (name, J, p, n, np.dtype(dtype).name, update),
+    rec = dict(workload="%s: J=%d, d=p=%d, n_obs=%d, %s, update=%s, time_step=%s, %s Gamma, %s Sigma, synthetic linear-Gaussian "
+                        "inputs resident in HBM, on-device noise, engine only"
+                        % (name, J, p, n, np.dtype(dtype).name, update, time_step, "dense" if dense_gamma else "diagonal",
+                           "dense" if dense_sigma else "diagonal"),
                value=J * steps / el, unit="particle-updates/s", steps=steps, ms_per_step=1e3 * el / steps,
                dtype={"float32": "f32", "float64": "f64"}[np.dtype(dtype).name],
                roofline=dict(bound="mfma", peak=peak, unit="TFLOP/s", kernels=kern,
@@ -415,6 +446,74 @@ def darcy_leg(engine, dev_index, J=512, T=3):
                 includes="sampling.run(trace=False): per iteration one host forward evaluation of every particle "
                          "(sparse solve of the 5-point Darcy operator), float64 arrays across PCIe into and out of the "
                          "update (host-array calling convention), the final forward evaluation")
+
+
+VARIANTS = (   # (key, kwargs of engine_leg) -- every rule / problem class of the same reference function (ces/calibrate.py:418-529)
+    ("aldi_default", dict()),
+    ("eks", dict(update="eks")),
+    ("aldi_constant", dict(update="aldi_constant")),
+    ("time_step_constant", dict(time_step="constant")),
+    ("time_step_mix_late", dict(time_step="mix", t_start=5.0)),
+    ("time_step_spectral", dict(time_step="spectral")),
+    ("dense_gamma", dict(dense_gamma=True)),
+    ("dense_sigma", dict(dense_sigma=True)),
+    ("dense_gamma_sigma", dict(dense_gamma=True, dense_sigma=True)),
+    ("eks_dense_gamma_sigma", dict(update="eks", dense_gamma=True, dense_sigma=True)),
+)
+
+
+def variants_leg(engine, p, n, J, dtype, dev_index, steps=10):
+    """"a dense-Gamma / dense-Sigma variant is run once to show the general path costs the same" -- and the
+    other update rules and time-step rules of the same reference function: engine-only legs of `steps` steps each at the
+    headline shape, measured like the headline (pipelined begin / finish / result over 4 resident batches, continuous
+    stepping up to the timed steps), with their ratio to the default step measured the same way."""
+    out = {}
+    for key, kw in VARIANTS:
+        try:
+            r = engine_leg(engine, "variant " + key, p, n, J, dtype, steps, dev_index, prewarm_s=0.25, sample=False, **kw)
+            out[key] = dict(ms_per_step=round(r["ms_per_step"], 4), value=r["value"], **{k: v for k, v in kw.items()})
+        except Exception as ex:                     # one leg must not cost the line the others
+            out[key] = dict(error=repr(ex))
+    base = out.get("aldi_default", {}).get("ms_per_step")
+    for key, r in out.items():
+        if base and "ms_per_step" in r:
+            r["ratio_to_default"] = round(r["ms_per_step"] / base, 3)
+    out["how"] = ("engine-only, %d timed steps each behind 0.25 s of continuous stepping, same shape and dtype as the headline; "
+                  "time_step_mix_late: pseudo-time past the spin-up (delta_t and the recomputed gain of ces/calibrate.py:470-473)"
+                  % steps)
+    return out
+
+
+def sharded_helper_main():
+    """``bench.py --sharded-helper``: started by the one-GPU benchmark BEFORE it touches the GPU (a process that has
+    initialised the GPU must not start another program); waits for a line on stdin, then runs the one-rank rehearsal of
+    the SHARDED path -- RCCL really initialised, the step's all-reduces really issued (CESX_FORCE_COLLECTIVES=1) -- once
+    per collective mode, each in a fresh child, and prints one JSON object."""
+    if not sys.stdin.readline().strip():
+        return                                       # parent went away / did not ask
+    out = {}
+    for key, extra_env in (("head_tail", {}), ("single", {"CESX_SINGLE_ALLREDUCE": "1"})):
+        env = dict(os.environ)
+        env.update(CESX_FORCE_COLLECTIVES="1", CESX_BENCH_PREWARM_S="1.0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.update(extra_env)
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            env["MASTER_PORT"] = str(sk.getsockname()[1])
+        env["MASTER_ADDR"] = "127.0.0.1"
+        try:
+            res = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-extras", "--no-cpu-baseline", "--steps", "20",
+                                  "--warmup", "3"], env=env, capture_output=True, text=True, timeout=240)
+            line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+            d = json.loads(line[-1])
+            out[key] = dict(value=d["value"], ms_per_step=d["ms_per_step"], ms_per_step_median=d["ms_per_step_median"],
+                            rccl_nranks=d["rccl_nranks"], collective_mode=d["sampled_step"]["collective_mode"],
+                            collectives_per_step=d["sampled_step"]["collectives_per_step"],
+                            collective_ms=d["sampled_step"]["collective_ms"],
+                            gram_end_to_k3_start_ms=d["sampled_step"]["gram_end_to_k3_start_ms"],
+                            parallelism=d["config"]["parallelism"])
+        except Exception as ex:
+            out[key] = dict(error=repr(ex))
+    print(json.dumps(out), flush=True)
 
 
 class Platform:
@@ -542,8 +641,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
     plat = PLATFORM
-    dev = plat.device(local)
     rehearse = world == 1 and os.environ.get("CESX_FORCE_COLLECTIVES") == "1"   # one-rank run of the N > 1 code path
+    # The one-rank rehearsal of the sharded path (`extra.sharded_one_rank`) runs in fresh processes; their launcher is
+    # started HERE, before this process touches the GPU, and sleeps on a pipe until the headline is measured.
+    helper = None
+    if (world == 1 and not rehearse and not args.no_extras and args.config == "C2" and plat.backend == "nccl"
+            and os.environ.get("CESX_BENCH_NO_SHARDED_LEG") != "1"):
+        try:
+            helper = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--sharded-helper"], stdin=subprocess.PIPE,
+                                      stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        except Exception:
+            helper = None
+    dev = plat.device(local)
     rccl_nranks = 0                               # ranks RCCL saw in an actual all-reduce (0: no communicator)
     if world > 1 or rehearse:
         # RCCL prints a version banner on stdout when its first communicator comes up: this process's stdout carries
@@ -771,8 +880,11 @@ def main():
         "gram_kernel(K1)": dict(ms=gram_ms / nprof, flops=float(p + n) ** 2 * J, launches=gram_cnt / nprof),
         "update_kernel(K3)": dict(ms=upd_ms / nprof, flops=2.0 * p * (2 * p + n) * J, launches=upd_cnt / nprof),
     }
+    # ... and what the matrix pipe really issues (triangular-aware, block-granular: flops_executed)
+    kern["gram_kernel(K1)"]["flops_executed"], kern["update_kernel(K3)"]["flops_executed"] = flops_executed(p, n, J, args.dtype)
     for k in kern.values():
         k["tflops"] = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
+        k["tflops_executed"] = k["flops_executed"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
     dom = max(kern, key=lambda k: kern[k]["ms"])
     peak = MFMA_PEAK_TF[np.dtype(args.dtype).name]
     dname = np.dtype(args.dtype).name
@@ -817,9 +929,17 @@ def main():
                                and k not in ("gram_kernel", "update_kernel", "colsum_final_kernel", "rowsum_kernel",
                                              "set_shift_kernel")))
                      if traffic_tab else None)
+    mfma_util_tab = traffic_tab.get("_mfma_util", {}) if traffic_tab else {}
     roofline = dict(bound="mfma", kernel=dom, achieved=round(kern[dom]["tflops"], 2), peak=peak,
                     unit="TFLOP/s", frac=round(kern[dom]["tflops"] / peak, 4), traffic=traffic,
                     traffic_source=traffic_source,
+                    # `frac` prices the ALGORITHMIC flops of SURVEY.md 8(d) (K3: 2 p (2p + n) J -- the zero blocks of the
+                    # triangular sqrt(2hk) L segment included, which the kernel skips); what the hardware did:
+                    #   frac_executed  flops the kernel really issues / its time / peak
+                    #   mfma_util      SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), PMC passes of an earlier
+                    #                  run of this configuration (profiles/traffic.json, same source as `traffic`)
+                    frac_executed=round(kern[dom]["tflops_executed"] / peak, 4),
+                    mfma_util=mfma_util_tab.get(tkey[dom]),
                     calibration=dict(tflops=round(calib_tf, 2), clock_ghz=round(calib_ghz, 4),
                                      frac_of_calibration=round(kern[dom]["tflops"] / calib_tf, 4) if calib_tf > 0 else None,
                                      what="bare %s loop (operands in registers, 4 accumulators per wave, 2 x 256 threads "
@@ -828,12 +948,16 @@ def main():
                     avg_launch_ms=round(kern[dom]["ms"], 4), profiled_steps=prof["steps"],
                     kernels={k: dict(avg_launch_ms=round(v["ms"], 4), launches_per_step=v["launches"],
                                      tflops=round(v["tflops"], 2), frac=round(v["tflops"] / peak, 4),
+                                     flops=v["flops"], flops_executed=v["flops_executed"],
+                                     frac_executed=round(v["tflops_executed"] / peak, 4),
+                                     mfma_util=mfma_util_tab.get(tkey[k]),
                                      sampled=where[k],
                                      traffic=traffic_tab.get(tkey[k]),
                                      hbm_gbs=(round(traffic_tab[tkey[k]] / (v["ms"] * 1e-3) / 1e9, 1)
                                               if traffic_tab.get(tkey[k]) and v["ms"] > 0 else None))
                              for k, v in kern.items()},
                     step_flops_frac=round(sum(v["flops"] for v in kern.values()) / step_s / 1e12 / peak, 4),
+                    step_flops_executed_frac=round(sum(v["flops_executed"] for v in kern.values()) / step_s / 1e12 / peak, 4),
                     # the other roofline the north star asks for: HBM bytes (PMC counters) / kernel time / 8 TB/s
                     hbm_gbs=(round(traffic / (kern[dom]["ms"] * 1e-3) / 1e9, 1) if traffic and kern[dom]["ms"] > 0 else None),
                     hbm_frac=(round(traffic / (kern[dom]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
@@ -907,15 +1031,44 @@ def main():
                 extra["C4"]["e2e_darcy"] = darcy_leg(engine, local)
             except Exception as ex:             # (scipy missing, ...): the engine legs above still stand
                 extra["C4"]["e2e_darcy"] = dict(error=repr(ex))
-            extra["small_J"] = small_j_leg(engine, local)
+            try:
+                extra["small_J"] = small_j_leg(engine, local)
+            except Exception as ex:
+                extra["small_J"] = dict(error=repr(ex))
+            # every other rule / time step / dense problem of the same reference function at the headline shape
+            extra["variants"] = variants_leg(engine, p, n, J, args.dtype, local)
+            # the sharded path on this one GPU, RCCL really initialised and issued, both collective modes (fresh processes;
+            # this one stays idle meanwhile).  NO 1 -> 8 scaling curve is measured by this line: one rank only.
+            if helper is not None:
+                try:
+                    torch.cuda.synchronize()
+                    txt, _ = helper.communicate("go\n", timeout=600)
+                    extra["sharded_one_rank"] = json.loads([ln for ln in txt.splitlines() if ln.startswith("{")][-1])
+                    extra["sharded_one_rank"]["note"] = ("one rank: the collectives are really issued through RCCL but move nothing "
+                                                         "over xGMI; no scaling curve is implied")
+                except Exception as ex:
+                    extra["sharded_one_rank"] = dict(error=repr(ex))
+                    try:
+                        helper.kill()
+                    except Exception:
+                        pass
+                helper = None
             rec["extra"] = extra
         rec["e2e"] = e2e_block(engine, prob, p, n, J, args.dtype, args.update, local)
     if world == 1 and not args.no_cpu_baseline:
         rec["cpu_baseline"] = cpu_baseline(prob, p, n, J, np.dtype(args.dtype).type)
+    if helper is not None:                       # (not asked: it exits on the empty line)
+        try:
+            helper.communicate("\n", timeout=10)
+        except Exception:
+            helper.kill()
     print(json.dumps(rec), flush=True)
     if world > 1 or rehearse:
         dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main()
+    if "--sharded-helper" in sys.argv:
+        sharded_helper_main()
+    else:
+        main()

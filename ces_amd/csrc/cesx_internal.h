@@ -318,18 +318,30 @@ struct Engine {
     int p = 0, n = 0, P = 0;
     int64_t J = 0, Jg = 0;
     size_t esz = 4;               // sizeof(T)
-    bool diag_gamma = false, diag_sigma = false;
+    bool diag_sigma = false;
+    // Dense Gamma (the reference's pde examples use a sample covariance, examples/notebooks/lorenz63.ipynb): the engine
+    // WHITENS the data once per step -- G~ = L_Gamma^{-1} G with Gamma = L L^T (one triangular n x n x J product on the matrix
+    // pipe, the update kernel's own code, ~4 GFLOP at C2), y~ = L^{-1} y, Gamma~ = I -- and every kernel behind it runs the
+    // diagonal-Gamma path: D = (1/J) E^T Gamma^{-1} R = (1/J) E~^T R~ (ces/calibrate.py:429/:461/:503), the data metrics
+    // (:434-435), the recomputed gain C_ug (hk C_gg + Gamma)^{-1} (g - y) (:440-441/:472-473) and K (g - y) are all invariant.
+    // (Round 4 kept Gamma^{-1} in the small algebra -- fp64 GEMMs for the Frobenius term and K -- and ran a VALU pass over G for
+    //  the per-particle metrics: 1.23 ms per step against 0.39 for diagonal Gamma.)
+    bool whiten = false;
+    void *d_Wwh = nullptr, *d_Wwh_f = nullptr;   // L_Gamma^{-1} zero padded [rpad][kn], row-major and in the update kernels' fragment-major order
+    void* d_Gw = nullptr;                        // [n][J] the whitened data of the current step (allocated with the first dense problem)
+    const void* gw_src = nullptr;                // ... of this caller array, whitened on gw_stream
+    hipStream_t gw_stream = nullptr;
+    std::vector<double> h_LG, h_Li;              // host copies of L_Gamma and its inverse (cesx_debug_dense reports in the caller's coordinates)
 
     // problem data (fp64) on device
     double *d_y = nullptr, *d_mu = nullptr, *d_ustar = nullptr;
-    double *d_Gamma = nullptr, *d_Ginv = nullptr, *d_gw = nullptr;    // gw = diag(Gamma^{-1}) if diagonal
+    double *d_Gamma = nullptr, *d_gw = nullptr;    // the engine's (diagonal, or whitened: identity) Gamma and gw = diag(Gamma^{-1})
     double *d_Sigma = nullptr, *d_Sinv = nullptr, *d_sw = nullptr;
     // centring shift
     double* d_shift64 = nullptr;   // [p+n]
     void*   d_shiftT = nullptr;    // [p+n] engine dtype
     void*   d_yT = nullptr;        // y in engine dtype
     void*   d_gwT = nullptr;       // diag(Gamma^{-1}) in engine dtype
-    void*   d_GinvT = nullptr;     // dense Gamma^{-1} in engine dtype (n x n)
     // gram: part 0 = U x U blocks (all chol(C) needs), part 1 = the rest
     GramPart gp[2];
     MomLayout ml{};
@@ -342,20 +354,19 @@ struct Engine {
     size_t mom_len = 0;
     double* d_mom = nullptr;
     double* d_sums = nullptr;      // [1+p+n]
+    double* d_sums_w = nullptr;    // [1+p+n] the same with the G part whitened (dense Gamma)
     // dense workspace (fp64)
     double *d_ubar = nullptr, *d_gbar = nullptr, *d_m = nullptr, *d_wdel = nullptr;
     double *d_C = nullptr, *d_L = nullptr, *d_Cug = nullptr, *d_See = nullptr, *d_Srr = nullptr;
     double *d_dg = nullptr;
     double *d_K = nullptr, *d_Kp = nullptr, *d_M = nullptr, *d_P = nullptr, *d_PK = nullptr;
     double *d_t1 = nullptr, *d_t2 = nullptr, *d_t3 = nullptr, *d_t4 = nullptr;   // max(p,n)^2 each
-    double *d_Wh = nullptr;        // chol(Gamma)^{-1} (dense Gamma, spectral rule)
+    double *d_Wh = nullptr;        // L_Gamma^{-1} in fp64 (dense Gamma: the centring sums of a fresh ensemble are whitened with it)
     double *d_Lp = nullptr;        // padded Cholesky workspace (round_up(max(p,n),32))^2
     double *d_lanczos = nullptr;
     int lanczos_steps = 512;       // cap on Krylov steps (min(n, this)); a run that exhausts it unconverged reports CESX_ENOCONV
     double *d_absmax = nullptr;    // [1]
-    double *d_c0 = nullptr;        // [1]
     void   *d_qe = nullptr;        // [J] per-particle q^e (engine dtype)
-    void   *d_wdT = nullptr;       // [n] Ginv (s_g - y) in engine dtype (dense Gamma)
     double *d_colsum_partq = nullptr;
     void   *d_rowc = nullptr;        // [kn][4] {gbar_i, y_i, 1/Gamma_ii, 0} engine dtype (K3 data metrics)
     double *d_metric_part = nullptr; // [blocks][2] per-workgroup {sum q_r^2, sum q_e^2}
@@ -530,7 +541,9 @@ __host__ __device__ inline size_t wd_index(int i, int k, int nkt) {
     const int kt = k >> 4, kk = k & 15, s = kk >> 2, lr = kk & 3, sp = s >> 1, e = s & 1;
     return ((((size_t)y * nkt + kt) * 16 + rb) * 2 + sp) * 128 + (size_t)(lr * 16 + li) * 2 + e;
 }
-int launch_data_metrics(Engine& e, const void* G, hipStream_t s);   // dense Gamma: separate pass
+// dense Gamma: the whitened copy of G this step's kernels read (G itself when Gamma is diagonal); force: whiten again even
+// when the same array was whitened last (the first moments call of a step: its contents may be new)
+const void* whitened_G(Engine& e, const void* G, hipStream_t s, bool force, int* rc);
 int launch_metric_final(Engine& e, const double* mom, bool publish, hipStream_t s);
 MetricFin metric_fin_args(Engine& e, const double* mom, bool publish);     // (publish: takes the next sequence number; mom == nullptr: the engine's own copy d_lag)
 int launch_publish(Engine& e, hipStream_t s);

@@ -154,20 +154,35 @@ int run_update_main(Engine& e, const cesx_step_params& prm, const void* U, const
         opt.s2p = &e.d_scal->sqrt2hk;
     }
     int rc = launch_update(e, e.p, e.d_W, e.ktot, e.d_bias, src, 3, nullptr, nullptr, 0.0, nullptr, nullptr, 0.0,
-                           Unext, nullptr, prm.step_index, e.diag_gamma, opt, s);
+                           Unext, nullptr, prm.step_index, true, opt, s);
     e.last_metric_parts = e.last_update_grid_x;
     return rc;
 }
 
-// data metrics: K3 accumulated them (diagonal Gamma) or a separate pass does (dense Gamma)
+// data metrics: K3 accumulated them while the (whitened) G rows streamed by
 int finish_metrics(Engine& e, const double* mom, const void* G, bool publish, hipStream_t s) {
-    if (!e.diag_gamma) TRY(launch_data_metrics(e, G, s));
+    (void)G;
     return launch_metric_final(e, mom, publish, s);
 }
 
 }  // namespace
 namespace cesx {
 void set_global_error(const std::string& msg) { try { g_create_err = msg; } catch (...) {} }
+
+const void* whitened_G(Engine& e, const void* G, hipStream_t s, bool force, int* rc) {
+    *rc = CESX_OK;
+    if (!e.whiten) return G;
+    if (!force && e.gw_src == G && e.gw_stream == s) return e.d_Gw;
+    // G~ = L_Gamma^{-1} G: one K segment with lower-triangular coefficients (the kernel skips the zero blocks), no bias
+    UpdateSrc src[1] = {{G, e.n, 0, 1}};
+    UpdateOpt opt;
+    opt.wf = e.d_Wwh_f;
+    *rc = launch_update(e, e.n, e.d_Wwh, e.kn, nullptr, src, 1, nullptr, nullptr, 0.0, nullptr, nullptr, 0.0, e.d_Gw,
+                        nullptr, 0, false, opt, s);
+    if (*rc != CESX_OK) return nullptr;
+    e.gw_src = G; e.gw_stream = s;
+    return e.d_Gw;
+}
 }  // namespace cesx
 namespace {
 // the deferred metric finalisation + publication of the last update (Engine::met_deferred), as a kernel of its own
@@ -177,6 +192,10 @@ int flush_metrics(Engine& e) {
     return launch_metric_final(e, nullptr, true, e.met_stream);
 }
 #define FLUSH(e) TRY(flush_metrics(e))
+// dense Gamma: from here on G is the engine's whitened copy of the caller's array (whitened_G)
+#define WHITEN(e, G, stream, force) do { int _wrc; G = whitened_G(e, G, (hipStream_t)(stream), force, &_wrc); if (_wrc != CESX_OK) return _wrc; } while (0)
+// (the U x U launch reads G rows only when p is not a multiple of the MFMA tile: whiten there only then)
+#define WHITEN_UU(e, G, stream) do { if ((e).whiten && (e).p % gram_tile((e).cfg.dtype) != 0) WHITEN(e, G, stream, true); } while (0)
 
 }  // namespace
 
@@ -296,7 +315,7 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
 
 #define DM(ptr, bytes) if ((rc = dmalloc(e, &ptr, (bytes)))) return fail(rc)
     DM(e.d_y, n * 8); DM(e.d_mu, p * 8); DM(e.d_ustar, p * 8);
-    DM(e.d_Gamma, nn * 8); DM(e.d_Ginv, nn * 8); DM(e.d_gw, n * 8); DM(e.d_Wh, nn * 8);
+    DM(e.d_Gamma, nn * 8); DM(e.d_gw, n * 8); DM(e.d_Wh, nn * 8);
     DM(e.d_Sigma, pp * 8); DM(e.d_Sinv, pp * 8); DM(e.d_sw, p * 8);
     DM(e.d_shift64, P * 8);
     {
@@ -304,8 +323,6 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
         DM(t, P * e.esz); e.d_shiftT = t;
         DM(t, n * e.esz); e.d_yT = t;
         DM(t, n * e.esz); e.d_gwT = t;
-        DM(t, nn * e.esz); e.d_GinvT = t;
-        DM(t, n * e.esz); e.d_wdT = t;
         DM(t, n * e.esz); e.d_gbarT = t;
         DM(t, (size_t)e.kn * 4 * e.esz); e.d_rowc = t;
         for (int part = 0; part < 2; ++part) {
@@ -335,7 +352,7 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
     DM(e.d_metric_part, ((size_t)((e.J + 63) / 64) + 8) * 2 * 8);
     DM(e.d_metric_sums, 2 * 8);
     DM(e.d_colsum_part, (size_t)P * e.colsum_slices * 8);
-    DM(e.d_mom, e.mom_len * 8); DM(e.d_sums, (1 + P) * 8);
+    DM(e.d_mom, e.mom_len * 8); DM(e.d_sums, (1 + P) * 8); DM(e.d_sums_w, (1 + P) * 8);
     DM(e.d_ubar, p * 8); DM(e.d_gbar, n * 8); DM(e.d_m, n * 8); DM(e.d_dg, n * 8); DM(e.d_wdel, n * 8);
     DM(e.d_C, pp * 8); DM(e.d_L, (size_t)potrf_ld(p) * potrf_ld(p) * 8); DM(e.d_Cug, pn * 8); DM(e.d_See, nn * 8); DM(e.d_Srr, nn * 8);
     DM(e.d_K, pn * 8); DM(e.d_Kp, pn * 8); DM(e.d_M, pp * 8); DM(e.d_P, pp * 8); DM(e.d_PK, pn * 8);
@@ -348,7 +365,7 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
         DM(e.d_lanczos, ((ms + 1) * n + 4 * ms) * 8);
     }
     DM(e.d_mv, (size_t)6 * mx * 8); DM(e.d_part, 256 * 4 * 8);
-    DM(e.d_scal, sizeof(Scalars)); DM(e.d_absmax, 8); DM(e.d_c0, 8);
+    DM(e.d_scal, sizeof(Scalars)); DM(e.d_absmax, 8);
     DM(e.d_absmax_part, (size_t)update_grid_blocks(e, p) * 8);
     DM(e.d_clk, 4 * 8);
     DM(e.d_cholflag, 128);
@@ -388,8 +405,8 @@ void cesx_destroy(cesx_handle h) {
     if (!h) return;
     Engine& e = *reinterpret_cast<Engine*>(h);
     DeviceGuard dg(e.cfg.device);
-    void* ptrs[] = {e.d_y, e.d_mu, e.d_ustar, e.d_Gamma, e.d_Ginv, e.d_gw, e.d_Wh, e.d_Sigma, e.d_Sinv, e.d_sw,
-                    e.d_shift64, e.d_shiftT, e.d_yT, e.d_gwT, e.d_GinvT, e.d_wdT, e.d_W, e.d_Wf, e.d_Lwork,
+    void* ptrs[] = {e.d_y, e.d_mu, e.d_ustar, e.d_Gamma, e.d_gw, e.d_Wh, e.d_Sigma, e.d_Sinv, e.d_sw,
+                    e.d_shift64, e.d_shiftT, e.d_yT, e.d_gwT, e.d_W, e.d_Wf, e.d_Lwork, e.d_Wwh, e.d_Wwh_f, e.d_Gw, e.d_sums_w,
                     e.d_bias, e.d_Wfwd, e.d_Wfwd_f, e.d_bfwd, e.d_metric_part, e.d_metric_sums,
                     e.d_gbarT, e.d_rowc,
                     e.d_colsum_part, e.d_mom,
@@ -397,7 +414,7 @@ void cesx_destroy(cesx_handle h) {
                     e.gp[1].d_type_hdr, e.gp[1].d_rows, e.gp[1].d_wblk, e.gp[1].d_blk_rc, e.gp[1].d_row_own, e.gp[1].d_slabs, e.gp[1].d_rowsum_part, e.d_sums, e.d_ubar, e.d_gbar, e.d_m, e.d_dg,
                     e.d_wdel, e.d_C, e.d_L, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_Kp, e.d_M, e.d_P, e.d_PK,
                     e.d_t1, e.d_t2, e.d_t3, e.d_t4, e.d_Lp, e.d_lanczos, e.d_mv, e.d_part, e.d_scal, e.d_absmax,
-                    e.d_c0, e.d_absmax_part, e.d_clk, e.d_cholflag, e.d_lag, e.d_A64, e.d_b64, e.d_lvec, e.d_Wq, e.d_ticket};
+                    e.d_absmax_part, e.d_clk, e.d_cholflag, e.d_lag, e.d_A64, e.d_b64, e.d_lvec, e.d_Wq, e.d_ticket};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     for (int w = 0; w < 2; ++w)
@@ -427,14 +444,39 @@ int cesx_set_problem(cesx_handle h, const double* y, const double* Gamma, const 
     if (!host_chol(n, Gamma, L)) { e.err = "Gamma is not symmetric positive definite"; return CESX_ENOTPD; }
     host_tri_inverse(n, L, Li);
     host_spd_inverse(n, Li, inv);
-    e.diag_gamma = is_diagonal(n, Gamma);
-    std::vector<double> gw(n);
+    // Dense Gamma: the engine works in whitened data coordinates (cesx_internal.h, Engine::whiten) -- y~ = L^{-1} y,
+    // Gamma~ = I, and G~ = L^{-1} G formed once per step by the update kernel's own code (whitened_G below)
+    e.whiten = !is_diagonal(n, Gamma);
+    e.gw_src = nullptr;
+    std::vector<double> gw(n), yi(y, y + n), Gi(Gamma, Gamma + (size_t)n * n);
     for (int i = 0; i < n; ++i) gw[i] = 1.0 / Gamma[(size_t)i * n + i];
-    TRY(upload(e, e.d_y, y, n * 8)); TRY(upload(e, e.d_Gamma, Gamma, (size_t)n * n * 8));
-    TRY(upload(e, e.d_Ginv, inv.data(), (size_t)n * n * 8)); TRY(upload(e, e.d_gw, gw.data(), n * 8));
+    if (e.whiten) {
+        e.h_LG = L; e.h_Li = Li;
+        for (int i = 0; i < n; ++i) {
+            double t = 0.0;
+            for (int k = 0; k <= i; ++k) t += Li[(size_t)i * n + k] * y[k];
+            yi[i] = t;
+            gw[i] = 1.0;
+            for (int k = 0; k < n; ++k) Gi[(size_t)i * n + k] = i == k ? 1.0 : 0.0;
+        }
+        // L^{-1} (lower triangular), zero padded to the update kernels' [rpad][kn] layout, row-major and fragment-major
+        const size_t len = (size_t)e.rpad * e.kn;
+        std::vector<double> rm(len, 0.0), fm(len, 0.0);
+        const int nkt = e.kn / 16;
+        for (int i = 0; i < n; ++i)
+            for (int k = 0; k <= i; ++k) {
+                const double v = Li[(size_t)i * n + k];
+                rm[(size_t)i * e.kn + k] = v;
+                fm[e.cfg.dtype == CESX_F32 ? wf_index(i, k, nkt) : wd_index(i, k, nkt)] = v;
+            }
+        if (!e.d_Wwh) { char* t; int rc; if ((rc = dmalloc(e, &t, len * e.esz))) return rc; e.d_Wwh = t; if ((rc = dmalloc(e, &t, len * e.esz))) return rc; e.d_Wwh_f = t; }
+        TRY(upload_T(e, e.d_Wwh, rm.data(), len)); TRY(upload_T(e, e.d_Wwh_f, fm.data(), len));
+        if (!e.d_Gw) CESX_HIP(hipMalloc(&e.d_Gw, (size_t)n * (size_t)e.J * e.esz));
+    }
+    TRY(upload(e, e.d_y, yi.data(), n * 8)); TRY(upload(e, e.d_Gamma, Gi.data(), (size_t)n * n * 8));
+    TRY(upload(e, e.d_gw, gw.data(), n * 8));
     TRY(upload(e, e.d_Wh, Li.data(), (size_t)n * n * 8));
-    TRY(upload_T(e, e.d_yT, y, n)); TRY(upload_T(e, e.d_gwT, gw.data(), n));
-    TRY(upload_T(e, e.d_GinvT, inv.data(), (size_t)n * n));
+    TRY(upload_T(e, e.d_yT, yi.data(), n)); TRY(upload_T(e, e.d_gwT, gw.data(), n));
     if (!host_chol(p, Sigma, L)) { e.err = "Sigma is not symmetric positive definite"; return CESX_ENOTPD; }
     host_tri_inverse(p, L, Li);
     host_spd_inverse(p, Li, inv);
@@ -492,6 +534,7 @@ int cesx_moments_uu(cesx_handle h, const void* U, const void* G, double* mom, vo
     SET_DEVICE(e);
     FLUSH(e);
     ++e.prof_step;
+    WHITEN_UU(e, G, stream);
     return launch_gram(e, 0, U, G, mom, (hipStream_t)stream);
 }
 
@@ -512,6 +555,7 @@ int cesx_chol_async(cesx_handle h, int update, const double* mom, void* stream) 
 static int moments_uu_handover(Engine& e, const void* U, const void* G, double* mom, hipStream_t s) {
     ++e.prof_step;
     if (e.met_deferred && e.met_stream != s) FLUSH(e);
+    WHITEN_UU(e, G, s);
     TRY(launch_gram(e, 0, U, G, mom, s, true));
     if (e.met_deferred) {
         MetricFin f = metric_fin_args(e, nullptr, true);
@@ -534,6 +578,7 @@ int cesx_moments_uu_handover(cesx_handle h, const void* U, const void* G, double
     if (s == e.side || !e.ext_events) {      // nothing to hand over / plain markers: the caller's own ordering applies
         FLUSH(e);
         ++e.prof_step;
+        WHITEN_UU(e, G, s);
         TRY(launch_gram(e, 0, U, G, mom, s));
         if (s != e.side) {
             CESX_HIP(hipEventRecord(e.ev_a, s));
@@ -554,6 +599,7 @@ int cesx_moments_uu_chol(cesx_handle h, int update, const void* U, const void* G
     if (s == e.side || !e.ext_events) {
         FLUSH(e);
         ++e.prof_step;
+        WHITEN_UU(e, G, s);
         TRY(launch_gram(e, 0, U, G, mom, s));
         return launch_chol_async(e, update, mom, s);
     }
@@ -570,6 +616,7 @@ int cesx_moments_rest(cesx_handle h, const void* U, const void* G, double* mom, 
     FLUSH(e);
     // (the reduce kernel of this launch also copies this shard's data-metric sums of the PREVIOUS
     //  apply to the tail of the buffer: they ride on this step's all-reduce)
+    WHITEN(e, G, stream, true);
     return launch_gram(e, 1, U, G, mom, (hipStream_t)stream);
 }
 
@@ -580,6 +627,7 @@ int cesx_moments_rest_lineal(cesx_handle h, double* mom, void* stream) {
     if (!e.problem_set) { e.err = "cesx_set_problem has not been called"; return CESX_ESTATE; }
     if (!e.shift_valid) { e.err = "no centring shift: call cesx_colsum + cesx_set_shift (or cesx_step with recenter) first"; return CESX_ESTATE; }
     if (!e.fwd_set) { e.err = "cesx_moments_rest_lineal: cesx_forward_set_lineal has not been called"; return CESX_ESTATE; }
+    if (e.whiten) { e.err = "cesx_moments_rest_lineal: dense Gamma (the engine works on whitened data: take cesx_moments_rest)"; return CESX_EUNSUPPORTED; }
     SET_DEVICE(e);
     FLUSH(e);
     return launch_moments_lineal(e, mom, (hipStream_t)stream);
@@ -599,12 +647,13 @@ int cesx_apply_drift(cesx_handle h, const cesx_step_params* prm, const double* m
     SET_DEVICE(e);
     FLUSH(e);
     hipStream_t s = (hipStream_t)stream;
+    WHITEN(e, G, s, false);
     TRY(launch_dense(e, *prm, mom, 1, s));
     UpdateSrc src[2] = {{U, e.p, 0, 0}, {G, e.n, 0, 0}};
     UpdateOpt opt;
     opt.wf = e.d_Wf;
     TRY(launch_update(e, e.p, e.d_W, e.kp + e.kn, e.d_bias, src, 2, nullptr, nullptr, 0.0, nullptr, nullptr, 0.0,
-                      Unext, e.d_absmax_part, prm->step_index, e.diag_gamma, opt, s));
+                      Unext, e.d_absmax_part, prm->step_index, true, opt, s));
     e.last_metric_parts = e.last_update_grid_x;
     const int nparts = e.last_update_grid;
     TRY(finish_metrics(e, mom, G, false, s));
@@ -646,13 +695,14 @@ int cesx_apply(cesx_handle h, const cesx_step_params* prm, const double* mom, co
     SET_DEVICE(e);
     FLUSH(e);
     hipStream_t s = (hipStream_t)stream;
-    e.last_apply = Engine::LastApply{true, *prm, mom, U, G, xi, Unext, s, e.moments_calls};
+    e.last_apply = Engine::LastApply{true, *prm, mom, U, G, xi, Unext, s, e.moments_calls};     // (the caller's G: a re-run whitens it again if need be)
+    WHITEN(e, G, s, false);
     // (whether the update launch qualifies for the LDS-DMA kernel is known here: the hk-free K2 has no other consumer)
     TRY(launch_dense(e, *prm, mom, 0, s, update2_qualifies(e, U, G, xi, Unext)));
     TRY(run_update_main(e, *prm, U, G, xi, Unext, s));
     // (Moving this last small kernel to the side stream was tried: the event record + wait pair costs
     //  as much GPU idle time as the 7 us kernel itself.)
-    if (e.met_defer_ok && e.ext_events && e.overlap_chol && e.diag_gamma) {
+    if (e.met_defer_ok && e.ext_events && e.overlap_chol) {
         // the finalisation rides on the next step's U x U reduce launch (cesx_moments_uu_chol / _handover on this
         // stream) -- no one-workgroup kernel (7 us) between this update and the next Gram launch; anything else flushes it
         e.met_deferred = true; e.met_stream = s;      // (reads the engine's own d_lag, not `mom`)
@@ -992,7 +1042,17 @@ int cesx_debug_dense(cesx_handle h, double* ubar, double* gbar, double* C, doubl
     CESX_HIP(hipDeviceSynchronize());
     const size_t p = e.p, n = e.n;
     if (ubar) CESX_HIP(hipMemcpy(ubar, e.d_ubar, p * 8, hipMemcpyDeviceToHost));
-    if (gbar) CESX_HIP(hipMemcpy(gbar, e.d_gbar, n * 8, hipMemcpyDeviceToHost));
+    if (gbar) {
+        CESX_HIP(hipMemcpy(gbar, e.d_gbar, n * 8, hipMemcpyDeviceToHost));
+        if (e.whiten) {          // the engine holds the mean of the WHITENED data: gbar = L_Gamma gbar~
+            std::vector<double> t(gbar, gbar + n);
+            for (size_t i = 0; i < n; ++i) {
+                double a = 0.0;
+                for (size_t k = 0; k <= i; ++k) a += e.h_LG[i * n + k] * t[k];
+                gbar[i] = a;
+            }
+        }
+    }
     if (C) CESX_HIP(hipMemcpy(C, e.d_C, p * p * 8, hipMemcpyDeviceToHost));
     if (L) {
         const size_t ld = potrf_ld(e.p);
@@ -1000,7 +1060,18 @@ int cesx_debug_dense(cesx_handle h, double* ubar, double* gbar, double* C, doubl
         for (size_t i = 0; i < p; ++i)
             for (size_t j = i + 1; j < p; ++j) L[i * p + j] = 0.0;     // the factor's upper triangle is not stored
     }
-    if (K) CESX_HIP(hipMemcpy(K, e.d_K, p * n * 8, hipMemcpyDeviceToHost));
+    if (K) {
+        CESX_HIP(hipMemcpy(K, e.d_K, p * n * 8, hipMemcpyDeviceToHost));
+        if (e.whiten) {          // K~ = C_ug~ = C_ug L^{-T}; the reference's gain C_ug Gamma^{-1} = K~ L^{-1}
+            std::vector<double> t(K, K + p * n);
+            for (size_t i = 0; i < p; ++i)
+                for (size_t j = 0; j < n; ++j) {
+                    double a = 0.0;
+                    for (size_t k = j; k < n; ++k) a += t[i * n + k] * e.h_Li[k * n + j];
+                    K[i * n + j] = a;
+                }
+        }
+    }
     if (M) CESX_HIP(hipMemcpy(M, e.d_M, p * p * 8, hipMemcpyDeviceToHost));
     return CESX_OK;
 }

@@ -188,25 +188,6 @@ __device__ __forceinline__ void st_agent(double* ptr, double v) {
     __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// part[blk*4 + 2] = sum A .* B   (dense-Gamma Frobenius term)
-__global__ __launch_bounds__(DT)
-void dot_kernel(const double* __restrict__ A, const double* __restrict__ B, long long len,
-                double* __restrict__ part) {
-    __shared__ double red[DT / 64];
-    double s = 0.0;
-    for (long long i = (long long)blockIdx.x * DT + threadIdx.x; i < len; i += (long long)gridDim.x * DT)
-        s += A[i] * B[i];
-    s = dblock_sum(s, red);
-    if (threadIdx.x == 0) part[blockIdx.x * 4 + 2] = s;
-}
-
-// out[i][j] = A[i][j] * w[j]
-__global__ void scale_cols_kernel(int rows, int cols, const double* __restrict__ A,
-                                  const double* __restrict__ w, double* __restrict__ out) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < (long long)rows * cols) out[idx] = A[idx] * w[idx % cols];
-}
-
 // C(m x n) = alpha * A(m x k) * B(k x n) with arbitrary element strides, fp64, on the matrix pipe: one wave per
 // 16 x 16 block of C (a workgroup = 2 x 2 blocks), v_mfma_f64_16x16x4_f64 with operands read straight from global
 // memory -- the matrices of K2 are a few hundred KB and L2-resident, a lane's A operand is A[i][k + lane/16], its B
@@ -1081,6 +1062,9 @@ void tail_aldi_kernel(MomView mv, cesx_step_params prm, const double* shift, con
                       double* __restrict__ dg, double* __restrict__ Cug, double* __restrict__ See,
                       double* __restrict__ Srr, double* __restrict__ K, double* part, Scalars* sc,
                       double* __restrict__ lag, double* mvs, int mx, const double* __restrict__ sw,
+                      // Sinv != nullptr: a dense prior covariance -- row i of M = C Sigma^{-1} is C_i . Sigma^{-1} (the C row goes
+                      // through LDS, a thread walks its column of Sigma^{-1}: p fp64 fmas and as many L2-resident loads)
+                      const double* __restrict__ Sinv,
                       const double* __restrict__ mu,
                       // self_u: no U-only centring ran for these moments (the factorisation formed C while it loaded S_aa):
                       // C, M, ubar and the trace / bias sums are formed here
@@ -1118,6 +1102,7 @@ void tail_aldi_kernel(MomView mv, cesx_step_params prm, const double* shift, con
     }
     const double invN = 1.0 / N, invdiv = 1.0 / (N - 1.0), al0 = (p + 1.0) / N;
     __shared__ double xch[4][DT];
+    __shared__ double crow[DT];
     const int wv = tid >> 6;
     // One row per workgroup and one column pass (p, n <= 256: the benchmark's shapes): the bulk stores of the row -- the
     // image entries, the fp64 copies of C_ug / K (and C / M) -- go out BEHIND the ticket; only what the last workgroup reads
@@ -1130,15 +1115,26 @@ void tail_aldi_kernel(MomView mv, cesx_step_params prm, const double* shift, con
         for (int c0 = 0; c0 < cmax; c0 += DT) {
             const int c = c0 + tid;
             double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+            double c_ = 0.0, suu = 0.0;
+            if (c < p) c_ = cov_entry(Saa[(size_t)i * p + c], sa[i], sa[c], invN, invdiv, i == c, &suu);
+            if (Sinv != nullptr && c0 == 0) {          // (p <= DT on this path: the whole row of C is in this column pass)
+                __syncthreads();
+                crow[tid] = c_;
+                __syncthreads();
+            }
             if (c < p) {
-                double suu;
-                const double c_ = cov_entry(Saa[(size_t)i * p + c], sa[i], sa[c], invN, invdiv, i == c, &suu);
-                const double m_ = c_ * sw[c];
+                double m_;
+                if (Sinv == nullptr) m_ = c_ * sw[c];
+                else {
+                    m_ = 0.0;
+                    for (int k = 0; k < p; ++k) m_ = fma(crow[k], Sinv[(size_t)k * p + c], m_);
+                }
                 if (self_u && i == c) st_agent(mvs + (size_t)5 * mx + i, suu);
                 if (i == c) st_agent(mvs + (size_t)4 * mx + i, al0 - m_);      // (the diagonal entry gets 1/hk from the last workgroup)
                 if (defer) { d_c = c_; d_m = m_; }
                 else {
-                    if (self_u) { Cm[(size_t)i * p + c] = c_; Mm[(size_t)i * p + c] = m_; }
+                    if (self_u) Cm[(size_t)i * p + c] = c_;
+                    if (self_u || Sinv != nullptr) Mm[(size_t)i * p + c] = m_;
                     if (i != c) wq[wf_index(i, kp + c, nkt)] = (float)(-m_);
                 }
                 v2 = m_ * mu[c];
@@ -1226,7 +1222,8 @@ void tail_aldi_kernel(MomView mv, cesx_step_params prm, const double* shift, con
     if (defer && (int)blockIdx.x < p) {
         const int i = blockIdx.x, c = tid;
         if (c < p) {
-            if (self_u) { Cm[(size_t)i * p + c] = d_c; Mm[(size_t)i * p + c] = d_m; }
+            if (self_u) Cm[(size_t)i * p + c] = d_c;
+            if (self_u || Sinv != nullptr) Mm[(size_t)i * p + c] = d_m;
             if (i != c) wq[wf_index(i, kp + c, nkt)] = (float)(-d_m);
         }
         if (c < n) {
@@ -1684,7 +1681,7 @@ static int assemble(Engine& e, hipStream_t s, int mode, int ktot, double sw) {
     const long long len = (long long)e.rpad * ktot;
     hipLaunchKernelGGL(assemble_kernel<T>, g1(len), dim3(256), 0, s, mode, e.p, e.n, e.kp, e.kn, e.rpad, ktot,
                        sw, e.d_scal, e.d_M, e.d_K, e.d_L, potrf_ld(e.p), e.d_P, e.d_PK, e.d_mv, mx, e.d_ubar, e.d_gbar,
-                       e.d_y, e.diag_gamma ? e.d_gw : (const double*)nullptr, (T*)e.d_W, (T*)e.d_bias,
+                       e.d_y, (const double*)e.d_gw, (T*)e.d_W, (T*)e.d_bias,
                        (T*)e.d_shiftT, e.d_shift64, (T*)e.d_rowc, (T*)e.d_gbarT,
                        (float*)e.d_Wf);
     CESX_HIP(hipGetLastError());
@@ -1726,7 +1723,7 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
     const int what = !early ? 3 : e.chol_fused_center ? (3 | 4) : 2;
     // hk kept out of the coefficient matrix (cesx_internal.h, Engine::d_Wq): the side stream wrote L, a I - M, M mu, M ubar
     // for this factorisation, ONE launch adds the rest and the update kernel takes hk at run time
-    const bool img_ok = e.hkfree_ok && e.d_Wq != nullptr && f32 && e.update_v2 && e.diag_gamma && e.diag_sigma && potrf_ld(p) <= 256;
+    const bool img_ok = e.hkfree_ok && e.d_Wq != nullptr && f32 && e.update_v2 && potrf_ld(p) <= 256;
     const bool hkfree = upd2_ok && fused_finish && prm.time_step == CESX_TS_DEFAULT && img_ok && (early ? e.side_img : true);
     e.last_hkfree = false;
     if (hkfree) {
@@ -1741,14 +1738,15 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
             if ((rc = potrf_reg_any(e, s, p, potrf_ld(p), mv.mom + e.ml.Saa(), e.d_L, p, 0, nullptr, cen, nullptr, 0, (float*)e.d_Wq))) return rc;
         } else if (!early) {
             hipLaunchKernelGGL(center_kernel, dim3(NPB), dim3(DT), 0, s, mv, e.d_shift64, e.d_y, e.d_ustar,
-                               (const double*)e.d_gw, (const double*)e.d_sw, unbiased, 1, e.d_ubar, e.d_gbar,
+                               (const double*)e.d_gw, e.diag_sigma ? (const double*)e.d_sw : (const double*)nullptr, unbiased, 1, e.d_ubar, e.d_gbar,
                                e.d_m, e.d_dg, e.d_C, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_M, e.d_part, e.d_scal, (double*)nullptr);
             CESX_HIP(hipGetLastError());
             if ((rc = potrf(e, s, p, e.d_C, e.d_L, nullptr, nullptr, 0, (float*)e.d_Wq))) return rc;
         } else if (!polled) CESX_HIP(hipStreamWaitEvent(s, e.ev_b, 0));
         hipLaunchKernelGGL(tail_aldi_kernel, dim3(NPB), dim3(DT), 0, s, mv, prm, (const double*)e.d_shift64, (const double*)e.d_y,
                            (const double*)e.d_gw, e.d_gbar, e.d_m, e.d_dg, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_part, e.d_scal,
-                           e.d_lag, e.d_mv, mx, (const double*)e.d_sw, (const double*)e.d_mu, self_u, (const double*)e.d_ustar,
+                           e.d_lag, e.d_mv, mx, (const double*)e.d_sw, e.diag_sigma ? (const double*)nullptr : (const double*)e.d_Sinv,
+                           (const double*)e.d_mu, self_u, (const double*)e.d_ustar,
                            e.d_ubar, e.d_C, e.d_M, (float*)e.d_Wq, e.ktot / 16, e.kp,
                            e.kn, (float*)e.d_bias, (float*)e.d_shiftT, e.d_shift64, (float*)e.d_rowc, (float*)e.d_gbarT,
                            e.d_ticket, polled ? (const unsigned long long*)e.d_cholflag : (const unsigned long long*)nullptr,
@@ -1769,10 +1767,10 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
     // loads (no queue-level acquire stands between that stream's kernels and it).  Only where nothing else sits between the two and reads those results (ALDI, default time
     // step, diagonal Gamma / Sigma, one device), and only for the one-kernel factorisation that signals.
     const bool can_poll = fused_finish && prm.time_step == CESX_TS_DEFAULT && early && !e.chol_fused_center && e.poll_join_ok &&
-        e.chol_signals && e.diag_gamma && e.diag_sigma && e.J == e.Jg && s != e.side && stream_below_side(e, s);
+        e.chol_signals && e.diag_sigma && e.J == e.Jg && s != e.side && stream_below_side(e, s);
     const bool polled = can_poll;
     hipLaunchKernelGGL(center_kernel, dim3(NPB), dim3(DT), 0, s, mv, e.d_shift64, e.d_y, e.d_ustar,
-                       e.diag_gamma ? e.d_gw : (const double*)nullptr,
+                       (const double*)e.d_gw,
                        e.diag_sigma ? e.d_sw : (const double*)nullptr, unbiased, what, e.d_ubar, e.d_gbar,
                        e.d_m, e.d_dg, e.d_C, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_M, e.d_part, e.d_scal, e.d_lag,
                        polled ? (const unsigned long long*)e.d_cholflag : (const unsigned long long*)nullptr,
@@ -1791,25 +1789,11 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
         e.evb_waited_stream = s;
         e.chol_inflight = false;
     }
-    if (!e.diag_gamma) {
-        // Frobenius term <Ginv Srr Ginv, See>, and K = C_ug Ginv
-        if ((rc = gemm(e, s, n, n, n, 1.0, e.d_Ginv, n, 1, e.d_Srr, n, 1, e.d_t1))) return rc;
-        if ((rc = gemm(e, s, n, n, n, 1.0, e.d_t1, n, 1, e.d_Ginv, n, 1, e.d_t2))) return rc;
-        hipLaunchKernelGGL(dot_kernel, dim3(NPB), dim3(DT), 0, s, e.d_t2, e.d_See, (long long)n * n, e.d_part);
-        CESX_HIP(hipGetLastError());
-        if ((rc = gemm(e, s, p, n, n, 1.0, e.d_Cug, n, 1, e.d_Ginv, n, 1, e.d_K))) return rc;
-    }
     if (!e.diag_sigma)
         if ((rc = gemm(e, s, p, p, p, 1.0, e.d_C, p, 1, e.d_Sinv, p, 1, e.d_M))) return rc;
     if (prm.time_step == CESX_TS_SPECTRAL && prm.update != CESX_UPDATE_ALDI_CONSTANT) {
-        // B = Wh See Wh^T, symmetric PSD, same non-zero spectrum as D (times N)
-        if (e.diag_gamma) {
-            hipLaunchKernelGGL(whiten_diag_kernel, g1((long long)n * n), dim3(256), 0, s, n, e.d_See, e.d_gw, e.d_t3);
-        } else {
-            // Wh = chol(Gamma)^{-1} (lower): B = Wh See Wh^T
-            if ((rc = gemm(e, s, n, n, n, 1.0, e.d_Wh, n, 1, e.d_See, n, 1, e.d_t1))) return rc;
-            if ((rc = gemm(e, s, n, n, n, 1.0, e.d_t1, n, 1, e.d_Wh, 1, n, e.d_t3))) return rc;
-        }
+        // B = Gamma^{-1/2} See Gamma^{-1/2} (Gamma diagonal, or whitened away), symmetric PSD, same non-zero spectrum as D (times N)
+        hipLaunchKernelGGL(whiten_diag_kernel, g1((long long)n * n), dim3(256), 0, s, n, e.d_See, e.d_gw, e.d_t3);
         const int msteps = n < e.lanczos_steps ? n : e.lanczos_steps;      // <= LANCZOS_MAX (engine.hip)
         double* lz = e.d_lanczos + (size_t)(msteps + 1) * n;               // [alpha | beta | 2 x scratch]
         hipLaunchKernelGGL(lanczos_kernel, dim3(1), dim3(DT), 0, s, n, e.d_t3, mom, msteps, e.d_lanczos,
@@ -1824,7 +1808,7 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
             hipLaunchKernelGGL((finish_aldi_kernel<T, POLLED>), dim3(nwb + nvb), dim3(DT), 0, s, mv, prm, (const double*)e.d_part, e.d_scal, nwb,
                                e.kp, e.kn, e.rpad, e.ktot, (const double*)e.d_M, (const double*)e.d_K, (const double*)e.d_L, potrf_ld(p),
                                (const double*)e.d_y, (const double*)e.d_gbar, (const double*)e.d_mu,
-                               (const double*)e.d_ubar, e.diag_gamma ? (const double*)e.d_gw : (const double*)nullptr, mx, e.d_mv, (T*)e.d_W,
+                               (const double*)e.d_ubar, (const double*)e.d_gw, mx, e.d_mv, (T*)e.d_W,
                                (T*)e.d_bias, (T*)e.d_shiftT, e.d_shift64, (T*)e.d_rowc, (T*)e.d_gbarT, (float*)e.d_Wf,
                                (const unsigned long long*)(e.d_cholflag + 1), (unsigned long long)e.chol_seq);
         };
@@ -1896,7 +1880,7 @@ int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s, b
     // the hk-free update's share of the side stream (cesx_internal.h, Engine::d_Wq): whether the step takes that path is
     // decided in cesx_apply (time-step rule, alignment of the ensembles); storing L into the image costs the factorisation ~1 us
     const bool img = e.hkfree_ok && e.d_Wq != nullptr && e.cfg.dtype == CESX_F32 && update == CESX_UPDATE_ALDI && e.update_v2 &&
-        e.diag_gamma && e.diag_sigma && potrf_ld(p) <= 256;
+        potrf_ld(p) <= 256;
     e.chol_fused_center = potrf_ld(p) <= 256 && (e.fuse_center_ok || (e.fuse_center_auto && img && e.gram_b_short));
     e.side_img = false;
     if (e.chol_fused_center) {
@@ -1921,7 +1905,7 @@ int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s, b
     float* wq = e.side_img ? (float*)e.d_Wq : (float*)nullptr;
     // (few workgroups -> 1024 threads each: 8 x 256 threads took 25 us for the 65 k elements of C, latency bound)
     hipLaunchKernelGGL(center_kernel, dim3(std::min(NPB, e.center_u_wgs)), dim3(e.center_u_wgs < NPB ? 1024 : DT), 0, e.side, mv, e.d_shift64, e.d_y, e.d_ustar,
-                       e.diag_gamma ? e.d_gw : (const double*)nullptr,
+                       (const double*)e.d_gw,
                        e.diag_sigma ? e.d_sw : (const double*)nullptr, unbiased, 1, e.d_ubar, e.d_gbar,
                        e.d_m, e.d_dg, e.d_C, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_M, e.d_part, e.d_scal, (double*)nullptr);
     CESX_HIP(hipGetLastError());

@@ -66,8 +66,8 @@ constexpr int G2_SLOT_IMM = 60 * 1024;                   // ... of launches whos
 #define G2_OPT 15   // 2 = row sums only where the type reports them, 4 = scalar DMA addressing, 8 = a block's partial sums stored
                     // as soon as its last MFMA of the slice is issued (no barrier behind the last tile), 16 = those stores non-temporal
 #endif
-#ifndef G2_OPQ      // dev A/B: which wave-uniform tests are re-evaluated at their use (1: DMA issue, 2: shift pass, 4: tile body)
-#define G2_OPQ 7
+#ifndef G2_OPQ      // dev A/B: which wave-uniform tests are re-evaluated at their use (1: DMA issue, 2: shift pass; tile body: 4 more, 8 nb, 16 shift_at)
+#define G2_OPQ 11
 #endif
 #ifdef G2_CLOCKS
 __device__ long long g_gram2_clk[4096 * 4];
@@ -364,7 +364,7 @@ void gram2_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __r
     auto tile = [&](auto curc, int k) {
         constexpr int CUR = decltype(curc)::value;
         const int more = opaque_if(G2_OPQ & 4, nt - 1 - k);    // > 0: a next tile exists
-        const int nbo = opaque_if(G2_OPQ & 4, nb), sat = opaque_if(G2_OPQ & 4, shift_at);
+        const int nbo = opaque_if(G2_OPQ & 8, nb), sat = opaque_if(G2_OPQ & 16, shift_at);
         const std::integral_constant<int, CUR> cur;
         const std::integral_constant<int, CUR ^ 1> nxt;
         // the next tile's pieces: behind this wave's first MFMA group (the matrix pipe restarts right behind the barrier,

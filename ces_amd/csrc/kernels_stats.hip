@@ -2,10 +2,8 @@
 //   rowsum_kernel      sum_j x_ij: the centring shift of a fresh ensemble
 //                      (U0.mean / Geval.mean, ces/calibrate.py:423, :427).  Inside a
 //                      run the first moments come fused out of the Gram kernel.
-//   particle_stats_dense_kernel   dense-Gamma data metrics
-//                      q^e_j = e_j^T Gamma^{-1} e_j (:434/:466), q^r_j = r_j^T Gamma^{-1} r_j
-//                      (:435/:467).  With diagonal Gamma (every reference example) the
-//                      update kernel K3 accumulates them while the G rows stream by.
+//   (the data metrics q^e_j = e_j^T Gamma^{-1} e_j (:434/:466), q^r_j = r_j^T Gamma^{-1} r_j (:435/:467) are
+//    accumulated by the update kernel K3 while the G rows stream by; a dense Gamma is whitened away first)
 //   metric_final_kernel  fixed-order fp64 sum of the per-workgroup partials.
 #include "cesx_internal.h"
 #include <cstddef>
@@ -66,67 +64,17 @@ __global__ void set_shift_kernel(const double* __restrict__ sums, int rows, T* _
     shift64[row] = (double)v;
 }
 
-// Dense Gamma: q^e_j = e_j^T Ginv e_j (e_j = g_j - gbar) with a 64-particle tile of E
-// staged in LDS; q^r_j = q^e_j + 2 wd^T e_j + c0 with d = gbar - y, wd = Ginv d, c0 = d^T wd
-// (one quadratic form per particle instead of two).  VALU kernel: the general
-// path, not the headline one (every reference example uses Gamma = gamma^2 I,
-// examples/scripts/darcy-flow.py:33-34).
-template <typename T>
-__global__ __launch_bounds__(ST_THREADS)
-void particle_stats_dense_kernel(const T* __restrict__ G, const T* __restrict__ shift_g,
-                                 const T* __restrict__ Ginv, const T* __restrict__ wd, const double* __restrict__ c0p, int n,
-                                 long long J, double* __restrict__ part) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* B = reinterpret_cast<T*>(smem);                 // [n][64]
-    T* acc = B + (size_t)n * 64;                       // [4][64] partial q per row group
-    T* lin = acc + 4 * 64;                             // [4][64] partial wd^T b
-    __shared__ double red[ST_THREADS / 64];
-    const int tj = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const long long j = (long long)blockIdx.x * 64 + tj;
-    for (int i = grp; i < n; i += 4) B[(size_t)i * 64 + tj] = j < J ? G[(size_t)i * J + j] - shift_g[i] : (T)0;
-    __syncthreads();
-    T q = 0, l = 0;
-    for (int i = grp; i < n; i += 4) {
-        const T* gi = Ginv + (size_t)i * n;
-        T t = 0;
-        for (int k = 0; k < n; ++k) t += gi[k] * B[(size_t)k * 64 + tj];
-        const T bi = B[(size_t)i * 64 + tj];
-        q += bi * t;
-        l += wd[i] * bi;
-    }
-    acc[grp * 64 + tj] = q;
-    lin[grp * 64 + tj] = l;
-    __syncthreads();
-    T qe = 0, qr = 0;
-    if (grp == 0) {
-        qe = acc[tj] + acc[64 + tj] + acc[128 + tj] + acc[192 + tj];
-        const T li = lin[tj] + lin[64 + tj] + lin[128 + tj] + lin[192 + tj];
-        qr = qe + 2 * li + (T)(*c0p);
-        if (j >= J) { qe = 0; qr = 0; }
-    }
-    const double a = block_sum((double)qr * (double)qr, red);
-    const double b2 = block_sum((double)qe * (double)qe, red);
-    if (threadIdx.x == 0) {
-        part[(size_t)blockIdx.x * 2 + 0] = a;
-        part[(size_t)blockIdx.x * 2 + 1] = b2;
-    }
-}
-
-// d = gbar - y, wd = Ginv d, c0 = d^T wd  (dense Gamma only; one block)
-template <typename T>
-__global__ void dense_shift_terms_kernel(const double* __restrict__ shift_g, const double* __restrict__ y,
-                                         const double* __restrict__ Ginv, int n, T* __restrict__ wd,
-                                         double* __restrict__ c0) {
-    __shared__ double red[ST_THREADS / 64];
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        double t = 0.0;
-        for (int k = 0; k < n; ++k) t += Ginv[(size_t)i * n + k] * (shift_g[k] - y[k]);
-        wd[i] = (T)t;
-        acc += t * (shift_g[i] - y[i]);
-    }
-    const double tot = block_sum(acc, red);
-    if (threadIdx.x == 0) *c0 = tot;
+// Dense Gamma (Engine::whiten): the G part of the centring sums of a fresh ensemble in the whitened coordinates the
+// engine works in, sums_g <- L_Gamma^{-1} sums_g (the sum is linear: the caller summed the RAW rows, cesx_colsum)
+__global__ void whiten_sums_kernel(const double* __restrict__ Li, int p, int n, const double* __restrict__ sums,
+                                   double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 1 + p + n) return;
+    if (i < 1 + p) { out[i] = sums[i]; return; }
+    const int r = i - 1 - p;
+    double t = 0.0;
+    for (int k = 0; k <= r; ++k) t += Li[(size_t)r * n + k] * sums[1 + p + k];
+    out[i] = t;
 }
 
 // sums[0..1] = sum over workgroups of {q_r^2, q_e^2}; scalars: this shard's contribution
@@ -152,6 +100,11 @@ int launch_colsum(Engine& e, const void* U, const void* G, double* sums, hipStre
 
 int launch_set_shift(Engine& e, const double* sums, hipStream_t s) {
     const int P = e.p + e.n;
+    if (e.whiten) {
+        hipLaunchKernelGGL(whiten_sums_kernel, dim3((1 + P + 255) / 256), dim3(256), 0, s, (const double*)e.d_Wh, e.p, e.n, sums, e.d_sums_w);
+        CESX_HIP(hipGetLastError());
+        sums = e.d_sums_w;
+    }
     if (e.cfg.dtype == CESX_F32)
         hipLaunchKernelGGL(set_shift_kernel<float>, dim3((P + 255) / 256), dim3(256), 0, s, sums, P,
                            (float*)e.d_shiftT, e.d_shift64);
@@ -161,28 +114,6 @@ int launch_set_shift(Engine& e, const double* sums, hipStream_t s) {
     CESX_HIP(hipGetLastError());
     e.shift_valid = true;
     return CESX_OK;
-}
-
-template <typename T>
-static int data_metrics_t(Engine& e, const void* G, hipStream_t s) {
-    const int n = e.n;
-    const int blocks = (int)((e.J + 63) / 64);
-    hipLaunchKernelGGL(dense_shift_terms_kernel<T>, dim3(1), dim3(ST_THREADS), 0, s, e.d_gbar, e.d_y, e.d_Ginv, n,
-                       (T*)e.d_wdT, e.d_c0);
-    CESX_HIP(hipGetLastError());
-    const size_t lds = ((size_t)n * 64 + 8 * 64) * sizeof(T);
-    if (lds > 150 * 1024) { e.err = "dense-Gamma data metrics: n_obs too large for the LDS tile"; return CESX_EINVAL; }
-    auto kern = particle_stats_dense_kernel<T>;
-    CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(ST_THREADS), lds, s, (const T*)G, (const T*)e.d_gbarT,
-                       (const T*)e.d_GinvT, (const T*)e.d_wdT, (const double*)e.d_c0, n, (long long)e.J,
-                       e.d_metric_part);
-    CESX_HIP(hipGetLastError());
-    return CESX_OK;
-}
-// dense Gamma only: fills e.d_metric_part with one entry per 64 particles
-int launch_data_metrics(Engine& e, const void* G, hipStream_t s) {
-    return e.cfg.dtype == CESX_F32 ? data_metrics_t<float>(e, G, s) : data_metrics_t<double>(e, G, s);
 }
 
 // Results of a step go straight into pinned host memory; the sequence number is written
@@ -207,7 +138,7 @@ int launch_publish(Engine& e, hipStream_t s) {
 
 // publish = true: this is the last kernel of the step and also writes the results to the host
 MetricFin metric_fin_args(Engine& e, const double* mom, bool publish) {
-    const int nparts = e.diag_gamma ? e.last_metric_parts : (int)((e.J + 63) / 64);
+    const int nparts = e.last_metric_parts;
     // mom == nullptr: {N, lag0, lag1} as K2's centring kernel copied them into the engine's d_lag
     return MetricFin{e.d_metric_part, nparts, mom ? mom : e.d_lag, mom ? e.ml.tail() : (size_t)1, e.d_metric_sums, e.d_scal,
                      publish ? e.h_scal_dev : (Scalars*)nullptr, publish ? ++e.seq : 0ull, 0.0};

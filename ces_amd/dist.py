@@ -227,6 +227,7 @@ class ShardedUpdate:
         (CESX_LINEAL_FAST=0 switches it off)."""
         return (getattr(model, "engine_lineal", False) and not getattr(model, "flag_noise", False)
                 and hasattr(self.engine, "moments_rest_lineal") and hasattr(self.engine, "moments_uu_chol")
+                and not getattr(self.engine, "dense_gamma", False)       # (whitened data: the full Gram)
                 and self.world == 1 and not self._force_collectives and not self.single_allreduce
                 and os.environ.get("CESX_LINEAL_FAST", "1") != "0")
 

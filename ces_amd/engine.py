@@ -526,6 +526,8 @@ class Engine:
             self._check(self.lib.cesx_set_problem(self._h, _dptr(y), _dptr(Gamma), _dptr(mu), _dptr(sigma),
                                                   _dptr(ustar)))
         self._problem = tuple(a.copy() for a in key)
+        # a dense Gamma: the engine whitens the data once per step and runs the diagonal path (include/cesx.h)
+        self.dense_gamma = bool(np.count_nonzero(Gamma - np.diag(np.diagonal(Gamma))))
 
     # -- single device step ------------------------------------------------
     def step(self, prm, U, G, xi=None, out=None, recenter=True):

@@ -136,7 +136,12 @@ int  cesx_abi_version(void);
    Gamma of eks_update* (ces/calibrate.py:418).  All HOST pointers to fp64
    arrays: y (n), Gamma (n x n, SPD), mu (p), Sigma (p x p, SPD), ustar (p).
    Factorises Gamma and Sigma once (the reference re-solves them every step,
-   ces/calibrate.py:429, :443, :485). */
+   ces/calibrate.py:429, :443, :485).
+   A DENSE Gamma = L L^T (the reference's pde examples use a sample covariance) is whitened away: once per step the
+   engine forms G~ = L^{-1} G (one triangular n x n x J product on the matrix pipe, into an engine-owned n x J buffer
+   allocated here) and works with y~ = L^{-1} y, Gamma~ = I -- D = (1/J) E^T Gamma^{-1} R, the data metrics, the gains
+   and K (g - y) are invariant (ces/calibrate.py:429-441, :461-473), and every kernel behind it is the diagonal-Gamma
+   one.  G_dev itself is never written.  cesx_debug_dense reports gbar and K in the caller's coordinates. */
 int cesx_set_problem(cesx_handle h, const double* y, const double* Gamma,
                      const double* mu, const double* Sigma, const double* ustar);
 
@@ -266,7 +271,8 @@ int cesx_allreduce_max(cesx_handle h, double* buf_dev, size_t count, void* strea
    c = A s_u + b - s_g -- two n x p x p fp64 products instead of the second Gram launch.  mom_dev must hold the
    complete (summed over devices) head; the rest is written, the lagged data-metric sums included.  Valid when
    the G_dev later passed to cesx_apply is what cesx_forward_apply produced from the same U_dev (K3 and the
-   per-particle data metrics still read that G).  The chained device-resident loops of ces_amd use it
+   per-particle data metrics still read that G).  Not with a dense Gamma (CESX_EUNSUPPORTED: the engine's moments are
+   those of the whitened data; take cesx_moments_rest).  The chained device-resident loops of ces_amd use it
    (e2e only; the benchmark's timed step always runs the full Gram). */
 int cesx_moments_rest_lineal(cesx_handle h, double* mom_dev, void* stream);
 

@@ -61,6 +61,25 @@ def traffic_per_step(summary):
     return per_step
 
 
+def mfma_util_per_kernel(summary):
+    """MFMA utilisation of each kernel from the counter passes: SQ_VALU_MFMA_BUSY_CYCLES (summed over the chip's SIMDs) /
+    (GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 x 1024 SIMDs), totals over all launches of the kernel in their passes
+    normalised per step like the traffic (a step's two Gram launches count together)."""
+    steps = {}
+    for k3 in ("update2_kernel", "update3_kernel", "metric_final_kernel"):
+        if k3 in summary and "SQ_VALU_MFMA_BUSY_CYCLES" in summary[k3] and "GRBM_GUI_ACTIVE" in summary[k3]:
+            steps = {c: summary[k3][c]["launches"] for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE")}
+            break
+    out = {}
+    for kern, c in summary.items():
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c and steps:
+            busy = c["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_launch"] * c["SQ_VALU_MFMA_BUSY_CYCLES"]["launches"] / steps["SQ_VALU_MFMA_BUSY_CYCLES"]
+            act = c["GRBM_GUI_ACTIVE"]["mean_per_launch"] * c["GRBM_GUI_ACTIVE"]["launches"] / steps["GRBM_GUI_ACTIVE"]
+            if busy > 0 and act > 0:
+                out[kern] = round(busy / (act / 8.0 * 1024.0), 4)
+    return out
+
+
 def main():
     if sys.argv[1] == "--retraffic":          # python tools/prof_summary.py --retraffic TAG[:CONFIG]  (from profiles/TAG_pmc_summary.json)
         tag, _, config = sys.argv[2].partition(":")
@@ -73,6 +92,10 @@ def main():
         per_step["gram_kernel"] = per_step.get("gram2_kernel", 0) + per_step.get("gram_kernel", 0)
         per_step["_source"] = tag + "_pmc_summary.json"
         per_step["_src_sha16"] = summary.get("_src_sha16") or kernel_sources_sha()
+        mu = mfma_util_per_kernel(summary)
+        if "gram2_kernel" in mu:
+            mu["gram_kernel"] = mu["gram2_kernel"]
+        per_step["_mfma_util"] = mu
         traffic[config] = per_step
         json.dump(traffic, open(tpath, "w"), indent=1, sort_keys=True)
         print({k: v for k, v in per_step.items() if isinstance(v, int) and v > 1e6})
@@ -136,6 +159,10 @@ def main():
             #  update2_kernel (fp32) / update3_kernel (fp64) when the LDS-DMA kernels ran)
             per_step["_source"] = tag + "_pmc_summary.json"
             per_step["_src_sha16"] = kernel_sources_sha()      # (run right behind the profile passes, on the tree they ran from)
+            mu = mfma_util_per_kernel(summary)
+            if "gram2_kernel" in mu:
+                mu["gram_kernel"] = mu["gram2_kernel"]
+            per_step["_mfma_util"] = mu
             traffic[config] = per_step
         json.dump(traffic, open(tpath, "w"), indent=1, sort_keys=True)
     print("wrote", sorted(os.listdir(out)))
