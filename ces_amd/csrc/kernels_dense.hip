@@ -1056,6 +1056,7 @@ void finish_aldi_kernel(MomView mv, cesx_step_params prm, const double* part, Sc
 // Nothing of the step is written when the poll runs out (the update launch checks the same fault word).
 // Launched with NPB workgroups of DT threads.
 // ---------------------------------------------------------------------------
+template <bool DSIG>        // DSIG: a dense prior covariance (its own instantiation: the benchmark's keeps its registers -- 121 VGPRs, 4 spilled SGPRs)
 __global__ __launch_bounds__(DT)
 void tail_aldi_kernel(MomView mv, cesx_step_params prm, const double* shift, const double* __restrict__ y,
                       const double* __restrict__ gw, double* __restrict__ gbar, double* __restrict__ mvec,
@@ -1102,7 +1103,7 @@ void tail_aldi_kernel(MomView mv, cesx_step_params prm, const double* shift, con
     }
     const double invN = 1.0 / N, invdiv = 1.0 / (N - 1.0), al0 = (p + 1.0) / N;
     __shared__ double xch[4][DT];
-    __shared__ double crow[DT];
+    __shared__ double crow[DSIG ? DT : 1];
     const int wv = tid >> 6;
     // One row per workgroup and one column pass (p, n <= 256: the benchmark's shapes): the bulk stores of the row -- the
     // image entries, the fp64 copies of C_ug / K (and C / M) -- go out BEHIND the ticket; only what the last workgroup reads
@@ -1117,24 +1118,36 @@ void tail_aldi_kernel(MomView mv, cesx_step_params prm, const double* shift, con
             double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
             double c_ = 0.0, suu = 0.0;
             if (c < p) c_ = cov_entry(Saa[(size_t)i * p + c], sa[i], sa[c], invN, invdiv, i == c, &suu);
-            if (Sinv != nullptr && c0 == 0) {          // (p <= DT on this path: the whole row of C is in this column pass)
+            if (DSIG && c0 == 0) {          // (p <= DT on this path: the whole row of C is in this column pass)
                 __syncthreads();
                 crow[tid] = c_;
                 __syncthreads();
             }
             if (c < p) {
                 double m_;
-                if (Sinv == nullptr) m_ = c_ * sw[c];
+                if (!DSIG) m_ = c_ * sw[c];
                 else {
-                    m_ = 0.0;
-                    for (int k = 0; k < p; ++k) m_ = fma(crow[k], Sinv[(size_t)k * p + c], m_);
+                    // (32 loads of the column in flight at a time: walked one dependent load after the other the column cost the
+                    //  launch 100 us -- 256 round trips to L2)
+                    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                    for (int k0 = 0; k0 < p; k0 += 32) {
+                        double v[32];
+#pragma unroll
+                        for (int u = 0; u < 32; ++u) v[u] = k0 + u < p ? Sinv[(size_t)(k0 + u) * p + c] : 0.0;
+#pragma unroll
+                        for (int u = 0; u < 32; u += 4) {
+                            a0 = fma(crow[k0 + u], v[u], a0); a1 = fma(crow[k0 + u + 1], v[u + 1], a1);
+                            a2 = fma(crow[k0 + u + 2], v[u + 2], a2); a3 = fma(crow[k0 + u + 3], v[u + 3], a3);
+                        }
+                    }
+                    m_ = (a0 + a1) + (a2 + a3);
                 }
                 if (self_u && i == c) st_agent(mvs + (size_t)5 * mx + i, suu);
                 if (i == c) st_agent(mvs + (size_t)4 * mx + i, al0 - m_);      // (the diagonal entry gets 1/hk from the last workgroup)
                 if (defer) { d_c = c_; d_m = m_; }
                 else {
                     if (self_u) Cm[(size_t)i * p + c] = c_;
-                    if (self_u || Sinv != nullptr) Mm[(size_t)i * p + c] = m_;
+                    if (self_u || DSIG) Mm[(size_t)i * p + c] = m_;
                     if (i != c) wq[wf_index(i, kp + c, nkt)] = (float)(-m_);
                 }
                 v2 = m_ * mu[c];
@@ -1223,7 +1236,7 @@ void tail_aldi_kernel(MomView mv, cesx_step_params prm, const double* shift, con
         const int i = blockIdx.x, c = tid;
         if (c < p) {
             if (self_u) Cm[(size_t)i * p + c] = d_c;
-            if (self_u || Sinv != nullptr) Mm[(size_t)i * p + c] = d_m;
+            if (self_u || DSIG) Mm[(size_t)i * p + c] = d_m;
             if (i != c) wq[wf_index(i, kp + c, nkt)] = (float)(-d_m);
         }
         if (c < n) {
@@ -1669,10 +1682,8 @@ static int spd_inverse(Engine& e, hipStream_t s, int n, const double* A, double*
     if ((rc = potrf(e, s, n, A, e.d_t1))) return rc;
     if ((rc = trsm_right_lt(e, s, n, np, nullptr, 0, e.d_t1, np, e.d_t2, np))) return rc;
     // X is upper triangular: X[i][k] = 0 for k < i; columns >= n of the rows < n are zero
-    hipLaunchKernelGGL(gemm_kernel, dim3((n + 31) / 32, (n + 31) / 32), dim3(DT), 0, s, n, n, n, 1.0,
-                       e.d_t2, (long long)np, 1LL, e.d_t2, 1LL, (long long)np, Ainv, n, (const double*)nullptr);
-    CESX_HIP(hipGetLastError());
-    return CESX_OK;
+    // (K split over the waves of a workgroup for the sizes of K2: 21 -> 7 us at n = 256)
+    return gemm(e, s, n, n, n, 1.0, e.d_t2, (long long)np, 1LL, e.d_t2, 1LL, (long long)np, Ainv);
 }
 
 template <typename T>
@@ -1743,7 +1754,8 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
             CESX_HIP(hipGetLastError());
             if ((rc = potrf(e, s, p, e.d_C, e.d_L, nullptr, nullptr, 0, (float*)e.d_Wq))) return rc;
         } else if (!polled) CESX_HIP(hipStreamWaitEvent(s, e.ev_b, 0));
-        hipLaunchKernelGGL(tail_aldi_kernel, dim3(NPB), dim3(DT), 0, s, mv, prm, (const double*)e.d_shift64, (const double*)e.d_y,
+        auto tail_kern = e.diag_sigma ? tail_aldi_kernel<false> : tail_aldi_kernel<true>;
+        hipLaunchKernelGGL(tail_kern, dim3(NPB), dim3(DT), 0, s, mv, prm, (const double*)e.d_shift64, (const double*)e.d_y,
                            (const double*)e.d_gw, e.d_gbar, e.d_m, e.d_dg, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_part, e.d_scal,
                            e.d_lag, e.d_mv, mx, (const double*)e.d_sw, e.diag_sigma ? (const double*)nullptr : (const double*)e.d_Sinv,
                            (const double*)e.d_mu, self_u, (const double*)e.d_ustar,

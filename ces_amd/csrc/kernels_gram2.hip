@@ -66,8 +66,18 @@ constexpr int G2_SLOT_IMM = 60 * 1024;                   // ... of launches whos
 #define G2_OPT 15   // 2 = row sums only where the type reports them, 4 = scalar DMA addressing, 8 = a block's partial sums stored
                     // as soon as its last MFMA of the slice is issued (no barrier behind the last tile), 16 = those stores non-temporal
 #endif
-#ifndef G2_OPQ      // dev A/B: which wave-uniform tests are re-evaluated at their use (1: DMA issue, 2: shift pass; tile body: 4 more, 8 nb, 16 shift_at)
-#define G2_OPQ 11
+// Which wave-uniform tests of the tile loop are re-evaluated at their use instead of being kept as hoisted lane masks (see
+// `opaque` in the kernel): 1 DMA issue, 2 shift pass; tile body: 4 `more`, 8 the block count, 16 the shift position.
+// Measured with tools/gram2_bench.hip (round 5, two boxes, C2 / C5 shapes; us first + second launch):
+//   f32:  round-4 code 49.4 + 120.8 | 11: 48.5 + 119.9 | 31: 48.8 + 113.9, 48.7 + 112.2      -> 31
+//   f64:  round-4 code 166 + 547    | 31: 172 + 549    | 8: 157 + 504 | 11: 157 + 505         -> 11
+// (f64 holds 8 blocks per wave: re-evaluating `more` and the shift position per block costs more scalar work than it frees
+//  registers; every instantiation is free of scratch and SGPR spills with either setting, tests/test_isa_audit.py)
+#ifndef G2_OPQ_F32
+#define G2_OPQ_F32 31
+#endif
+#ifndef G2_OPQ_F64
+#define G2_OPQ_F64 11
 #endif
 #ifdef G2_CLOCKS
 __device__ long long g_gram2_clk[4096 * 4];
@@ -91,6 +101,7 @@ void gram2_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __r
     constexpr int PPB = TILE / 8;                        // DMA pieces per block row and tile: 4 / 2
     constexpr int BLKB = TILE * G2_ROWB;                 // bytes of a block row in a slot: 4 KiB / 2 KiB
     constexpr bool F32 = sizeof(T) == 4;
+    constexpr int G2_OPQ = F32 ? G2_OPQ_F32 : G2_OPQ_F64;
     constexpr int GSTR = 512;                            // bytes between immediate k-groups inside a piece (f32: g1, f64: g)
     constexpr int NG0 = NGROUP / 2;                      // k-groups folded into the lane address (f32: g0 = 0, 1; f64: none)
     static_assert(NG0 == (F32 ? 2 : 1), "cell maps of the header");

@@ -585,7 +585,7 @@ def test_update_kernels_v1_v2_match(eng_mod, monkeypatch, update, shape, dtype, 
     assert outs[1][1:] == pytest.approx(outs[0][1:], rel=tol)
 
 
-def test_comm_overlap_stream_path_matches(eng_mod):
+def test_comm_overlap_stream_path_matches(eng_mod, monkeypatch):
     """ShardedUpdate with the head all-reduce + chol(C) on a second stream (the multi-GPU path,
     forced here on one rank) gives bit-identical steps to the in-order path."""
     from ces_amd.dist import ShardedUpdate

@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 @pytest.fixture(scope="module")
 def table():
     import isa_audit
-    t = isa_audit.collect(["kernels_gram2.hip", "kernels_update2.hip", "kernels_update3.hip"])
+    t = isa_audit.collect(["kernels_gram2.hip", "kernels_update2.hip", "kernels_update3.hip", "kernels_dense.hip"])
     names = isa_audit.demangle(sorted(t))
     return {re.sub(r"\(.*", "", names[k]).replace("cesx::", "").replace("void ", ""): v for k, v in t.items()}
 
@@ -44,3 +44,11 @@ def test_update_kernels_keep_their_loops_free_of_scratch(table):
     # k-tile loop still has (round 5 count; the Philox instantiations, which nothing on the hot path launches, have 36 - 40)
     assert table["update2_kernel<false, true>"]["spill_in_loop"] <= 6
     assert table["update2_kernel<false, true>"]["ScratchSize [bytes/lane]"] == 0
+
+
+def test_the_tail_launch_of_the_benchmark_keeps_its_registers(table):
+    """tail_aldi_kernel<false> sits between the second reduce and K3 on the benchmark's critical path (12 - 16 us, latency
+    bound).  Round 5's first dense-Sigma version of it shared the instantiation: 157 VGPRs, 98 spilled SGPRs, occupancy 3 --
+    and the step lost 4 us before anybody looked.  The dense path is its own instantiation now."""
+    r = table["tail_aldi_kernel<false>"]
+    assert r["Occupancy [waves/SIMD]"] == 4 and r["SGPRs Spill"] <= 4 and r["ScratchSize [bytes/lane]"] == 0
