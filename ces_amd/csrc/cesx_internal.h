@@ -363,8 +363,7 @@ struct Engine {
     double *d_t1 = nullptr, *d_t2 = nullptr, *d_t3 = nullptr, *d_t4 = nullptr;   // max(p,n)^2 each
     double *d_Wh = nullptr;        // L_Gamma^{-1} in fp64 (dense Gamma: the centring sums of a fresh ensemble are whitened with it)
     double *d_Lp = nullptr;        // padded Cholesky workspace (round_up(max(p,n),32))^2
-    double *d_lanczos = nullptr;
-    int lanczos_steps = 512;       // cap on Krylov steps (min(n, this)); a run that exhausts it unconverged reports CESX_ENOCONV
+    double *d_spec = nullptr;      // spectral rule: {sum 2^-k log N_k, 2^-k, degenerate flag, pad} + 2 x ceil(n/16)^2 partial sums of squares
     double *d_absmax = nullptr;    // [1]
     void   *d_qe = nullptr;        // [J] per-particle q^e (engine dtype)
     double *d_colsum_partq = nullptr;

@@ -359,10 +359,9 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
     { const size_t np_ = (size_t)(mx + 31) / 32 * 32; DM(e.d_Lp, np_ * np_ * 8); }
     if (potrf_ld(mx) > 256) DM(e.d_Lwork, (size_t)potrf_ld(mx) * potrf_ld(mx) * 8);
     DM(e.d_t1, mm * 8); DM(e.d_t2, mm * 8); DM(e.d_t3, mm * 8); DM(e.d_t4, mm * 8);
-    {
-        if (const char* lv = std::getenv("CESX_LANCZOS_STEPS")) e.lanczos_steps = std::max(2, std::min(512, std::atoi(lv)));
-        const size_t ms = (size_t)std::min(n, e.lanczos_steps);
-        DM(e.d_lanczos, ((ms + 1) * n + 4 * ms) * 8);
+    {   // spectral rule (kernels_dense.hip, spec_square_kernel): {log accumulator, weight, flag, pad} + 2 x per-workgroup partial sums
+        const size_t nb16 = ((size_t)n + 15) / 16;
+        DM(e.d_spec, (4 + 2 * nb16 * nb16) * 8);
     }
     DM(e.d_mv, (size_t)6 * mx * 8); DM(e.d_part, 256 * 4 * 8);
     DM(e.d_scal, sizeof(Scalars)); DM(e.d_absmax, 8);
@@ -413,7 +412,7 @@ void cesx_destroy(cesx_handle h) {
                     e.gp[0].d_type_hdr, e.gp[0].d_rows, e.gp[0].d_wblk, e.gp[0].d_blk_rc, e.gp[0].d_row_own, e.gp[0].d_slabs, e.gp[0].d_rowsum_part,
                     e.gp[1].d_type_hdr, e.gp[1].d_rows, e.gp[1].d_wblk, e.gp[1].d_blk_rc, e.gp[1].d_row_own, e.gp[1].d_slabs, e.gp[1].d_rowsum_part, e.d_sums, e.d_ubar, e.d_gbar, e.d_m, e.d_dg,
                     e.d_wdel, e.d_C, e.d_L, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_Kp, e.d_M, e.d_P, e.d_PK,
-                    e.d_t1, e.d_t2, e.d_t3, e.d_t4, e.d_Lp, e.d_lanczos, e.d_mv, e.d_part, e.d_scal, e.d_absmax,
+                    e.d_t1, e.d_t2, e.d_t3, e.d_t4, e.d_Lp, e.d_spec, e.d_mv, e.d_part, e.d_scal, e.d_absmax,
                     e.d_absmax_part, e.d_clk, e.d_cholflag, e.d_lag, e.d_A64, e.d_b64, e.d_lvec, e.d_Wq, e.d_ticket};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);

@@ -249,7 +249,9 @@ void gemm_kernel(int m, int n, int k, double alpha, const double* __restrict__ A
 // order.  For the small n x p x p products of K2 (moments of a linear map, EKS gain, dense Gamma / Sigma).
 __global__ __launch_bounds__(DT)
 void gemm_splitk_kernel(int m, int n, int k, double alpha, const double* __restrict__ A, long long a0, long long a1,
-                        const double* __restrict__ B, long long b0, long long b1, double* Cm, int ldc) {
+                        const double* __restrict__ B, long long b0, long long b1, double* Cm, int ldc,
+                        const double* __restrict__ scale = nullptr) {      // scale != nullptr: alpha times (*scale)^2 (a device scalar)
+    if (scale != nullptr) alpha *= scale[0] * scale[0];
     __shared__ double part[3][4][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16;
@@ -616,157 +618,121 @@ __global__ void select_kernel(long long len, const Scalars* __restrict__ sc, con
 }
 
 // ---------------------------------------------------------------------------
-// lambda_max of the symmetric PSD matrix B = Wh (See / N) Wh^T (Wh = Gamma^{-1/2}
-// factor, so eig(B) = eig(Gamma^{-1} See / N) = eig(D) \ {0}):
-// Lanczos with full re-orthogonalisation (m steps, one workgroup) followed by
-// bisection on the tridiagonal matrix.
+// lambda_max of the symmetric PSD matrix B = Gamma^{-1/2} (See / N) Gamma^{-1/2} (Gamma diagonal, or whitened away), which has
+// the non-zero spectrum of D = (1/J) E^T Gamma^{-1} E (ces/calibrate.py:250 takes eigvals of the J x J matrix)
+// -- by REPEATED SQUARING, on the matrix pipe, with a two-sided bound instead of a convergence test:
+//     M_0 = B,   M_{k+1} = (M_k / N_k)^2,   N_k = ||M_k||_F
+//     log lambda_1(M_0) = sum_{k < K} 2^-k log N_k + 2^-K log lambda_1(M_K),      N_K / sqrt(n) <= lambda_1(M_K) <= N_K
+// so with lambda_1(M_K) ~ N_K n^(-1/4) the relative error is at most 2^-K (ln n) / 4: 3e-11 at K = 36 for n = 16 384, whatever
+// the spectrum looks like -- clustered leading eigenvalues (a Marchenko-Pastur bulk at C2: neighbours half a percent apart)
+// included.  Rounds 1-4 ran a one-workgroup Lanczos iteration with full re-orthogonalisation and a residual stop criterion:
+// rigorous too, but on such a spectrum it walks the whole Krylov space -- 256 steps of 8 - 20 us, 1.8 ms of a 2.2-ms step --
+// and it can fail to converge under its step cap.  36 products of n x n x n on v_mfma_f64_16x16x4_f64 (~8 us each at n = 256):
+// 0.3 ms, every CU busy, no failure mode.  Rounding: a squaring perturbs lambda_1(M_k) by O(n eps) relatively, weighted 2^-k in
+// the sum: O(n eps) in all.  Deterministic: each product leaves the sum of squares of its output as per-workgroup partials,
+// the next one adds them in a fixed order.
 // ---------------------------------------------------------------------------
-// largest eigenvalue of tridiag(alpha[0..m), beta[0..m-1)) by 64-way multisection on Sturm counts:
-// called by the 64 lanes of ONE wave; lane l counts the eigenvalues below the l-th interior point of
-// the bracket, the bracket shrinks 65-fold per round (10 rounds reach the last bit).  Same value on
-// every lane.
-__device__ double tridiag_max_eig(const double* alpha, const double* beta, int m) {
-    const int lane = threadIdx.x & 63;
-    double lo = alpha[0], hi = alpha[0];
-    for (int i = 0; i < m; ++i) {
-        const double bl = i > 0 ? fabs(beta[i - 1]) : 0.0, br = i + 1 < m ? fabs(beta[i]) : 0.0;
-        lo = fmin(lo, alpha[i] - bl - br);
-        hi = fmax(hi, alpha[i] + bl + br);
-    }
-    for (int it = 0; it < 16; ++it) {
-        const double w = hi - lo;
-        const double mid = lo + w * ((double)(lane + 1) / 65.0);
-        int cnt = 0;                                   // number of eigenvalues < mid
-        double d = 1.0;
-        for (int i = 0; i < m; ++i) {
-            const double b2 = i > 0 ? beta[i - 1] * beta[i - 1] : 0.0;
-            d = alpha[i] - mid - (i > 0 ? b2 / d : 0.0);
-            if (d == 0.0) d = 1e-300;
-            if (d < 0.0) ++cnt;
-        }
-        // lanes whose point lies above the whole spectrum (the counts are monotone in the lane index)
-        const unsigned long long above = __ballot(cnt >= m);
-        const int first = above ? __ffsll((long long)above) - 1 : 64;     // first lane with mid > lambda_max
-        const double nlo = first > 0 ? __shfl(mid, first - 1, 64) : lo;
-        const double nhi = first < 64 ? __shfl(mid, first, 64) : hi;
-        if (!(nhi - nlo < w)) break;                   // the bracket no longer shrinks: last bit reached
-        lo = nlo; hi = nhi;
-    }
-    return 0.5 * (lo + hi);
+constexpr int SPEC_SQUARINGS = 36;
+
+// acc[0] = sum_k 2^-k log N_k so far, acc[1] = 2^-k of the next term.  parts: npart partial sums of squares of M_k (fixed order).
+__device__ __forceinline__ double spec_norm2(const double* __restrict__ parts, int npart, double* red) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < npart; i += DT) s += parts[i];
+    return dblock_sum(s, red);          // (same value on every thread, the same in every workgroup)
 }
 
-// |last component| of the unit eigenvector of tridiag(alpha, beta) (order m) for the eigenvalue th:
-// two steps of inverse iteration with the shift nudged off the eigenvalue (LU of the shifted
-// tridiagonal without pivoting is safe above the spectrum: all pivots are negative).  d, x: scratch
-// of m doubles each.  One thread.  With full re-orthogonalisation the residual of the Ritz pair is
-// exactly  || B v - th v || = beta_m * |s_m|  (Paige), beta_m = norm of the next Lanczos vector.
-__device__ double tridiag_last_component(const double* alpha, const double* beta, int m, double th,
-                                         double* d, double* x) {
-    const double shift = th + 4e-16 * fabs(th) + 1e-300;
-    for (int i = 0; i < m; ++i) {
-        d[i] = alpha[i] - shift - (i > 0 ? beta[i - 1] * beta[i - 1] / d[i - 1] : 0.0);
-        if (d[i] == 0.0) d[i] = -1e-300;
-        x[i] = 1.0;
-    }
-    for (int it = 0; it < 3; ++it) {
-        // (T - shift) z = x: forward elimination with the stored pivots, back substitution
-        for (int i = 1; i < m; ++i) x[i] -= beta[i - 1] / d[i - 1] * x[i - 1];
-        x[m - 1] /= d[m - 1];
-        for (int i = m - 2; i >= 0; --i) x[i] = (x[i] - beta[i] * x[i + 1]) / d[i];
-        double nrm = 0.0;
-        for (int i = 0; i < m; ++i) nrm = fmax(nrm, fabs(x[i]));
-        double n2 = 0.0;
-        for (int i = 0; i < m; ++i) { x[i] /= nrm; n2 += x[i] * x[i]; }
-        n2 = sqrt(n2);
-        for (int i = 0; i < m; ++i) x[i] /= n2;
-    }
-    return fabs(x[m - 1]);
-}
-
-constexpr int LANCZOS_MAX = 512;     // Krylov steps (cq[] below, and the workspace engine.hip allocates)
-
+// M_out = (M_in / N)^2 with N^2 = sum(parts_in); parts_out[workgroup] = sum of squares of this workgroup's 16 x 16 block of M_out.
+// One 16 x 16 block per workgroup, K split over its four waves (the structure of gemm_splitk_kernel).
 __global__ __launch_bounds__(DT)
-void lanczos_kernel(int n, const double* __restrict__ B, const double* __restrict__ divp, int msteps,
-                    double* __restrict__ V, double* __restrict__ alpha, double* __restrict__ beta,
-                    double* __restrict__ scratch, Scalars* __restrict__ sc) {
+void spec_square_kernel(int n, const double* __restrict__ Min, const double* __restrict__ parts_in, int npart,
+                        double* __restrict__ Mout, double* __restrict__ parts_out, double* __restrict__ acc) {
     __shared__ double red[DT / 64];
-    __shared__ double s_val;
-    __shared__ double s_done;
-    __shared__ double cq[LANCZOS_MAX];         // projections of one re-orthogonalisation pass
-    const int tid = threadIdx.x;
-    if (tid == 0) s_done = 0.0;
-    // start vector: normalised ones + small ramp (generic direction)
-    double nrm = 0.0;
-    for (int i = tid; i < n; i += DT) { const double v = 1.0 + 0.01 * i; V[i] = v; nrm += v * v; }
-    nrm = dblock_sum(nrm, red);
-    for (int i = tid; i < n; i += DT) V[i] /= sqrt(nrm);
-    __syncthreads();
-    int m = 0;
-    bool converged = false;
-    for (int k = 0; k < msteps; ++k) {
-        double* vk = V + (size_t)k * n;
-        double* w = V + (size_t)(k + 1) * n;
-        // w = B vk  (B is symmetric: column i of B read along rows, so that consecutive threads
-        // read consecutive addresses)
-        for (int i = tid; i < n; i += DT) {
-            double s = 0.0;
-#pragma unroll 8
-            for (int c = 0; c < n; ++c) s += B[(size_t)c * n + i] * vk[c];
-            w[i] = s;
-        }
-        __syncthreads();
-        // full re-orthogonalisation against v_0..v_k, classical Gram-Schmidt done twice: all k+1
-        // projections of a pass first (one wave per dot product), then one update of w
-        for (int pass = 0; pass < 2; ++pass) {
-            const int lane = tid & 63, wv = tid >> 6;
-            for (int q = wv; q <= k; q += DT / 64) {
-                const double* vq = V + (size_t)q * n;
-                double d = 0.0;
-                for (int i = lane; i < n; i += 64) d += w[i] * vq[i];
+    __shared__ double part[3][4][64];
+    const double N2 = spec_norm2(parts_in, npart, red);
+    const double inv = (N2 > 0.0 && N2 < 1e300) ? 1.0 / N2 : 0.0;          // (B = 0: everything stays zero, lambda = 0)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        if (N2 > 0.0 && N2 < 1e300) acc[0] += acc[1] * 0.5 * log(N2);
+        else acc[2] = 1.0;                                                    // degenerate: reported as lambda = 0
+        acc[1] *= 0.5;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16;
+    const int i = r0 + (lane & 15), j = c0 + (lane & 15), kk = lane >> 4;
+    const bool iok = i < n, jok = j < n;
+    const double* pa = Min + (size_t)(iok ? i : 0) * n;          // row i of M (symmetric: column j = row j)
+    const double* pb = Min + (size_t)(jok ? j : 0) * n;
+    const int kper = ((n + 3) / 4 + 3) / 4 * 4;
+    const int kbeg = wave * kper, kend = kbeg + kper < n ? kbeg + kper : n;
+    constexpr int UN = 8;
+    gemm_d4_t a4 = {0.0, 0.0, 0.0, 0.0};
+    double av[2][UN], bv[2][UN];
+    auto load = [&](int buf, int k0) {
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o, 64);
-                if (lane == 0) cq[q] = d;
-            }
-            __syncthreads();
-            if (pass == 0 && tid == 0) alpha[k] = cq[k];        // alpha_k = (B v_k) . v_k
-            for (int i = tid; i < n; i += DT) {
-                double acc = 0.0;
-                for (int q = 0; q <= k; ++q) acc += cq[q] * V[(size_t)q * n + i];
-                w[i] -= acc;
-            }
-            __syncthreads();
+        for (int u = 0; u < UN; ++u) {
+            const int kc = k0 + 4 * u + kk;
+            const bool kok = kc < kend;
+            av[buf][u] = (iok && kok) ? pa[kc] : 0.0;
+            bv[buf][u] = (jok && kok) ? pb[kc] : 0.0;
         }
-        double b = 0.0;
-        for (int i = tid; i < n; i += DT) b += w[i] * w[i];
-        b = sqrt(dblock_sum(b, red));
-        m = k + 1;
-        if (tid == 0) beta[k] = b;
-        // invariant subspace (or the whole space, m = n): the Ritz values are exact eigenvalues
-        if (!(b > 1e-14 * fabs(alpha[0]) + 1e-300) || m == n) { converged = true; break; }
-        for (int i = tid; i < n; i += DT) w[i] /= b;
-        __syncthreads();
-        // Convergence test every 4 steps (the largest Ritz value converges long before the Krylov
-        // space is exhausted): residual of the Ritz pair  beta_m |s_m|  <=  1e-10 theta
-        if ((k & 3) == 3 || k + 1 == msteps) {
-            if (tid < 64) {
-                const double th = tridiag_max_eig(alpha, beta, m);
-                if (tid == 0) {
-                    const double sm = tridiag_last_component(alpha, beta, m, th, scratch, scratch + msteps);
-                    s_done = (b * sm <= 1e-10 * fabs(th)) ? 1.0 : 0.0;
-                }
-            }
-            __syncthreads();
-            if (s_done != 0.0) { converged = true; break; }
-            __syncthreads();
+    };
+    if (kbeg < kend) load(0, kbeg);
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += 4 * UN) {
+        if (k0 + 4 * UN < kend) {
+            if (buf == 0) load(1, k0 + 4 * UN); else load(0, k0 + 4 * UN);
         }
+        if (buf == 0) {
+#pragma unroll
+            for (int u = 0; u < UN; ++u) a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0][u], bv[0][u], a4, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int u = 0; u < UN; ++u) a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1][u], bv[1][u], a4, 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[wave - 1][r][lane] = a4[r];
     }
     __syncthreads();
-    if (tid < 64) s_val = tridiag_max_eig(alpha, beta, m) / (*divp);     // (every lane writes the same value)
-    if (tid == 0) {
-        sc->radspec = s_val > 0.0 ? s_val : 0.0;
-        sc->spare[3] = (double)m;                               // Krylov steps taken (diagnostic)
-        if (!converged && sc->status == CESX_OK) sc->status = CESX_ENOCONV;
+    double sq = 0.0;
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = r0 + kk + 4 * r;
+            const double v = inv * (((a4[r] + part[0][r][lane]) + part[1][r][lane]) + part[2][r][lane]);
+            if (row < n && jok) { Mout[(size_t)row * n + j] = v; sq += v * v; }
+        }
     }
+    sq = dblock_sum(sq, red);          // (waves 1-3 contribute zeros; fixed order)
+    if (threadIdx.x == 0) parts_out[blockIdx.y * gridDim.x + blockIdx.x] = sq;
+}
+
+// parts[0 .. npart) = per-workgroup sums of squares of A (len doubles); acc = {0, 1, 0}: the start of the sequence
+__global__ __launch_bounds__(DT)
+void spec_begin_kernel(long long len, const double* __restrict__ A, double* __restrict__ parts, int npart, double* __restrict__ acc) {
+    __shared__ double red[DT / 64];
+    double s = 0.0;
+    const long long per = (len + npart - 1) / npart, lo = (long long)blockIdx.x * per, hi = lo + per < len ? lo + per : len;
+    for (long long i = lo + threadIdx.x; i < hi; i += DT) s += A[i] * A[i];
+    s = dblock_sum(s, red);
+    if (threadIdx.x == 0) {
+        parts[blockIdx.x] = s;
+        if (blockIdx.x == 0) { acc[0] = 0.0; acc[1] = 1.0; acc[2] = 0.0; }
+    }
+}
+
+// radspec = lambda_1(B) / N from the accumulated logarithms and the last norm (see the header above)
+__global__ __launch_bounds__(DT)
+void spec_end_kernel(int n, const double* __restrict__ parts, int npart, const double* __restrict__ acc, const double* __restrict__ divp,
+                     Scalars* __restrict__ sc) {
+    __shared__ double red[DT / 64];
+    const double N2 = spec_norm2(parts, npart, red);
+    if (threadIdx.x != 0) return;
+    double lam = 0.0;
+    if (acc[2] == 0.0 && N2 > 0.0 && N2 < 1e300) lam = exp(acc[0] + acc[1] * (0.5 * log(N2) - 0.25 * log((double)n)));
+    sc->radspec = lam / (*divp) > 0.0 ? lam / (*divp) : 0.0;
+    sc->spare[3] = (double)SPEC_SQUARINGS;
 }
 
 // B = Wh See Wh^T for diagonal Gamma: B_ij = See_ij sqrt(gw_i gw_j)  (1/N applied by the caller)
@@ -1806,10 +1772,21 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
     if (prm.time_step == CESX_TS_SPECTRAL && prm.update != CESX_UPDATE_ALDI_CONSTANT) {
         // B = Gamma^{-1/2} See Gamma^{-1/2} (Gamma diagonal, or whitened away), symmetric PSD, same non-zero spectrum as D (times N)
         hipLaunchKernelGGL(whiten_diag_kernel, g1((long long)n * n), dim3(256), 0, s, n, e.d_See, e.d_gw, e.d_t3);
-        const int msteps = n < e.lanczos_steps ? n : e.lanczos_steps;      // <= LANCZOS_MAX (engine.hip)
-        double* lz = e.d_lanczos + (size_t)(msteps + 1) * n;               // [alpha | beta | 2 x scratch]
-        hipLaunchKernelGGL(lanczos_kernel, dim3(1), dim3(DT), 0, s, n, e.d_t3, mom, msteps, e.d_lanczos,
-                           lz, lz + msteps, lz + 2 * msteps, e.d_scal);
+        // lambda_max(B) by repeated squaring (spec_square_kernel above): B in d_t3, the squares alternate between d_t1 and d_t2
+        const int nb16 = (n + 15) / 16, npart = nb16 * nb16;
+        double* acc = e.d_spec;                          // {sum of 2^-k log N_k, 2^-k, degenerate flag}
+        double* parts[2] = {e.d_spec + 4, e.d_spec + 4 + npart};
+        hipLaunchKernelGGL(spec_begin_kernel, dim3(npart), dim3(DT), 0, s, (long long)n * n, (const double*)e.d_t3, parts[0], npart, acc);
+        const double* src = e.d_t3;
+        double* dst = e.d_t1;
+        for (int q = 0; q < SPEC_SQUARINGS; ++q) {
+            hipLaunchKernelGGL(spec_square_kernel, dim3(nb16, nb16), dim3(DT), 0, s, n, src, (const double*)parts[q & 1], npart, dst,
+                               parts[(q & 1) ^ 1], acc);
+            src = dst;
+            dst = dst == e.d_t1 ? e.d_t2 : e.d_t1;
+        }
+        hipLaunchKernelGGL(spec_end_kernel, dim3(1), dim3(DT), 0, s, n, (const double*)parts[SPEC_SQUARINGS & 1], npart, (const double*)acc,
+                           mom, e.d_scal);
         CESX_HIP(hipGetLastError());
     }
     if (fused_finish) {

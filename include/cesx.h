@@ -43,9 +43,11 @@ extern "C" {
 #define CESX_EHIP          3   /* HIP runtime failure                                     */
 #define CESX_ESTATE        4   /* call order violated (e.g. no problem set)              */
 #define CESX_ERCCL         7   /* RCCL failure (cesx_comm_*, cesx_allreduce_*)            */
-#define CESX_ENOCONV       6   /* time_step='spectral': the eigenvalue iteration did not meet
-                                  its residual criterion (np.linalg.LinAlgError "Eigenvalues
-                                  did not converge", what np.linalg.eigvals of :250 raises)  */
+#define CESX_ENOCONV       6   /* reserved: rounds 1-4 returned it when the Lanczos iteration of
+                                  time_step='spectral' missed its residual criterion; since round 5
+                                  lambda_max comes from repeated squaring with a two-sided bound and
+                                  cannot fail to converge (what np.linalg.eigvals of :250 raises
+                                  in that case stays mapped to np.linalg.LinAlgError)          */
 #define CESX_EUNSUPPORTED  5   /* time_step='adaptive': the reference calls the undefined
                                   self.LM_procedure (ces/calibrate.py:255)               */
 

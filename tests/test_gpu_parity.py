@@ -270,28 +270,29 @@ def test_time_step_rules_at_benchmark_shape(eng_mod, ts, p, n, J, dense, dtype, 
     assert np.allclose(got, want, rtol=tol), (got, want)
 
 
-def test_spectral_rule_reports_non_convergence(eng_mod, monkeypatch):
-    """The Lanczos iteration behind time_step='spectral' checks its residual (|| B v - theta v || <=
-    1e-10 theta); when the step cap is exhausted without it the step reports CESX_ENOCONV ->
-    LinAlgError, what np.linalg.eigvals (ces/calibrate.py:250) raises -- never a silent, too large hk."""
-    p, n, J = 16, 200, 1500
-    rng = np.random.default_rng(0)
+@pytest.mark.parametrize("kind", ["flat", "clustered", "gapped", "tiny"])
+def test_spectral_rule_lambda_max_by_repeated_squaring(eng_mod, kind):
+    """time_step='spectral' (ces/calibrate.py:249-251: hk = 1 / max Re eig(D)): the engine takes lambda_max of the n x n
+    whitened S_ee / N by 36 squarings on the matrix pipe with a two-sided bound from the Frobenius norms (relative error
+    <= 2^-36 (ln n) / 4 whatever the spectrum) -- no iteration that could stall on clustered leading eigenvalues, where the
+    Lanczos iteration of rounds 1-4 walked the whole Krylov space or ran into its step cap.  Against numpy's eigvalsh."""
+    rng = np.random.default_rng(11)
+    p, n, J = (16, 200, 1500) if kind != "tiny" else (3, 5, 64)
     d = _synthetic(p, n, J, seed=2)
-    d["G"] = rng.standard_normal((n, J))                       # flat spectrum: slow Krylov convergence
-    monkeypatch.setenv("CESX_LANCZOS_STEPS", "6")
+    if kind == "flat":
+        d["G"] = rng.standard_normal((n, J))                       # Marchenko-Pastur bulk: neighbours a fraction of a percent apart
+    elif kind == "clustered":
+        Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        s = np.ones(n); s[:4] = [3.0, 3.0 * (1 - 1e-7), 3.0 * (1 - 2e-7), 2.9999]
+        d["G"] = (Q * s) @ rng.standard_normal((n, J))             # leading eigenvalues 1e-7 apart (relative)
     eng = eng_mod.Engine(p, n, J, dtype="float64")
-    eng.set_problem(d["y"], d["Gamma"], d["mu"], d["sigma"], d["ustar"])
-    eng.step(eng_mod.step_params(update="aldi", time_step="spectral"), d["U0"], d["G"], xi=d["xi"])
-    with pytest.raises(np.linalg.LinAlgError, match="converge"):
-        eng.result()
-    monkeypatch.delenv("CESX_LANCZOS_STEPS")
-    eng = eng_mod.Engine(p, n, J, dtype="float64")             # default cap (min(n, 512)): converges
     eng.set_problem(d["y"], d["Gamma"], d["mu"], d["sigma"], d["ustar"])
     eng.step(eng_mod.step_params(update="aldi", time_step="spectral"), d["U0"], d["G"], xi=d["xi"])
     res = eng.result()
     E = d["G"] - d["G"].mean(axis=1, keepdims=True)
     lam = np.linalg.eigvalsh(E @ E.T / J / 0.01).max()
     assert res.radspec == pytest.approx(lam, rel=1e-9)
+    assert res.hk == pytest.approx(1.0 / lam, rel=1e-9)
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])

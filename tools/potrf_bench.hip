@@ -23,15 +23,15 @@ int main(int argc, char** argv) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     long long* dbg; hipMalloc(&dbg, 8 * 80); hipMemset(dbg, 0, 8 * 80);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(kern, dim3(1), dim3(cesx::PRT), lds, 0, n, np, dA, dLp, st, (long long*)nullptr, 0, 0, (const double*)nullptr, (const double*)nullptr, 0);
+    for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(kern, dim3(1), dim3(cesx::PRT), lds, 0, n, np, dA, dLp, st, (long long*)nullptr, 0, 0, (const double*)nullptr, (const double*)nullptr, 0, (unsigned long long*)nullptr, 0ull, (float*)nullptr, 0, 0);
     hipEventRecord(e0);
-    for (int it = 0; it < 10; ++it) hipLaunchKernelGGL(kern, dim3(1), dim3(cesx::PRT), lds, 0, n, np, dA, dLp, st, (long long*)nullptr, 0, 0, (const double*)nullptr, (const double*)nullptr, 0);
+    for (int it = 0; it < 10; ++it) hipLaunchKernelGGL(kern, dim3(1), dim3(cesx::PRT), lds, 0, n, np, dA, dLp, st, (long long*)nullptr, 0, 0, (const double*)nullptr, (const double*)nullptr, 0, (unsigned long long*)nullptr, 0ull, (float*)nullptr, 0, 0);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     std::vector<double> L((size_t)n * n); hipMemcpy2D(L.data(), n*8, dLp, np*8, n*8, n, hipMemcpyDeviceToHost);
     double err = 0; for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) { double s = 0; for (int k = 0; k <= j; ++k) s += L[i*n+k]*L[j*n+k]; err = fmax(err, fabs(s - A[i*n+j])); }
     int hst; hipMemcpy(&hst, st, 4, hipMemcpyDeviceToHost);
-    hipLaunchKernelGGL(kern, dim3(1), dim3(cesx::PRT), lds, 0, n, np, dA, dLp, st, dbg, 0, 0, (const double*)nullptr, (const double*)nullptr, 0);
+    hipLaunchKernelGGL(kern, dim3(1), dim3(cesx::PRT), lds, 0, n, np, dA, dLp, st, dbg, 0, 0, (const double*)nullptr, (const double*)nullptr, 0, (unsigned long long*)nullptr, 0ull, (float*)nullptr, 0, 0);
     long long hd[5]; hipMemcpy(hd, dbg, 40, hipMemcpyDeviceToHost);
     { long long pp[72]; hipMemcpy(pp, dbg + 8, 72 * 8, hipMemcpyDeviceToHost); printf("per panel (factor, trailing) cycles:"); for (int k = 0; k < np / 8; k += 1) printf(" %lld/%lld", pp[2 * k], pp[2 * k + 1]); printf("\n"); }
     printf("cycles (wave 0): init %lld | factor %lld barrier %lld | trailing %lld barrier %lld\n", hd[0], hd[1], hd[2], hd[3], hd[4]);
