@@ -363,6 +363,13 @@ struct Engine {
     double *d_t1 = nullptr, *d_t2 = nullptr, *d_t3 = nullptr, *d_t4 = nullptr;   // max(p,n)^2 each
     double *d_Wh = nullptr;        // L_Gamma^{-1} in fp64 (dense Gamma: the centring sums of a fresh ensemble are whitened with it)
     double *d_Lp = nullptr;        // padded Cholesky workspace (round_up(max(p,n),32))^2
+    // warm-started SPD inverses of K2 (kernels_dense.hip, spd_inverse): the previous step's inverse of the gain matrix (0, n x n) and
+    // of the EKS matrix (1, p x p), three n_max^2 scratch matrices, 2 x ceil(n_max/16)^2 residual partials, the verdict word
+    double *d_ns_xprev[2] = {nullptr, nullptr}, *d_ns_r[3] = {nullptr, nullptr, nullptr}, *d_ns_parts = nullptr;
+    int* d_ns_skip = nullptr;
+    bool ns_ok = true;             // CESX_NS_WARM=0: always the factorisation
+    double ns_r0_last = 1e300;     // ||I - A X_prev||_F^2 of the last step's warm-start attempt (cesx_result reads it from the result block)
+    const int* gate = nullptr;     // != nullptr while spd_inverse enqueues its factorisation chain: those kernels return when *gate != 0
     double *d_spec = nullptr;      // spectral rule: {sum 2^-k log N_k, 2^-k, degenerate flag, pad} + 2 x ceil(n/16)^2 partial sums of squares
     double *d_absmax = nullptr;    // [1]
     void   *d_qe = nullptr;        // [J] per-particle q^e (engine dtype)

@@ -359,6 +359,14 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
     { const size_t np_ = (size_t)(mx + 31) / 32 * 32; DM(e.d_Lp, np_ * np_ * 8); }
     if (potrf_ld(mx) > 256) DM(e.d_Lwork, (size_t)potrf_ld(mx) * potrf_ld(mx) * 8);
     DM(e.d_t1, mm * 8); DM(e.d_t2, mm * 8); DM(e.d_t3, mm * 8); DM(e.d_t4, mm * 8);
+    if (potrf_ld(mx) <= 256) {          // warm-started SPD inverses (kernels_dense.hip, spd_inverse); zeroed: X_prev = 0 is a cold start
+        if (const char* nv = std::getenv("CESX_NS_WARM")) e.ns_ok = nv[0] != '0';
+        const size_t nb16 = ((size_t)mx + 15) / 16;
+        DM(e.d_ns_xprev[0], nn * 8); DM(e.d_ns_xprev[1], pp * 8);
+        for (int k = 0; k < 3; ++k) DM(e.d_ns_r[k], (size_t)mx * mx * 8);
+        DM(e.d_ns_parts, 2 * nb16 * nb16 * 8);
+        { char* t; DM(t, 64); e.d_ns_skip = reinterpret_cast<int*>(t); }
+    }
     {   // spectral rule (kernels_dense.hip, spec_square_kernel): {log accumulator, weight, flag, pad} + 2 x per-workgroup partial sums
         const size_t nb16 = ((size_t)n + 15) / 16;
         DM(e.d_spec, (4 + 2 * nb16 * nb16) * 8);
@@ -412,7 +420,8 @@ void cesx_destroy(cesx_handle h) {
                     e.gp[0].d_type_hdr, e.gp[0].d_rows, e.gp[0].d_wblk, e.gp[0].d_blk_rc, e.gp[0].d_row_own, e.gp[0].d_slabs, e.gp[0].d_rowsum_part,
                     e.gp[1].d_type_hdr, e.gp[1].d_rows, e.gp[1].d_wblk, e.gp[1].d_blk_rc, e.gp[1].d_row_own, e.gp[1].d_slabs, e.gp[1].d_rowsum_part, e.d_sums, e.d_ubar, e.d_gbar, e.d_m, e.d_dg,
                     e.d_wdel, e.d_C, e.d_L, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_Kp, e.d_M, e.d_P, e.d_PK,
-                    e.d_t1, e.d_t2, e.d_t3, e.d_t4, e.d_Lp, e.d_spec, e.d_mv, e.d_part, e.d_scal, e.d_absmax,
+                    e.d_t1, e.d_t2, e.d_t3, e.d_t4, e.d_Lp, e.d_spec, e.d_ns_xprev[0], e.d_ns_xprev[1], e.d_ns_r[0], e.d_ns_r[1], e.d_ns_r[2],
+                    e.d_ns_parts, e.d_ns_skip, e.d_mv, e.d_part, e.d_scal, e.d_absmax,
                     e.d_absmax_part, e.d_clk, e.d_cholflag, e.d_lag, e.d_A64, e.d_b64, e.d_lvec, e.d_Wq, e.d_ticket};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
@@ -485,6 +494,8 @@ int cesx_set_problem(cesx_handle h, const double* y, const double* Gamma, const 
     TRY(upload(e, e.d_mu, mu, p * 8)); TRY(upload(e, e.d_ustar, ustar, p * 8));
     TRY(upload(e, e.d_Sigma, Sigma, (size_t)p * p * 8)); TRY(upload(e, e.d_Sinv, inv.data(), (size_t)p * p * 8));
     TRY(upload(e, e.d_sw, sw.data(), p * 8));
+    // a new problem: the warm starts of K2's SPD inverses (kernels_dense.hip, spd_inverse) start cold
+    if (e.d_ns_xprev[0]) { CESX_HIP(hipMemset(e.d_ns_xprev[0], 0, (size_t)n * n * 8)); CESX_HIP(hipMemset(e.d_ns_xprev[1], 0, (size_t)p * p * 8)); }
     e.problem_set = true;
     e.shift_valid = false;
     return CESX_OK;
@@ -768,6 +779,7 @@ int cesx_result(cesx_handle h, cesx_step_result* out) {
     out->bias_data = sc.bias_data; out->bias = sc.bias;
     out->radspec = sc.radspec; out->status = sc.status; out->reserved = 0;
     out->lag_bias_data = sc.spare[1]; out->lag_self_bias_data = sc.spare[2];
+    e.ns_r0_last = sc.spare[3] > 0.0 ? sc.spare[3] : 1e300;      // (kernels_dense.hip, spd_inverse: sizes the next warm start's sweeps)
     if (sc.status == CESX_ENOTPD) {
         e.err = "ensemble covariance is not positive definite (Cholesky failed)";
         return CESX_ENOTPD;
@@ -814,6 +826,16 @@ int cesx_result(cesx_handle h, cesx_step_result* out) {
 }
 
 unsigned long long cesx_debug_poll_recoveries(cesx_handle h) { return h ? reinterpret_cast<Engine*>(h)->poll_recoveries : 0; }
+
+int cesx_debug_warm_inverse(cesx_handle h) {
+    if (!h) return -1;
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    if (!e.d_ns_skip) return 0;
+    DeviceGuard dg(e.cfg.device);
+    int v = 0;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&v, e.d_ns_skip, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return v;
+}
 
 int cesx_draw_noise(cesx_handle h, uint64_t step_index, void* xi, void* stream) {
     if (!h) return CESX_EINVAL;

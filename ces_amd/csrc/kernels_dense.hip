@@ -197,7 +197,9 @@ using gemm_d4_t = double __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(DT)
 void gemm_kernel(int m, int n, int k, double alpha, const double* __restrict__ A, long long a0, long long a1,
                  const double* __restrict__ B, long long b0, long long b1, double* Cm, int ldc,
-                 const double* Cin = nullptr) {       // Cin (may be Cm itself): C = Cin + alpha A B
+                 const double* Cin = nullptr,         // Cin (may be Cm itself): C = Cin + alpha A B
+                 const int* __restrict__ skip = nullptr) {      // *skip != 0: nothing to do (spd_inverse)
+    if (skip != nullptr && *skip != 0) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r0 = (blockIdx.y * 2 + (wave >> 1)) * 16, c0 = (blockIdx.x * 2 + (wave & 1)) * 16;
     if (r0 >= m || c0 >= n) return;
@@ -250,8 +252,8 @@ void gemm_kernel(int m, int n, int k, double alpha, const double* __restrict__ A
 __global__ __launch_bounds__(DT)
 void gemm_splitk_kernel(int m, int n, int k, double alpha, const double* __restrict__ A, long long a0, long long a1,
                         const double* __restrict__ B, long long b0, long long b1, double* Cm, int ldc,
-                        const double* __restrict__ scale = nullptr) {      // scale != nullptr: alpha times (*scale)^2 (a device scalar)
-    if (scale != nullptr) alpha *= scale[0] * scale[0];
+                        const int* __restrict__ skip = nullptr) {          // skip != nullptr and *skip != 0: nothing to do (spd_inverse)
+    if (skip != nullptr && *skip != 0) return;
     __shared__ double part[3][4][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16;
@@ -371,7 +373,9 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
                       // wq != nullptr: every finished panel also goes, in fp32, into the first K segment (columns [0, wq_kp)) of
                       // the fragment-major coefficient image of the hk-free update (Engine::d_Wq, wf_index): a row's 8 panel
                       // entries are two 16-byte pieces of it (even / odd columns = the two k sub-blocks of the MFMA operand)
-                      float* __restrict__ wq = nullptr, int wq_nkt = 0, int wq_kp = 0) {
+                      float* __restrict__ wq = nullptr, int wq_nkt = 0, int wq_kp = 0,
+                      const int* __restrict__ skip = nullptr) {      // *skip != 0: nothing to do (spd_inverse's warm start converged)
+    if (skip != nullptr && *skip != 0) return;
     if (lda == 0) lda = n;
     if (ldl == 0) ldl = np;
     double cinvN = 1.0, cinvdiv = 1.0;
@@ -732,7 +736,6 @@ void spec_end_kernel(int n, const double* __restrict__ parts, int npart, const d
     double lam = 0.0;
     if (acc[2] == 0.0 && N2 > 0.0 && N2 < 1e300) lam = exp(acc[0] + acc[1] * (0.5 * log(N2) - 0.25 * log((double)n)));
     sc->radspec = lam / (*divp) > 0.0 ? lam / (*divp) : 0.0;
-    sc->spare[3] = (double)SPEC_SQUARINGS;
 }
 
 // B = Wh See Wh^T for diagonal Gamma: B_ij = See_ij sqrt(gw_i gw_j)  (1/N applied by the caller)
@@ -1386,10 +1389,10 @@ static int gemm(Engine& e, hipStream_t s, int m, int n, int k, double alpha, con
     // (small output, long k: K split over the waves of a workgroup -- a 256^3 product 20 -> see DESIGN.md; else 2 x 2 blocks per workgroup)
     if (k >= 64 && (long long)((m + 15) / 16) * ((n + 15) / 16) <= 4096)
         hipLaunchKernelGGL(gemm_splitk_kernel, dim3((n + 15) / 16, (m + 15) / 16), dim3(DT), 0, s, m, n, k, alpha, A, a0,
-                           a1, B, b0, b1, C, n);
+                           a1, B, b0, b1, C, n, e.gate);
     else
     hipLaunchKernelGGL(gemm_kernel, dim3((n + 31) / 32, (m + 31) / 32), dim3(DT), 0, s, m, n, k, alpha, A, a0,
-                       a1, B, b0, b1, C, n, (const double*)nullptr);
+                       a1, B, b0, b1, C, n, (const double*)nullptr, e.gate);
     CESX_HIP(hipGetLastError());
     return CESX_OK;
 }
@@ -1408,10 +1411,10 @@ static int potrf_reg_launch(Engine& e, hipStream_t s, int n, int np, const doubl
     if (stop)
         hipExtLaunchKernelGGL(potrf_reg_kernel<SLOTS>, dim3(1), dim3(PRT), (unsigned)lds, s, nullptr, stop, 0, n, np, A, Lp,
                               &e.d_scal->status, (long long*)nullptr, lda, ldl, cen.sa, cen.N, cen.unbiased, done, done_val,
-                              wq, e.ktot / 16, e.kp);
+                              wq, e.ktot / 16, e.kp, e.gate);
     else
     hipLaunchKernelGGL(potrf_reg_kernel<SLOTS>, dim3(1), dim3(PRT), lds, s, n, np, A, Lp, &e.d_scal->status, (long long*)nullptr,
-                       lda, ldl, cen.sa, cen.N, cen.unbiased, done, done_val, wq, e.ktot / 16, e.kp);
+                       lda, ldl, cen.sa, cen.N, cen.unbiased, done, done_val, wq, e.ktot / 16, e.kp, e.gate);
     CESX_HIP(hipGetLastError());
     return CESX_OK;
 }
@@ -1428,7 +1431,8 @@ static int potrf_reg_launch(Engine& e, hipStream_t s, int n, int np, const doubl
 template <int SLOTS>
 __global__ __launch_bounds__(PRT, 2)
 void trsm_reg_kernel(int nr, int nc, const double* __restrict__ A, int lda, const double* __restrict__ L, int ldl,
-                     double* __restrict__ X, int ldx) {
+                     double* __restrict__ X, int ldx, const int* __restrict__ skip = nullptr) {
+    if (skip != nullptr && *skip != 0) return;
     __shared__ double XP[QNB][64 + 4];        // the panel: current values, then the solution (column major)
     __shared__ double LBs[2][QNB][256 + 4];   // L[r][kb + j] for r >= kb + j, 0 above the diagonal; double buffered:
                                               // the next panel's columns are fetched from global memory while this
@@ -1556,10 +1560,10 @@ static int trsm_reg(Engine& e, hipStream_t s, int nr, int nc, const double* A, i
                     double* X, int ldx) {
     const dim3 grid((nr + 63) / 64), block(PRT);
     const int slots = (4 * (nc / 16) + 7) / 8;
-    if (slots <= 2) hipLaunchKernelGGL(trsm_reg_kernel<2>, grid, block, 0, s, nr, nc, A, lda, L, ldl, X, ldx);
-    else if (slots <= 4) hipLaunchKernelGGL(trsm_reg_kernel<4>, grid, block, 0, s, nr, nc, A, lda, L, ldl, X, ldx);
-    else if (slots <= 6) hipLaunchKernelGGL(trsm_reg_kernel<6>, grid, block, 0, s, nr, nc, A, lda, L, ldl, X, ldx);
-    else hipLaunchKernelGGL(trsm_reg_kernel<8>, grid, block, 0, s, nr, nc, A, lda, L, ldl, X, ldx);
+    if (slots <= 2) hipLaunchKernelGGL(trsm_reg_kernel<2>, grid, block, 0, s, nr, nc, A, lda, L, ldl, X, ldx, e.gate);
+    else if (slots <= 4) hipLaunchKernelGGL(trsm_reg_kernel<4>, grid, block, 0, s, nr, nc, A, lda, L, ldl, X, ldx, e.gate);
+    else if (slots <= 6) hipLaunchKernelGGL(trsm_reg_kernel<6>, grid, block, 0, s, nr, nc, A, lda, L, ldl, X, ldx, e.gate);
+    else hipLaunchKernelGGL(trsm_reg_kernel<8>, grid, block, 0, s, nr, nc, A, lda, L, ldl, X, ldx, e.gate);
     CESX_HIP(hipGetLastError());
     return CESX_OK;
 }
@@ -1641,15 +1645,173 @@ static int trsm_right_lt(Engine& e, hipStream_t s, int nr, int np, const double*
     return CESX_OK;
 }
 
-// Ainv = A^{-1} for SPD A (n x n); uses t1 (chol), t2 (X = L^{-T}):  A^{-1} = L^{-T} L^{-1} = X X^T
-static int spd_inverse(Engine& e, hipStream_t s, int n, const double* A, double* Ainv) {
+// ---------------------------------------------------------------------------
+// The hk-dependent SPD inverses of K2 -- (Sigma + hk C)^{-1} of the EKS rule (ces/calibrate.py:443), (hk C_gg + Gamma)^{-1} of the
+// recomputed gain (:440-441 / :472-473) -- sit on the step's critical path with nothing to hide behind: hk comes from the
+// Frobenius term of the COMPLETE Gram.  Factored from scratch they are a 97-us column-sequential Cholesky + a 77-us triangular
+// inverse + a product (n = 256).  Inside a run the matrix changes little from step to step, so the previous step's inverse X is
+// a good start for Newton-Schulz:   R = I - A X,   X <- X + X R,   R <- R R   (the residual squares every sweep; both products of
+// a sweep are independent: one launch).  Tried when ||R_0||_F < 4 (a sufficient condition is rho(R_0) < 1; the Frobenius norm of
+// an n x n residual whose every direction is off by 10 % is 0.1 sqrt(n)): five sweeps when the PREVIOUS step's start was close
+// (||R_0||_F < 0.3: 0.3^32 = 2e-17), seven otherwise (rho = 0.7: 0.7^128 = 1e-20).  Then the TRUE residual I - A X is formed and
+// checked (||.||_F < 1e-10): only then the factorisation chain is skipped (its kernels read one word and return).  Anything else
+// -- the first step, an ensemble that moved a lot (the sweeps diverge: the check fails), an ill-conditioned A whose residual floor
+// is higher, a NaN -- takes the factorisation, as before.  80 - 100 us instead of ~180 at n = 256; every product on
+// v_mfma_f64_16x16x4_f64.
+// One 16 x 16 block of the output per workgroup, K split over its four waves (gemm_splitk_kernel's structure).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ gemm_d4_t ns_block(int n, const double* __restrict__ A, const double* __restrict__ B, int r0, int c0,
+                                              double (*part)[4][64]) {
+    // C(r0.., c0..) = A (n x n, row-major) . B (n x n, row-major); valid in wave 0 (C/D map: col = lane & 15, row = (lane >> 4) + 4 reg)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = r0 + (lane & 15), j = c0 + (lane & 15), kk = lane >> 4;
+    const bool iok = i < n, jok = j < n;
+    const double* pa = A + (size_t)(iok ? i : 0) * n;
+    const double* pb = B + (jok ? j : 0);
+    const int kper = ((n + 3) / 4 + 3) / 4 * 4;
+    const int kbeg = wave * kper, kend = kbeg + kper < n ? kbeg + kper : n;
+    constexpr int UN = 8;
+    gemm_d4_t acc = {0.0, 0.0, 0.0, 0.0};
+    double av[2][UN], bv[2][UN];
+    auto load = [&](int buf, int k0) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int kc = k0 + 4 * u + kk;
+            const bool kok = kc < kend;
+            av[buf][u] = (iok && kok) ? pa[kc] : 0.0;
+            bv[buf][u] = (jok && kok) ? pb[(size_t)kc * n] : 0.0;
+        }
+    };
+    if (kbeg < kend) load(0, kbeg);
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += 4 * UN) {
+        if (k0 + 4 * UN < kend) {
+            if (buf == 0) load(1, k0 + 4 * UN); else load(0, k0 + 4 * UN);
+        }
+        if (buf == 0) {
+#pragma unroll
+            for (int u = 0; u < UN; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0][u], bv[0][u], acc, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int u = 0; u < UN; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1][u], bv[1][u], acc, 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = ((acc[r] + part[0][r][lane]) + part[1][r][lane]) + part[2][r][lane];
+    }
+    return acc;
+}
+
+constexpr double NS_START2 = 16.0;      // ||I - A X_prev||_F^2 below which the warm start is tried
+constexpr double NS_CLOSE2 = 0.09;      // ... below which five sweeps are enough for the next step (seven otherwise)
+constexpr double NS_DONE2 = 1e-20;      // ||I - A X||_F^2 below which the result is accepted
+
+// R = I - A X, parts[workgroup] = sum of squares of its block of R.  gate != nullptr: only when sum(gate[0..npart)) < NS_START2
+__global__ __launch_bounds__(DT)
+void ns_resid_kernel(int n, const double* __restrict__ A, const double* __restrict__ X, double* __restrict__ R,
+                     double* __restrict__ parts, const double* __restrict__ gate, int npart) {
+    __shared__ double red[DT / 64];
+    __shared__ double part[3][4][64];
+    if (gate != nullptr && !(spec_norm2(gate, npart, red) < NS_START2)) return;
+    const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, lane = threadIdx.x & 63, kk = lane >> 4, j = c0 + (lane & 15);
+    const gemm_d4_t acc = ns_block(n, A, X, r0, c0, part);
+    double sq = 0.0;
+    if ((threadIdx.x >> 6) == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = r0 + kk + 4 * r;
+            if (row < n && j < n) { const double v = (row == j ? 1.0 : 0.0) - acc[r]; R[(size_t)row * n + j] = v; sq += v * v; }
+        }
+    }
+    sq = dblock_sum(sq, red);
+    if (threadIdx.x == 0) parts[blockIdx.y * gridDim.x + blockIdx.x] = sq;
+}
+
+// one sweep, both products in one launch: blockIdx.z == 0: Xn = X + X R;  1: Rn = R R
+__global__ __launch_bounds__(DT)
+void ns_sweep_kernel(int n, const double* __restrict__ X, const double* __restrict__ R, double* __restrict__ Xn,
+                     double* __restrict__ Rn, const double* __restrict__ gate, int npart) {
+    __shared__ double red[DT / 64];
+    __shared__ double part[3][4][64];
+    if (!(spec_norm2(gate, npart, red) < NS_START2)) return;
+    const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, lane = threadIdx.x & 63, kk = lane >> 4, j = c0 + (lane & 15);
+    const bool isx = blockIdx.z == 0;
+    const gemm_d4_t acc = ns_block(n, isx ? X : R, R, r0, c0, part);
+    if ((threadIdx.x >> 6) == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = r0 + kk + 4 * r;
+            if (row < n && j < n) {
+                const size_t o = (size_t)row * n + j;
+                if (isx) Xn[o] = X[o] + acc[r]; else Rn[o] = acc[r];
+            }
+        }
+    }
+}
+
+// skip[0] = 1: the warm start was taken AND its true residual passed -- the factorisation chain behind has nothing to do
+__global__ __launch_bounds__(DT)
+void ns_verdict_kernel(const double* __restrict__ parts0, const double* __restrict__ partsf, int npart, int* __restrict__ skip,
+                       Scalars* __restrict__ sc) {
+    __shared__ double red[DT / 64];
+    const double r0 = spec_norm2(parts0, npart, red);
+    const double rf = spec_norm2(partsf, npart, red);
+    if (threadIdx.x == 0) {
+        skip[0] = (r0 < NS_START2 && rf < NS_DONE2) ? 1 : 0;
+        sc->spare[3] = r0;          // published with the step's result: the host sizes the next step's sweeps with it
+    }
+}
+
+__global__ void copy_kernel(long long len, const double* __restrict__ src, double* __restrict__ dst) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < len) dst[i] = src[i];
+}
+
+// Ainv = A^{-1} for SPD A (n x n).  which: 0 the recomputed gain's matrix, 1 the EKS rule's (each keeps its own previous inverse).
+// Cold (or not converged): t1 (chol), t2 (X = L^{-T}),  A^{-1} = L^{-T} L^{-1} = X X^T.
+static int spd_inverse(Engine& e, hipStream_t s, int n, const double* A, double* Ainv, int which) {
     int rc;
     const int np = potrf_ld(n);
-    if ((rc = potrf(e, s, n, A, e.d_t1))) return rc;
-    if ((rc = trsm_right_lt(e, s, n, np, nullptr, 0, e.d_t1, np, e.d_t2, np))) return rc;
+    const bool warm = np <= 256 && e.d_ns_xprev[which] != nullptr && e.ns_ok;
+    if (warm) {
+        const int nb = (n + 15) / 16, npart = nb * nb;
+        double* Xp = e.d_ns_xprev[which];
+        double* parts0 = e.d_ns_parts, *partsf = e.d_ns_parts + npart;
+        double* Rb[2] = {e.d_ns_r[0], e.d_ns_r[1]};
+        double* Xb[2] = {Ainv, e.d_ns_r[2]};
+        hipLaunchKernelGGL(ns_resid_kernel, dim3(nb, nb), dim3(DT), 0, s, n, A, (const double*)Xp, Rb[0], parts0, (const double*)nullptr, npart);
+        const double* Xc = Xp;
+        const int sweeps = e.ns_r0_last < NS_CLOSE2 ? 5 : 7;          // (odd: X_1 -> Ainv, X_2 -> scratch, ..., the last one -> Ainv)
+        for (int it = 0; it < sweeps; ++it) {
+            hipLaunchKernelGGL(ns_sweep_kernel, dim3(nb, nb, 2), dim3(DT), 0, s, n, Xc, (const double*)Rb[it & 1], Xb[it & 1], Rb[(it & 1) ^ 1],
+                               (const double*)parts0, npart);
+            Xc = Xb[it & 1];
+        }
+        hipLaunchKernelGGL(ns_resid_kernel, dim3(nb, nb), dim3(DT), 0, s, n, A, (const double*)Ainv, Rb[0], partsf, (const double*)parts0, npart);
+        hipLaunchKernelGGL(ns_verdict_kernel, dim3(1), dim3(DT), 0, s, (const double*)parts0, (const double*)partsf, npart, e.d_ns_skip,
+                           e.d_scal);
+        CESX_HIP(hipGetLastError());
+        e.gate = e.d_ns_skip;
+    }
+    rc = potrf(e, s, n, A, e.d_t1);
+    if (rc == CESX_OK) rc = trsm_right_lt(e, s, n, np, nullptr, 0, e.d_t1, np, e.d_t2, np);
     // X is upper triangular: X[i][k] = 0 for k < i; columns >= n of the rows < n are zero
     // (K split over the waves of a workgroup for the sizes of K2: 21 -> 7 us at n = 256)
-    return gemm(e, s, n, n, n, 1.0, e.d_t2, (long long)np, 1LL, e.d_t2, 1LL, (long long)np, Ainv);
+    if (rc == CESX_OK) rc = gemm(e, s, n, n, n, 1.0, e.d_t2, (long long)np, 1LL, e.d_t2, 1LL, (long long)np, Ainv);
+    e.gate = nullptr;
+    if (rc != CESX_OK) return rc;
+    if (warm) {          // this step's inverse is the next one's start
+        hipLaunchKernelGGL(copy_kernel, g1((long long)n * n), dim3(256), 0, s, (long long)n * n, (const double*)Ainv, e.d_ns_xprev[which]);
+        CESX_HIP(hipGetLastError());
+    }
+    return CESX_OK;
 }
 
 template <typename T>
@@ -1821,7 +1983,7 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
         hipLaunchKernelGGL(axpb_kernel, g1((long long)n * n), dim3(256), 0, s, (long long)n * n, &e.d_scal->hk,
                            mom, e.d_See, e.d_Gamma, e.d_t3);
         CESX_HIP(hipGetLastError());
-        if ((rc = spd_inverse(e, s, n, e.d_t3, e.d_t4))) return rc;
+        if ((rc = spd_inverse(e, s, n, e.d_t3, e.d_t4, 0))) return rc;
         if ((rc = gemm(e, s, p, n, n, 1.0, e.d_Cug, n, 1, e.d_t4, n, 1, e.d_Kp))) return rc;
         hipLaunchKernelGGL(select_kernel, g1((long long)p * n), dim3(256), 0, s, (long long)p * n, e.d_scal, e.d_Kp, e.d_K);
         CESX_HIP(hipGetLastError());
@@ -1837,7 +1999,7 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
         hipLaunchKernelGGL(axpb_kernel, g1((long long)p * p), dim3(256), 0, s, (long long)p * p, &e.d_scal->hk,
                            (const double*)nullptr, e.d_C, e.d_Sigma, e.d_t3);
         CESX_HIP(hipGetLastError());
-        if ((rc = spd_inverse(e, s, p, e.d_t3, e.d_t4))) return rc;
+        if ((rc = spd_inverse(e, s, p, e.d_t3, e.d_t4, 1))) return rc;
         if ((rc = gemm(e, s, p, p, p, 1.0, e.d_Sigma, p, 1, e.d_t4, p, 1, e.d_P))) return rc;
         if ((rc = gemm(e, s, p, n, p, 1.0, e.d_P, p, 1, e.d_K, n, 1, e.d_PK))) return rc;
         hipLaunchKernelGGL(hk_sum_kernel, g1(p), dim3(256), 0, s, p, e.d_scal, e.d_mv, e.d_mv + 2 * mx, e.d_mv + 5 * mx);

@@ -27,7 +27,8 @@ EXPORTS = ("cesx_abi_version", "cesx_create", "cesx_destroy", "cesx_last_error",
            "cesx_moments_uu_len", "cesx_moments_uu", "cesx_chol_async", "cesx_moments_rest", "cesx_side_stream",
            "cesx_prefetch_noise", "cesx_forward_set_lineal", "cesx_forward_apply", "cesx_moments_uu_chol", "cesx_debug_poll_recoveries", "cesx_comm_unique_id", "cesx_comm_init", "cesx_comm_destroy", "cesx_comm_nranks",
            "cesx_comm_stats", "cesx_allreduce_head", "cesx_allreduce_tail", "cesx_allreduce_whole", "cesx_allreduce_sum", "cesx_allreduce_max", "cesx_moments_uu_handover", "cesx_debug_gram_plan",
-           "cesx_profile_clock", "cesx_calibrate_mfma", "cesx_profile_gap", "cesx_moments_rest_lineal", "cesx_copy_cols_async")
+           "cesx_profile_clock", "cesx_calibrate_mfma", "cesx_profile_gap", "cesx_moments_rest_lineal", "cesx_copy_cols_async",
+           "cesx_debug_warm_inverse")
 
 
 class Config(C.Structure):
@@ -144,6 +145,7 @@ def load_library(path=None):
         getattr(lib, name).argtypes = [vp, vp, C.c_size_t, vp]
     lib.cesx_debug_poll_recoveries.argtypes = [vp]
     lib.cesx_debug_poll_recoveries.restype = C.c_ulonglong
+    lib.cesx_debug_warm_inverse.argtypes = [vp]
     lib.cesx_forward_lineal.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.cesx_forward_set_lineal.argtypes = [vp, vp, vp, vp]
     lib.cesx_forward_apply.argtypes = [vp, vp, vp, vp]
@@ -668,6 +670,10 @@ class Engine:
             fn = self.lib.cesx_allreduce_max if op == "max" else self.lib.cesx_allreduce_sum
             self._check(fn(self._h, t.data_ptr(), t.numel(), self._stream()))
         return t
+
+    def warm_inverse(self):
+        """1 when the last hk-dependent SPD inverse of a step came from the warm start (cesx_debug_warm_inverse)."""
+        return int(self.lib.cesx_debug_warm_inverse(self._h))
 
     def poll_recoveries(self):
         """Steps whose polled join of the side stream ran out and that cesx_result re-ran (include/cesx.h)."""

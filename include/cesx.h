@@ -198,6 +198,14 @@ int cesx_result(cesx_handle h, cesx_step_result* out);
    cesx_debug_poll_recoveries: how many steps of this handle were re-run that way. */
 unsigned long long cesx_debug_poll_recoveries(cesx_handle h);
 
+/* The hk-dependent SPD inverses of a step -- (Sigma + hk C)^{-1} of the EKS rule (ces/calibrate.py:443), (hk C_gg + Gamma)^{-1} of the
+   recomputed gain (:440-441, :472-473) -- are started from the previous step's inverse (Newton-Schulz sweeps on the matrix pipe)
+   when that start is close (||I - A X_prev||_F < 0.3) and accepted only when the TRUE residual of the result passes
+   (||I - A X||_F < 1e-10); otherwise, and always on the first step of a problem, they are factored from scratch (Cholesky,
+   triangular inverse, product).  Same inverse to ~1e-10 either way; CESX_NS_WARM=0 pins the factorisation.
+   cesx_debug_warm_inverse: 1 when the last such inverse of this handle was taken from the warm start, else 0.  Synchronises. */
+int cesx_debug_warm_inverse(cesx_handle h);
+
 /* ---- split entry points (multi-device, testing) ----------------------- */
 
 /* Length in doubles of the packed moment buffer that is summed across devices:

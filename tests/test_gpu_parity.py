@@ -295,6 +295,53 @@ def test_spectral_rule_lambda_max_by_repeated_squaring(eng_mod, kind):
     assert res.hk == pytest.approx(1.0 / lam, rel=1e-9)
 
 
+@pytest.mark.parametrize("update,ts", [("eks", None), ("aldi", "constant"), ("eks", "constant"), ("aldi", "mix")])
+def test_warm_started_spd_inverses_equal_the_factored_ones(eng_mod, monkeypatch, update, ts):
+    """The hk-dependent SPD inverses of K2 ((Sigma + hk C)^-1 of the EKS rule, (hk C_gg + Gamma)^-1 of the recomputed gain) start
+    from the previous step's inverse inside a chain (Newton-Schulz sweeps, the true residual checked, the factorisation chain
+    skipped only then).  A chain on one engine: the first step factors (cold), the later ones take the warm start -- and the
+    ensembles and scalars equal those of a chain that always factors (CESX_NS_WARM=0) to 1e-9."""
+    from oracle import ces_numpy as oc
+    p, n, J = 96, 80, 4096
+    d = _synthetic(p, n, J, seed=13, dense=True)
+    kw = dict(time_step=ts, delta_t=0.02, spinup=0.0)
+
+    def chain():
+        eng = eng_mod.Engine(p, n, J, dtype="float64")
+        eng.set_problem(d["y"], d["Gamma"], d["mu"], d["sigma"], d["ustar"])
+        U, t_last, outs, warm = d["U0"], 0.0, [], []
+        rng = np.random.default_rng(5)
+        for i in range(4):
+            G = d["A"] @ U + 0.05 * np.sin(d["A"] @ U)
+            xi = rng.standard_normal((p, J))
+            prm = eng_mod.step_params(update=update, first_step=(i == 0), t_len=min(i, 1), t_last=t_last + 2.0 * (ts == "mix"),
+                                      step_index=i, **kw)
+            out = eng.step(prm, U, G, xi=xi).cpu().numpy().astype(np.float64)
+            res = eng.result()
+            warm.append(eng.warm_inverse())
+            outs.append((out, res.hk, res.bias_data))
+            # (small moves: the next ensemble is a convex step towards the update, as late in a run)
+            U, t_last = U + 0.1 * (out - U), res.t_new
+        return outs, warm
+    monkeypatch.setenv("CESX_NS_WARM", "0")
+    ref, w0 = chain()
+    monkeypatch.delenv("CESX_NS_WARM")
+    got, w1 = chain()
+    assert w0 == [0, 0, 0, 0]
+    # (time_step='mix': its first step takes the Frobenius step size, the second delta_t -- another matrix, factored once more)
+    assert w1[0] == 0 and w1[-2:] == [1, 1] and (ts == "mix" or w1[1] == 1), w1
+    for (a, ha, ba), (b, hb, bb) in zip(got, ref):
+        assert rel_err(a, b) < 1e-9 and abs(ha - hb) <= 1e-12 * abs(hb) and abs(ba - bb) <= 1e-9 * abs(bb)
+    # ... and the first (cold) step is the pinned oracle's
+    st = oc.OracleState(p, n, J, d["mu"], d["sigma"], d["ustar"])
+    G0 = d["A"] @ d["U0"] + 0.05 * np.sin(d["A"] @ d["U0"])
+    xi0 = np.random.default_rng(5).standard_normal((p, J))
+    okw = {k: v for k, v in kw.items() if v is not None and (k != "spinup" or ts == "mix")}
+    if ts != "mix":
+        ref0 = oc.factored_step(st, d["y"], d["U0"], G0, d["Gamma"], xi0, update=update, **okw)
+        assert rel_err(got[0][0], ref0) < TOL64
+
+
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_moments_against_oracle(eng_mod, dtype):
     """K1 alone: ubar, gbar, C, K, M from the engine vs. the oracle's moments."""
