@@ -331,6 +331,7 @@ struct Engine {
     void* d_Gw = nullptr;                        // [n][J] the whitened data of the current step (allocated with the first dense problem)
     const void* gw_src = nullptr;                // ... of this caller array, whitened on gw_stream
     hipStream_t gw_stream = nullptr;
+    unsigned long long gw_calls = 0;             // Engine::moments_calls when it was whitened
     std::vector<double> h_LG, h_Li;              // host copies of L_Gamma and its inverse (cesx_debug_dense reports in the caller's coordinates)
 
     // problem data (fp64) on device
@@ -346,8 +347,6 @@ struct Engine {
     GramPart gp[2];
     MomLayout ml{};
     // stats partials
-    int stats_blocks = 0;
-    double* d_stat_part = nullptr; // [stats_blocks][stat_len]
     int colsum_slices = 0;
     double* d_colsum_part = nullptr;
     // moments
@@ -356,13 +355,12 @@ struct Engine {
     double* d_sums = nullptr;      // [1+p+n]
     double* d_sums_w = nullptr;    // [1+p+n] the same with the G part whitened (dense Gamma)
     // dense workspace (fp64)
-    double *d_ubar = nullptr, *d_gbar = nullptr, *d_m = nullptr, *d_wdel = nullptr;
+    double *d_ubar = nullptr, *d_gbar = nullptr, *d_m = nullptr;
     double *d_C = nullptr, *d_L = nullptr, *d_Cug = nullptr, *d_See = nullptr, *d_Srr = nullptr;
     double *d_dg = nullptr;
     double *d_K = nullptr, *d_Kp = nullptr, *d_M = nullptr, *d_P = nullptr, *d_PK = nullptr;
     double *d_t1 = nullptr, *d_t2 = nullptr, *d_t3 = nullptr, *d_t4 = nullptr;   // max(p,n)^2 each
     double *d_Wh = nullptr;        // L_Gamma^{-1} in fp64 (dense Gamma: the centring sums of a fresh ensemble are whitened with it)
-    double *d_Lp = nullptr;        // padded Cholesky workspace (round_up(max(p,n),32))^2
     // warm-started SPD inverses of K2 (kernels_dense.hip, spd_inverse): the previous step's inverse of the gain matrix (0, n x n) and
     // of the EKS matrix (1, p x p), three n_max^2 scratch matrices, 2 x ceil(n_max/16)^2 residual partials, the verdict word
     double *d_ns_xprev[2] = {nullptr, nullptr}, *d_ns_r[3] = {nullptr, nullptr, nullptr}, *d_ns_parts = nullptr;
@@ -372,12 +370,9 @@ struct Engine {
     const int* gate = nullptr;     // != nullptr while spd_inverse enqueues its factorisation chain: those kernels return when *gate != 0
     double *d_spec = nullptr;      // spectral rule: {sum 2^-k log N_k, 2^-k, degenerate flag, pad} + 2 x ceil(n/16)^2 partial sums of squares
     double *d_absmax = nullptr;    // [1]
-    void   *d_qe = nullptr;        // [J] per-particle q^e (engine dtype)
-    double *d_colsum_partq = nullptr;
     void   *d_rowc = nullptr;        // [kn][4] {gbar_i, y_i, 1/Gamma_ii, 0} engine dtype (K3 data metrics)
     double *d_metric_part = nullptr; // [blocks][2] per-workgroup {sum q_r^2, sum q_e^2}
     double *d_metric_sums = nullptr; // [2] this shard's sums of the last apply
-    void   *d_gbarT = nullptr;       // [n] gbar in the engine dtype (dense-Gamma metrics)
     double *d_mv = nullptr;        // matvec results [6][max(p,n)]
     double *d_part = nullptr;      // reduction partials
     Scalars* d_scal = nullptr;
@@ -425,7 +420,6 @@ struct Engine {
     std::vector<hipEvent_t> prof_pool;
     long long* d_clk = nullptr;    // [4] {s_memtime, s_memrealtime} ticks of the last PROFILED update launch (workgroup 0, wave 0)
     // results
-    cesx_step_result* h_res = nullptr;   // pinned
     Scalars* h_scal = nullptr;           // pinned, device-mapped: the GPU writes results straight into it
     Scalars* h_scal_dev = nullptr;       // device address of h_scal
     unsigned long long seq = 0;

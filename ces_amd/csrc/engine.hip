@@ -172,7 +172,8 @@ void set_global_error(const std::string& msg) { try { g_create_err = msg; } catc
 const void* whitened_G(Engine& e, const void* G, hipStream_t s, bool force, int* rc) {
     *rc = CESX_OK;
     if (!e.whiten) return G;
-    if (!force && e.gw_src == G && e.gw_stream == s) return e.d_Gw;
+    // (reused only inside the step that whitened it: the same array, the same stream, no cesx_moments* call since)
+    if (!force && e.gw_src == G && e.gw_stream == s && e.gw_calls == e.moments_calls) return e.d_Gw;
     // G~ = L_Gamma^{-1} G: one K segment with lower-triangular coefficients (the kernel skips the zero blocks), no bias
     UpdateSrc src[1] = {{G, e.n, 0, 1}};
     UpdateOpt opt;
@@ -180,7 +181,7 @@ const void* whitened_G(Engine& e, const void* G, hipStream_t s, bool force, int*
     *rc = launch_update(e, e.n, e.d_Wwh, e.kn, nullptr, src, 1, nullptr, nullptr, 0.0, nullptr, nullptr, 0.0, e.d_Gw,
                         nullptr, 0, false, opt, s);
     if (*rc != CESX_OK) return nullptr;
-    e.gw_src = G; e.gw_stream = s;
+    e.gw_src = G; e.gw_stream = s; e.gw_calls = e.moments_calls;
     return e.d_Gw;
 }
 }  // namespace cesx
@@ -308,7 +309,6 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
     }
     e.colsum_slices = (int)std::min<long long>(16, (e.J + 1023) / 1024);
     if (e.colsum_slices < 1) e.colsum_slices = 1;
-    e.stats_blocks = (int)((e.J + 63) / 64);
     e.kp = (p + 15) / 16 * 16; e.kn = (n + 15) / 16 * 16; e.ktot = 2 * e.kp + e.kn;
     e.rpad = (mx + 255) / 256 * 256;
     e.mom_len = e.ml.len();                      // incl. lagged {sum q_r^2, sum q_e^2} of the previous apply
@@ -323,7 +323,6 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
         DM(t, P * e.esz); e.d_shiftT = t;
         DM(t, n * e.esz); e.d_yT = t;
         DM(t, n * e.esz); e.d_gwT = t;
-        DM(t, n * e.esz); e.d_gbarT = t;
         DM(t, (size_t)e.kn * 4 * e.esz); e.d_rowc = t;
         for (int part = 0; part < 2; ++part) {
             const GramPlan& pl = e.gp[part].plan;
@@ -353,10 +352,9 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
     DM(e.d_metric_sums, 2 * 8);
     DM(e.d_colsum_part, (size_t)P * e.colsum_slices * 8);
     DM(e.d_mom, e.mom_len * 8); DM(e.d_sums, (1 + P) * 8); DM(e.d_sums_w, (1 + P) * 8);
-    DM(e.d_ubar, p * 8); DM(e.d_gbar, n * 8); DM(e.d_m, n * 8); DM(e.d_dg, n * 8); DM(e.d_wdel, n * 8);
+    DM(e.d_ubar, p * 8); DM(e.d_gbar, n * 8); DM(e.d_m, n * 8); DM(e.d_dg, n * 8);
     DM(e.d_C, pp * 8); DM(e.d_L, (size_t)potrf_ld(p) * potrf_ld(p) * 8); DM(e.d_Cug, pn * 8); DM(e.d_See, nn * 8); DM(e.d_Srr, nn * 8);
     DM(e.d_K, pn * 8); DM(e.d_Kp, pn * 8); DM(e.d_M, pp * 8); DM(e.d_P, pp * 8); DM(e.d_PK, pn * 8);
-    { const size_t np_ = (size_t)(mx + 31) / 32 * 32; DM(e.d_Lp, np_ * np_ * 8); }
     if (potrf_ld(mx) > 256) DM(e.d_Lwork, (size_t)potrf_ld(mx) * potrf_ld(mx) * 8);
     DM(e.d_t1, mm * 8); DM(e.d_t2, mm * 8); DM(e.d_t3, mm * 8); DM(e.d_t4, mm * 8);
     if (potrf_ld(mx) <= 256) {          // warm-started SPD inverses (kernels_dense.hip, spd_inverse); zeroed: X_prev = 0 is a cold start
@@ -415,12 +413,12 @@ void cesx_destroy(cesx_handle h) {
     void* ptrs[] = {e.d_y, e.d_mu, e.d_ustar, e.d_Gamma, e.d_gw, e.d_Wh, e.d_Sigma, e.d_Sinv, e.d_sw,
                     e.d_shift64, e.d_shiftT, e.d_yT, e.d_gwT, e.d_W, e.d_Wf, e.d_Lwork, e.d_Wwh, e.d_Wwh_f, e.d_Gw, e.d_sums_w,
                     e.d_bias, e.d_Wfwd, e.d_Wfwd_f, e.d_bfwd, e.d_metric_part, e.d_metric_sums,
-                    e.d_gbarT, e.d_rowc,
+                    e.d_rowc,
                     e.d_colsum_part, e.d_mom,
                     e.gp[0].d_type_hdr, e.gp[0].d_rows, e.gp[0].d_wblk, e.gp[0].d_blk_rc, e.gp[0].d_row_own, e.gp[0].d_slabs, e.gp[0].d_rowsum_part,
                     e.gp[1].d_type_hdr, e.gp[1].d_rows, e.gp[1].d_wblk, e.gp[1].d_blk_rc, e.gp[1].d_row_own, e.gp[1].d_slabs, e.gp[1].d_rowsum_part, e.d_sums, e.d_ubar, e.d_gbar, e.d_m, e.d_dg,
-                    e.d_wdel, e.d_C, e.d_L, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_Kp, e.d_M, e.d_P, e.d_PK,
-                    e.d_t1, e.d_t2, e.d_t3, e.d_t4, e.d_Lp, e.d_spec, e.d_ns_xprev[0], e.d_ns_xprev[1], e.d_ns_r[0], e.d_ns_r[1], e.d_ns_r[2],
+                    e.d_C, e.d_L, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_Kp, e.d_M, e.d_P, e.d_PK,
+                    e.d_t1, e.d_t2, e.d_t3, e.d_t4, e.d_spec, e.d_ns_xprev[0], e.d_ns_xprev[1], e.d_ns_r[0], e.d_ns_r[1], e.d_ns_r[2],
                     e.d_ns_parts, e.d_ns_skip, e.d_mv, e.d_part, e.d_scal, e.d_absmax,
                     e.d_absmax_part, e.d_clk, e.d_cholflag, e.d_lag, e.d_A64, e.d_b64, e.d_lvec, e.d_Wq, e.d_ticket};
     for (void* q : ptrs)
@@ -816,11 +814,6 @@ int cesx_result(cesx_handle h, cesx_step_result* out) {
               "buffer had already been handed to a later cesx_moments* call: not re-run (include/cesx.h, lifetime rules)"
             : "the side stream's factorisation never signalled its completion (the polled join timed out)";
         return CESX_EHIP;
-    }
-    if (sc.status == CESX_ENOCONV) {
-        e.err = "time_step='spectral': the Lanczos iteration for the spectral radius did not converge "
-                "(residual > 1e-10 theta after the step cap); hk of this step is not reliable";
-        return CESX_ENOCONV;
     }
     return CESX_OK;
 }

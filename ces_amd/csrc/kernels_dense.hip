@@ -839,7 +839,7 @@ __global__ void assemble_kernel(int mode, int p, int n, int kp, int kn, int rpad
                                 const double* __restrict__ gbar, const double* __restrict__ y,
                                 const double* __restrict__ gw, T* __restrict__ W, T* __restrict__ bias,
                                 T* __restrict__ shiftT, double* __restrict__ shift64, T* __restrict__ rowc,
-                                T* __restrict__ gbarT, float* __restrict__ Wf) {
+                                float* __restrict__ Wf) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const double hk = sc->hk, s2 = sc->sqrt2hk, al = sc->alpha;
     const double* Ky = mvs;            // K y
@@ -894,7 +894,6 @@ __global__ void assemble_kernel(int mode, int p, int n, int kp, int kn, int rpad
         rowc[i * 4 + 1] = (T)(i < n ? y[i] : 0.0);
         rowc[i * 4 + 2] = (T)((i < n && gw != nullptr) ? gw[i] : 0.0);
         rowc[i * 4 + 3] = (T)0;
-        if (i < n) gbarT[i] = (T)gbar[i];
     }
     if (idx < p + n && mode != 3) {
         const int i = (int)idx;
@@ -928,7 +927,7 @@ void finish_aldi_kernel(MomView mv, cesx_step_params prm, const double* part, Sc
                         const double* __restrict__ y, const double* gbar, const double* __restrict__ mu,
                         const double* ubar, const double* __restrict__ gw, int mx, double* __restrict__ mvs,
                         T* __restrict__ W, T* __restrict__ bias, T* __restrict__ shiftT, double* __restrict__ shift64,
-                        T* __restrict__ rowc, T* __restrict__ gbarT, float* __restrict__ Wf,
+                        T* __restrict__ rowc, float* __restrict__ Wf,
                         const unsigned long long* fault, unsigned long long fault_seq) {
     static_assert(DT == NPB, "one partial per thread");
     __shared__ double red[DT / 64];
@@ -1001,7 +1000,6 @@ void finish_aldi_kernel(MomView mv, cesx_step_params prm, const double* part, Sc
         rowc[i * 4 + 1] = (T)(i < n ? y[i] : 0.0);
         rowc[i * 4 + 2] = (T)((i < n && gw != nullptr) ? gw[i] : 0.0);
         rowc[i * 4 + 3] = (T)0;
-        if (i < n) gbarT[i] = (T)gb;
     }
     if (idx >= p && idx < p + n) {
         const T st = (T)gbar[idx - p];
@@ -1041,7 +1039,7 @@ void tail_aldi_kernel(MomView mv, cesx_step_params prm, const double* shift, con
                       int self_u, const double* __restrict__ ustar, double* __restrict__ ubar, double* __restrict__ Cm,
                       double* __restrict__ Mm,
                       float* wq, int nkt, int kp, int kn, float* __restrict__ bias, float* shiftT, double* shift64,
-                      float* __restrict__ rowc, float* __restrict__ gbarT, unsigned* ticket,
+                      float* __restrict__ rowc, unsigned* ticket,
                       const unsigned long long* join, unsigned long long join_want, unsigned long long* fault,
                       unsigned long long join_ticks) {
     static_assert(DT == NPB, "one partial per thread");
@@ -1180,7 +1178,6 @@ void tail_aldi_kernel(MomView mv, cesx_step_params prm, const double* shift, con
             gbar[i] = gb;
             dg[i] = d;
             mvec[i] = gb - y[i];
-            gbarT[i] = (float)gb;
         }
         rowc[i * 4 + 0] = (float)gb;
         rowc[i * 4 + 1] = (float)(i < (unsigned)n ? y[i] : 0.0);
@@ -1821,7 +1818,7 @@ static int assemble(Engine& e, hipStream_t s, int mode, int ktot, double sw) {
     hipLaunchKernelGGL(assemble_kernel<T>, g1(len), dim3(256), 0, s, mode, e.p, e.n, e.kp, e.kn, e.rpad, ktot,
                        sw, e.d_scal, e.d_M, e.d_K, e.d_L, potrf_ld(e.p), e.d_P, e.d_PK, e.d_mv, mx, e.d_ubar, e.d_gbar,
                        e.d_y, (const double*)e.d_gw, (T*)e.d_W, (T*)e.d_bias,
-                       (T*)e.d_shiftT, e.d_shift64, (T*)e.d_rowc, (T*)e.d_gbarT,
+                       (T*)e.d_shiftT, e.d_shift64, (T*)e.d_rowc,
                        (float*)e.d_Wf);
     CESX_HIP(hipGetLastError());
     return CESX_OK;
@@ -1888,7 +1885,7 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
                            e.d_lag, e.d_mv, mx, (const double*)e.d_sw, e.diag_sigma ? (const double*)nullptr : (const double*)e.d_Sinv,
                            (const double*)e.d_mu, self_u, (const double*)e.d_ustar,
                            e.d_ubar, e.d_C, e.d_M, (float*)e.d_Wq, e.ktot / 16, e.kp,
-                           e.kn, (float*)e.d_bias, (float*)e.d_shiftT, e.d_shift64, (float*)e.d_rowc, (float*)e.d_gbarT,
+                           e.kn, (float*)e.d_bias, (float*)e.d_shiftT, e.d_shift64, (float*)e.d_rowc,
                            e.d_ticket, polled ? (const unsigned long long*)e.d_cholflag : (const unsigned long long*)nullptr,
                            (unsigned long long)e.chol_seq, e.d_cholflag + 1, e.poll_ticks);
         CESX_HIP(hipGetLastError());
@@ -1960,7 +1957,7 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
                                e.kp, e.kn, e.rpad, e.ktot, (const double*)e.d_M, (const double*)e.d_K, (const double*)e.d_L, potrf_ld(p),
                                (const double*)e.d_y, (const double*)e.d_gbar, (const double*)e.d_mu,
                                (const double*)e.d_ubar, (const double*)e.d_gw, mx, e.d_mv, (T*)e.d_W,
-                               (T*)e.d_bias, (T*)e.d_shiftT, e.d_shift64, (T*)e.d_rowc, (T*)e.d_gbarT, (float*)e.d_Wf,
+                               (T*)e.d_bias, (T*)e.d_shiftT, e.d_shift64, (T*)e.d_rowc, (float*)e.d_Wf,
                                (const unsigned long long*)(e.d_cholflag + 1), (unsigned long long)e.chol_seq);
         };
         auto pick = [&](auto tag) {
