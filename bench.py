@@ -478,9 +478,64 @@ def variants_leg(engine, p, n, J, dtype, dev_index, steps=10):
     for key, r in out.items():
         if base and "ms_per_step" in r:
             r["ratio_to_default"] = round(r["ms_per_step"] / base, 3)
+    try:
+        out["in_a_run"] = variants_in_a_run(engine, p, n, J, dtype, dev_index)
+    except Exception as ex:
+        out["in_a_run"] = dict(error=repr(ex))
     out["how"] = ("engine-only, %d timed steps each behind 0.25 s of continuous stepping, same shape and dtype as the headline; "
                   "time_step_mix_late: pseudo-time past the spin-up (delta_t and the recomputed gain of ces/calibrate.py:470-473)"
                   % steps)
+    return out
+
+
+def variants_in_a_run(engine, p, n, J, dtype, dev_index, T=120):
+    """The rules that carry an hk-dependent SPD inverse (`eks`, the gain-recomputing time steps), measured INSIDE A RUN: the
+    ensemble evolves (G = A U on the device, update, U_next fed back -- ShardedSampler.run, full Gram over [U; G]), so the
+    previous step's inverse is the close start it is in use; the ring of four unrelated ensembles of the legs above is the
+    warm start's worst case.  Ratio to the default ALDI step driven the same way.  (`mix`: the adaptive rule up to pseudo-time 1,
+    then delta_t and the recomputed gain, ces/calibrate.py:256-260 / :470-473 -- about a third of the steps are default ones.)"""
+    from ces_amd.dist import ShardedSampler
+    from ces_amd.utils import lineal
+    prob = synthetic_problem(p, n)
+    rng = np.random.default_rng(3)
+    U0 = prob["ustar"] + rng.standard_normal((p, J))
+    model = lineal(prob["A"])
+    out, dt = {}, None
+    os.environ["CESX_LINEAL_FAST"] = "0"
+    try:
+        for key, kw in (("aldi_default", dict(update="aldi")), ("eks", dict(update="eks")),
+                        ("time_step_constant", dict(update="aldi", time_step="constant")),
+                        ("time_step_mix", dict(update="aldi", time_step="mix", spinup=1.0))):
+            eng = engine.Engine(p, n, J, dtype=dtype, device=dev_index, seed=77)
+            try:
+              for steps, timed in ((8, False), (T, True)):
+                smp = ShardedSampler(eng, p, n, J)
+                smp.T = steps
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                smp.run(prob["y"], U0, model, prob["Gamma"], prob["mu"], prob["sigma"], prob["ustar"], t_tol=1e30,
+                        **(dict(kw, delta_t=dt) if "time_step" in kw else kw))
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t0
+            except Exception as ex:
+                out[key] = dict(error=repr(ex), steps_done=len(smp.metrics["t"]))
+                continue
+            out[key] = dict(ms_per_step=round(1e3 * el / T, 4), steps=T, last_inverse_warm=bool(eng.warm_inverse()))
+            if key == "aldi_default":          # the fixed step of the constant / mix rules: half the adaptive rule's last one
+                t = smp.metrics["t"]
+                dt = 0.5 * float(t[-1] - t[-2])
+            elif "time_step" in kw:
+                out[key]["delta_t"] = dt
+            del eng, smp
+            torch.cuda.empty_cache()
+    finally:
+        os.environ.pop("CESX_LINEAL_FAST", None)
+    base = out["aldi_default"].get("ms_per_step")
+    for r in out.values():
+        if base and "ms_per_step" in r:
+            r["ratio_to_default"] = round(r["ms_per_step"] / base, 3)
+    out["how"] = ("ShardedSampler.run, %d steps behind 8 untimed ones: forward map on the device, full Gram, update, feedback; "
+                  "includes one upload of U0" % T)
     return out
 
 

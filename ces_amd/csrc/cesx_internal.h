@@ -363,7 +363,9 @@ struct Engine {
     double *d_Wh = nullptr;        // L_Gamma^{-1} in fp64 (dense Gamma: the centring sums of a fresh ensemble are whitened with it)
     // warm-started SPD inverses of K2 (kernels_dense.hip, spd_inverse): the previous step's inverse of the gain matrix (0, n x n) and
     // of the EKS matrix (1, p x p), three n_max^2 scratch matrices, 2 x ceil(n_max/16)^2 residual partials, the verdict word
-    double *d_ns_xprev[2] = {nullptr, nullptr}, *d_ns_r[3] = {nullptr, nullptr, nullptr}, *d_ns_parts = nullptr;
+    double *d_ns_x[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // [which][ns_cur[which]]: the previous inverse; the other one: this step's
+    int ns_cur[2] = {0, 0};
+    double *d_ns_r[3] = {nullptr, nullptr, nullptr}, *d_ns_parts = nullptr;
     int* d_ns_skip = nullptr;
     bool ns_ok = true;             // CESX_NS_WARM=0: always the factorisation
     double ns_r0_last = 1e300;     // ||I - A X_prev||_F^2 of the last step's warm-start attempt (cesx_result reads it from the result block)

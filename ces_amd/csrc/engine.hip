@@ -360,7 +360,7 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
     if (potrf_ld(mx) <= 256) {          // warm-started SPD inverses (kernels_dense.hip, spd_inverse); zeroed: X_prev = 0 is a cold start
         if (const char* nv = std::getenv("CESX_NS_WARM")) e.ns_ok = nv[0] != '0';
         const size_t nb16 = ((size_t)mx + 15) / 16;
-        DM(e.d_ns_xprev[0], nn * 8); DM(e.d_ns_xprev[1], pp * 8);
+        for (int k = 0; k < 2; ++k) { DM(e.d_ns_x[0][k], nn * 8); DM(e.d_ns_x[1][k], pp * 8); }
         for (int k = 0; k < 3; ++k) DM(e.d_ns_r[k], (size_t)mx * mx * 8);
         DM(e.d_ns_parts, 2 * nb16 * nb16 * 8);
         { char* t; DM(t, 64); e.d_ns_skip = reinterpret_cast<int*>(t); }
@@ -418,7 +418,7 @@ void cesx_destroy(cesx_handle h) {
                     e.gp[0].d_type_hdr, e.gp[0].d_rows, e.gp[0].d_wblk, e.gp[0].d_blk_rc, e.gp[0].d_row_own, e.gp[0].d_slabs, e.gp[0].d_rowsum_part,
                     e.gp[1].d_type_hdr, e.gp[1].d_rows, e.gp[1].d_wblk, e.gp[1].d_blk_rc, e.gp[1].d_row_own, e.gp[1].d_slabs, e.gp[1].d_rowsum_part, e.d_sums, e.d_ubar, e.d_gbar, e.d_m, e.d_dg,
                     e.d_C, e.d_L, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_Kp, e.d_M, e.d_P, e.d_PK,
-                    e.d_t1, e.d_t2, e.d_t3, e.d_t4, e.d_spec, e.d_ns_xprev[0], e.d_ns_xprev[1], e.d_ns_r[0], e.d_ns_r[1], e.d_ns_r[2],
+                    e.d_t1, e.d_t2, e.d_t3, e.d_t4, e.d_spec, e.d_ns_x[0][0], e.d_ns_x[0][1], e.d_ns_x[1][0], e.d_ns_x[1][1], e.d_ns_r[0], e.d_ns_r[1], e.d_ns_r[2],
                     e.d_ns_parts, e.d_ns_skip, e.d_mv, e.d_part, e.d_scal, e.d_absmax,
                     e.d_absmax_part, e.d_clk, e.d_cholflag, e.d_lag, e.d_A64, e.d_b64, e.d_lvec, e.d_Wq, e.d_ticket};
     for (void* q : ptrs)
@@ -493,7 +493,9 @@ int cesx_set_problem(cesx_handle h, const double* y, const double* Gamma, const 
     TRY(upload(e, e.d_Sigma, Sigma, (size_t)p * p * 8)); TRY(upload(e, e.d_Sinv, inv.data(), (size_t)p * p * 8));
     TRY(upload(e, e.d_sw, sw.data(), p * 8));
     // a new problem: the warm starts of K2's SPD inverses (kernels_dense.hip, spd_inverse) start cold
-    if (e.d_ns_xprev[0]) { CESX_HIP(hipMemset(e.d_ns_xprev[0], 0, (size_t)n * n * 8)); CESX_HIP(hipMemset(e.d_ns_xprev[1], 0, (size_t)p * p * 8)); }
+    if (e.d_ns_x[0][0]) {
+        for (int k = 0; k < 2; ++k) { CESX_HIP(hipMemset(e.d_ns_x[0][k], 0, (size_t)n * n * 8)); CESX_HIP(hipMemset(e.d_ns_x[1][k], 0, (size_t)p * p * 8)); }
+    }
     e.problem_set = true;
     e.shift_valid = false;
     return CESX_OK;

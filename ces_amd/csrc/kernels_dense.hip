@@ -1707,16 +1707,31 @@ __device__ __forceinline__ gemm_d4_t ns_block(int n, const double* __restrict__ 
 }
 
 constexpr double NS_START2 = 16.0;      // ||I - A X_prev||_F^2 below which the warm start is tried
-constexpr double NS_CLOSE2 = 0.09;      // ... below which five sweeps are enough for the next step (seven otherwise)
 constexpr double NS_DONE2 = 1e-20;      // ||I - A X||_F^2 below which the result is accepted
 
-// R = I - A X, parts[workgroup] = sum of squares of its block of R.  gate != nullptr: only when sum(gate[0..npart)) < NS_START2
+// R = I - A X, parts[workgroup] = sum of squares of its block of R.  gate != nullptr: the closing residual -- formed only when
+// sum(gate[0..npart)) < NS_START2 (the warm start was tried), and the LAST workgroup to arrive writes the verdict:
+// skip[0] = 1 -- the warm start was taken AND its true residual passed: the factorisation chain behind has nothing to do;
+// sc->spare[3] = ||R_0||^2, published with the step's result (the host sizes the next step's sweeps with it; accum: the
+// larger of the step's two inverses).  skip[1] is the arrival counter (zero between launches).
 __global__ __launch_bounds__(DT)
 void ns_resid_kernel(int n, const double* __restrict__ A, const double* __restrict__ X, double* __restrict__ R,
-                     double* __restrict__ parts, const double* __restrict__ gate, int npart) {
+                     double* __restrict__ parts, const double* __restrict__ gate, int npart, int* __restrict__ skip,
+                     Scalars* __restrict__ sc, int accum) {
     __shared__ double red[DT / 64];
     __shared__ double part[3][4][64];
-    if (gate != nullptr && !(spec_norm2(gate, npart, red) < NS_START2)) return;
+    __shared__ int s_last;
+    double g0 = 0.0;
+    if (gate != nullptr) {
+        g0 = spec_norm2(gate, npart, red);
+        if (!(g0 < NS_START2)) {
+            if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+                skip[0] = 0;
+                sc->spare[3] = accum ? fmax(sc->spare[3], g0) : g0;
+            }
+            return;
+        }
+    }
     const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, lane = threadIdx.x & 63, kk = lane >> 4, j = c0 + (lane & 15);
     const gemm_d4_t acc = ns_block(n, A, X, r0, c0, part);
     double sq = 0.0;
@@ -1728,7 +1743,27 @@ void ns_resid_kernel(int n, const double* __restrict__ A, const double* __restri
         }
     }
     sq = dblock_sum(sq, red);
-    if (threadIdx.x == 0) parts[blockIdx.y * gridDim.x + blockIdx.x] = sq;
+    if (gate == nullptr) {
+        if (threadIdx.x == 0) parts[blockIdx.y * gridDim.x + blockIdx.x] = sq;
+        return;
+    }
+    // arrival: the partial goes out at agent scope (the last workgroup may sit on another XCD), then the ticket
+    if (threadIdx.x == 0) {
+        st_agent(parts + blockIdx.y * gridDim.x + blockIdx.x, sq);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(skip) + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = t == gridDim.x * gridDim.y - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    double rf = 0.0;
+    for (int i = threadIdx.x; i < npart; i += DT) rf += ld_agent(parts + i);
+    rf = dblock_sum(rf, red);          // (fixed order: the same verdict whichever workgroup arrives last)
+    if (threadIdx.x == 0) {
+        skip[0] = rf < NS_DONE2 ? 1 : 0;
+        sc->spare[3] = accum ? fmax(sc->spare[3], g0) : g0;
+        __hip_atomic_store(reinterpret_cast<unsigned*>(skip) + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // one sweep, both products in one launch: blockIdx.z == 0: Xn = X + X R;  1: Rn = R R
@@ -1753,47 +1788,49 @@ void ns_sweep_kernel(int n, const double* __restrict__ X, const double* __restri
     }
 }
 
-// skip[0] = 1: the warm start was taken AND its true residual passed -- the factorisation chain behind has nothing to do
-__global__ __launch_bounds__(DT)
-void ns_verdict_kernel(const double* __restrict__ parts0, const double* __restrict__ partsf, int npart, int* __restrict__ skip,
-                       Scalars* __restrict__ sc) {
-    __shared__ double red[DT / 64];
-    const double r0 = spec_norm2(parts0, npart, red);
-    const double rf = spec_norm2(partsf, npart, red);
-    if (threadIdx.x == 0) {
-        skip[0] = (r0 < NS_START2 && rf < NS_DONE2) ? 1 : 0;
-        sc->spare[3] = r0;          // published with the step's result: the host sizes the next step's sweeps with it
-    }
+// rows of X scaled by a diagonal: P = diag(d) X  (the EKS rule's Sigma (Sigma + hk C)^{-1} with a diagonal prior covariance)
+__global__ void scale_rows_kernel(int n, const double* __restrict__ D, int ldd, const double* __restrict__ X, double* __restrict__ P) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)n * n) return;
+    P[idx] = D[(size_t)(idx / n) * ldd] * X[idx];
 }
 
-__global__ void copy_kernel(long long len, const double* __restrict__ src, double* __restrict__ dst) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < len) dst[i] = src[i];
-}
-
-// Ainv = A^{-1} for SPD A (n x n).  which: 0 the recomputed gain's matrix, 1 the EKS rule's (each keeps its own previous inverse).
+// *Ainv = A^{-1} for SPD A (n x n).  which: 0 the recomputed gain's matrix, 1 the EKS rule's.  Each keeps two buffers: the
+// previous step's inverse (the warm start) and this step's result, which is the next step's start -- no copy.
 // Cold (or not converged): t1 (chol), t2 (X = L^{-T}),  A^{-1} = L^{-T} L^{-1} = X X^T.
-static int spd_inverse(Engine& e, hipStream_t s, int n, const double* A, double* Ainv, int which) {
+static int ns_sweeps(double r0sq) {
+    // the residual squares every sweep: r^(2^s) <= 1e-11 with r = 1.5 ||R_0||_F of the last step (the ensemble keeps moving)
+    const double r = 1.5 * std::sqrt(r0sq);
+    if (!(r < 0.9)) return 7;
+    if (!(r > 1e-6)) return 2;
+    const int s = (int)std::ceil(std::log2(std::log(1e-11) / std::log(r)));
+    return s < 2 ? 2 : s > 7 ? 7 : s;
+}
+
+static int spd_inverse(Engine& e, hipStream_t s, int n, const double* A, const double** Ainv, int which, bool accum) {
     int rc;
     const int np = potrf_ld(n);
-    const bool warm = np <= 256 && e.d_ns_xprev[which] != nullptr && e.ns_ok;
+    const bool keep = np <= 256 && e.d_ns_x[which][0] != nullptr;          // (larger: blocked factorisation, no warm start)
+    const bool warm = keep && e.ns_ok;
+    double* out = keep ? e.d_ns_x[which][e.ns_cur[which] ^ 1] : e.d_t4;
     if (warm) {
         const int nb = (n + 15) / 16, npart = nb * nb;
-        double* Xp = e.d_ns_xprev[which];
+        const double* Xp = e.d_ns_x[which][e.ns_cur[which]];
         double* parts0 = e.d_ns_parts, *partsf = e.d_ns_parts + npart;
         double* Rb[2] = {e.d_ns_r[0], e.d_ns_r[1]};
-        double* Xb[2] = {Ainv, e.d_ns_r[2]};
-        hipLaunchKernelGGL(ns_resid_kernel, dim3(nb, nb), dim3(DT), 0, s, n, A, (const double*)Xp, Rb[0], parts0, (const double*)nullptr, npart);
+        double* Xb[2] = {out, e.d_ns_r[2]};
+        hipLaunchKernelGGL(ns_resid_kernel, dim3(nb, nb), dim3(DT), 0, s, n, A, Xp, Rb[0], parts0, (const double*)nullptr, npart,
+                           (int*)nullptr, (Scalars*)nullptr, 0);
         const double* Xc = Xp;
-        const int sweeps = e.ns_r0_last < NS_CLOSE2 ? 5 : 7;          // (odd: X_1 -> Ainv, X_2 -> scratch, ..., the last one -> Ainv)
-        for (int it = 0; it < sweeps; ++it) {
-            hipLaunchKernelGGL(ns_sweep_kernel, dim3(nb, nb, 2), dim3(DT), 0, s, n, Xc, (const double*)Rb[it & 1], Xb[it & 1], Rb[(it & 1) ^ 1],
+        const int sweeps = ns_sweeps(e.ns_r0_last);
+        for (int it = 0; it < sweeps; ++it) {          // X_sweeps lands in out
+            double* Xn = Xb[(sweeps - 1 - it) & 1];
+            hipLaunchKernelGGL(ns_sweep_kernel, dim3(nb, nb, 2), dim3(DT), 0, s, n, Xc, (const double*)Rb[it & 1], Xn, Rb[(it & 1) ^ 1],
                                (const double*)parts0, npart);
-            Xc = Xb[it & 1];
+            Xc = Xn;
         }
-        hipLaunchKernelGGL(ns_resid_kernel, dim3(nb, nb), dim3(DT), 0, s, n, A, (const double*)Ainv, Rb[0], partsf, (const double*)parts0, npart);
-        hipLaunchKernelGGL(ns_verdict_kernel, dim3(1), dim3(DT), 0, s, (const double*)parts0, (const double*)partsf, npart, e.d_ns_skip,
-                           e.d_scal);
+        hipLaunchKernelGGL(ns_resid_kernel, dim3(nb, nb), dim3(DT), 0, s, n, A, (const double*)out, Rb[0], partsf, (const double*)parts0, npart,
+                           e.d_ns_skip, e.d_scal, accum ? 1 : 0);
         CESX_HIP(hipGetLastError());
         e.gate = e.d_ns_skip;
     }
@@ -1801,13 +1838,11 @@ static int spd_inverse(Engine& e, hipStream_t s, int n, const double* A, double*
     if (rc == CESX_OK) rc = trsm_right_lt(e, s, n, np, nullptr, 0, e.d_t1, np, e.d_t2, np);
     // X is upper triangular: X[i][k] = 0 for k < i; columns >= n of the rows < n are zero
     // (K split over the waves of a workgroup for the sizes of K2: 21 -> 7 us at n = 256)
-    if (rc == CESX_OK) rc = gemm(e, s, n, n, n, 1.0, e.d_t2, (long long)np, 1LL, e.d_t2, 1LL, (long long)np, Ainv);
+    if (rc == CESX_OK) rc = gemm(e, s, n, n, n, 1.0, e.d_t2, (long long)np, 1LL, e.d_t2, 1LL, (long long)np, out);
     e.gate = nullptr;
     if (rc != CESX_OK) return rc;
-    if (warm) {          // this step's inverse is the next one's start
-        hipLaunchKernelGGL(copy_kernel, g1((long long)n * n), dim3(256), 0, s, (long long)n * n, (const double*)Ainv, e.d_ns_xprev[which]);
-        CESX_HIP(hipGetLastError());
-    }
+    if (keep) e.ns_cur[which] ^= 1;
+    *Ainv = out;
     return CESX_OK;
 }
 
@@ -1975,13 +2010,16 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
     scalars_and_matvecs();
     CESX_HIP(hipGetLastError());
 
+    bool gain_inverse = false;
     if (phase == 0 && (prm.time_step == CESX_TS_CONSTANT || (prm.time_step == CESX_TS_MIX && prm.update == CESX_UPDATE_ALDI))) {
         // K' = C_ug (hk C_gg + Gamma)^{-1},  C_gg = See / N   (:440-441, :472-473)
         hipLaunchKernelGGL(axpb_kernel, g1((long long)n * n), dim3(256), 0, s, (long long)n * n, &e.d_scal->hk,
                            mom, e.d_See, e.d_Gamma, e.d_t3);
         CESX_HIP(hipGetLastError());
-        if ((rc = spd_inverse(e, s, n, e.d_t3, e.d_t4, 0))) return rc;
-        if ((rc = gemm(e, s, p, n, n, 1.0, e.d_Cug, n, 1, e.d_t4, n, 1, e.d_Kp))) return rc;
+        const double* inv;
+        if ((rc = spd_inverse(e, s, n, e.d_t3, &inv, 0, false))) return rc;
+        gain_inverse = true;
+        if ((rc = gemm(e, s, p, n, n, 1.0, e.d_Cug, n, 1, inv, n, 1, e.d_Kp))) return rc;
         hipLaunchKernelGGL(select_kernel, g1((long long)p * n), dim3(256), 0, s, (long long)p * n, e.d_scal, e.d_Kp, e.d_K);
         CESX_HIP(hipGetLastError());
         scalars_and_matvecs();          // K y and K gbar with the selected gain (scalars are recomputed identically)
@@ -1996,8 +2034,12 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
         hipLaunchKernelGGL(axpb_kernel, g1((long long)p * p), dim3(256), 0, s, (long long)p * p, &e.d_scal->hk,
                            (const double*)nullptr, e.d_C, e.d_Sigma, e.d_t3);
         CESX_HIP(hipGetLastError());
-        if ((rc = spd_inverse(e, s, p, e.d_t3, e.d_t4, 1))) return rc;
-        if ((rc = gemm(e, s, p, p, p, 1.0, e.d_Sigma, p, 1, e.d_t4, p, 1, e.d_P))) return rc;
+        const double* inv;
+        if ((rc = spd_inverse(e, s, p, e.d_t3, &inv, 1, gain_inverse))) return rc;
+        if (e.diag_sigma) {
+            hipLaunchKernelGGL(scale_rows_kernel, g1((long long)p * p), dim3(256), 0, s, p, (const double*)e.d_Sigma, p + 1, inv, e.d_P);
+            CESX_HIP(hipGetLastError());
+        } else if ((rc = gemm(e, s, p, p, p, 1.0, e.d_Sigma, p, 1, inv, p, 1, e.d_P))) return rc;
         if ((rc = gemm(e, s, p, n, p, 1.0, e.d_P, p, 1, e.d_K, n, 1, e.d_PK))) return rc;
         hipLaunchKernelGGL(hk_sum_kernel, g1(p), dim3(256), 0, s, p, e.d_scal, e.d_mv, e.d_mv + 2 * mx, e.d_mv + 5 * mx);
         hipLaunchKernelGGL(matvec_kernel, g1(p, 4), dim3(DT), 0, s, p, p, e.d_P, e.d_mv + 5 * mx, e.d_mv + 4 * mx);
