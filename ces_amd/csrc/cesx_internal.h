@@ -401,6 +401,7 @@ struct Engine {
     void* d_Wq = nullptr;          // [rpad][ktot] fragment-major (wf_index), fp32; zero outside what the kernels above write
     unsigned* d_ticket = nullptr;  // arrival counter of tail_aldi_kernel
     bool hkfree_ok = true;         // CESX_HKFREE=0 switches the path off
+    bool update_small = true;      // CESX_UPDATE_SMALL=0: update2_kernel also for out_rows <= 64 (dev A/B)
     bool side_img = false;         // the factorisation in flight stores L into d_Wq (launch_chol_async)
     bool last_hkfree = false;      // the last launch_dense took the path: the update launch reads d_Wq in the order [xi; U; G]
     void* d_Wfwd = nullptr;        // forward-map staging [npad][kp]

@@ -251,6 +251,7 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
     if (const char* fv = std::getenv("CESX_FUSE_CENTER")) { e.fuse_center_ok = fv[0] != '0'; e.fuse_center_auto = false; }
     if (const char* pv = std::getenv("CESX_POLL_JOIN")) e.poll_join_ok = pv[0] != '0';
     if (const char* hv = std::getenv("CESX_HKFREE")) e.hkfree_ok = hv[0] != '0';
+    if (const char* sv = std::getenv("CESX_UPDATE_SMALL")) e.update_small = sv[0] != '0';
     if (const char* dv = std::getenv("CESX_TEST_DROP_CHOL_SIGNAL")) e.test_drop_signal_at = (unsigned long long)std::max(0, std::atoi(dv));
     if (const char* tv = std::getenv("CESX_POLL_TIMEOUT_MS")) e.poll_ticks = (unsigned long long)std::max(1, std::atoi(tv)) * 100000ull;
     auto fail = [&](int rc) { g_create_err = e.err; cesx_destroy(reinterpret_cast<cesx_handle>(ep)); return rc; };
@@ -348,7 +349,7 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
         if ((rc = upload(e, gp.d_row_own, pl.row_own.data(), pl.row_own.size() * 4))) return fail(rc);
         DM(gp.d_rowsum_part, (size_t)pl.total_rs * P * 8);
     }
-    DM(e.d_metric_part, ((size_t)((e.J + 63) / 64) + 8) * 2 * 8);
+    DM(e.d_metric_part, ((size_t)((e.J + 31) / 32) + 8) * 2 * 8);
     DM(e.d_metric_sums, 2 * 8);
     DM(e.d_colsum_part, (size_t)P * e.colsum_slices * 8);
     DM(e.d_mom, e.mom_len * 8); DM(e.d_sums, (1 + P) * 8); DM(e.d_sums_w, (1 + P) * 8);

@@ -463,7 +463,8 @@ int launch_update(Engine& e, int out_rows, const void* W, int ktot, const void* 
 
 // upper bound of the number of workgroups of any update launch (sizes the partial-result buffers)
 int update_grid_blocks(Engine& e, int out_rows) {
-    const int bn = e.cfg.dtype == CESX_F32 ? UpdCfg<float>::WC * 32 : UpdCfg<double>::WC * 16;
+    int bn = e.cfg.dtype == CESX_F32 ? UpdCfg<float>::WC * 32 : UpdCfg<double>::WC * 16;
+    if (bn > 32) bn = 32;          // (update2s_kernel / update3s_kernel: 64 / 32 particles per workgroup)
     const int rc = 256;
     return (int)((e.J + bn - 1) / bn) * ((out_rows + rc - 1) / rc);
 }

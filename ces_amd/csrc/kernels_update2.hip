@@ -521,6 +521,184 @@ void update2_kernel(const Upd2Args a) {
 #undef U2_LDSP
 }
 
+// ---------------------------------------------------------------------------
+// K3 for SMALL coefficient matrices (out_rows <= 64, ktot <= 192: the reference's own problem sizes -- Darcy p = 64,
+// n = 50, examples/scripts/darcy-flow.py:97-105; BASELINE config C4).  update2_kernel walks 16-column k-tiles through a
+// 3-slot ring with one barrier per tile and two of its eight row blocks per wave pair: with 64 output rows two of its four
+// waves hold no block at all and every one of the 12 tiles is a DMA round trip with 32 MFMAs to hide behind (25 us at C4).
+// Here the WHOLE problem of a workgroup -- 64 rows x 64 particles x ktot -- is LDS resident: every DMA of W and [U; G; xi]
+// is issued up front (24 per wave), ONE wait, ONE barrier, then the MFMAs; wave (rb, cb) owns one 32 x 32 block.
+// Same W image (wf_index), same arguments, same Philox counters as update2_kernel; the triangular segment's zero blocks
+// are multiplied (0 x finite = 0).  Chosen by the SHAPE alone (launch_update2), so every call flow of a problem runs it.
+// ---------------------------------------------------------------------------
+constexpr int U2S_BN = 64;            // particles per workgroup
+constexpr int U2S_MAX_KT = 12;        // ktot <= 192
+template <bool NOISE, bool HKF>
+__global__ __launch_bounds__(U2_THREADS)
+void update2s_kernel(const Upd2Args a) {
+    using acc_t = Mfma<float>::acc_t;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nkt = a.nkt;
+    // [ W: nkt x 4 pieces (g, rb) of 1 KiB | X: ktot rows x 64 particles | rowc ktot x 16 B | bias 64 | comb 2 x 4 x 64 floats ]
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
+    const unsigned ldsx = lds0 + (unsigned)nkt * 4096u;
+    const char* const sW = smem;
+    float* const sX = reinterpret_cast<float*>(smem + (size_t)nkt * 4096);
+    float* const sRowc = reinterpret_cast<float*>(smem + (size_t)nkt * 8192);
+    float* const sBias = sRowc + (size_t)nkt * U2_BK * 4;
+    float* const comb = sBias + 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const long long jt0 = (long long)blockIdx.x * U2S_BN;
+    const int rb = wave & 1, cb = wave >> 1;
+    // every DMA first (into LDS only: harmless should the launch turn out to be faulted) ...
+    // W: piece pw = (kt, g, rb') -> image piece (kt * 16 + g * 8 + rb')
+    for (int pw = wave; pw < nkt * 4; pw += 4) {
+        const int kt = pw >> 2, g = (pw >> 1) & 1, rbp = pw & 1;
+        glds16s(reinterpret_cast<const char*>(a.Wf) + (size_t)(kt * 16 + g * 8 + rbp) * 1024, lane * 16, lds0 + pw * 1024);
+    }
+    // [U; G; xi]: piece px = 4 rows x 64 particles (256 B per row): lane = (row lane >> 4, 16-byte chunk lane & 15)
+    long long colc = jt0 + 4 * (lane & 15);
+    if (colc > a.J - 4) colc = a.J - 4;
+    for (int px = wave; px < nkt * 4; px += 4) {
+        const TileD d = make_tile<NOISE>(px >> 2, a);
+        if (d.noise) continue;
+        int row = d.r0 + (px & 3) * 4 + (lane >> 4);
+        row = row < d.rows ? row : d.rows - 1;          // padded rows meet zero columns of W
+        glds16(d.base + (size_t)row * a.J + colc, ldsx + px * 1024);
+    }
+    // ... then, in their shadow, everything else the workgroup reads from memory
+    // (a polled join of the side stream that ran out in front of this launch: W is stale, the output stays as it was)
+    const bool faulted = a.fault != nullptr && __hip_atomic_load(a.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.fault_seq;
+    if (a.clk != nullptr && blockIdx.x == 0 && wave == 0) {
+        const long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) { a.clk[0] = c0; a.clk[1] = r0; }
+    }
+    float hkf = 1.f, cres = 1.f;
+    if (HKF) {
+        const double hk = *a.hkp;
+        hkf = (float)hk;
+        cres = (float)(*a.s2p / hk);
+    }
+    const double c1 = a.add1 ? (a.c1p ? *a.c1p * a.c1i : a.c1i) : 0.0;
+    const double c2 = a.add2 ? (a.c2p ? *a.c2p * a.c2i : a.c2i) : 0.0;
+    const bool do_metrics = a.metric_part != nullptr;
+    const int met_t0 = a.metric_seg == 0 ? 0 : a.metric_seg == 1 ? a.kt1 : a.kt2;
+    const int met_t1 = a.metric_seg == 0 ? (a.kt1 < nkt ? a.kt1 : nkt) : a.metric_seg == 1 ? (a.kt2 < nkt ? a.kt2 : nkt) : nkt;
+    const int nrow_m = do_metrics ? (met_t1 - met_t0) * U2_BK : 0;
+    for (int i = tid; i < nrow_m * 4; i += U2_THREADS) sRowc[i] = a.rowc[i];
+    if (tid < 64) sBias[tid] = (a.bias && tid < a.out_rows) ? a.bias[tid] : 0.f;
+    if (NOISE) {
+        // xi rows by Philox4x32-10 + Box-Muller: item = (row quad of the tile, particle), the counters of update2_kernel
+        const unsigned long long gj0 = (unsigned long long)(a.j_offset + jt0);
+        for (int kt = 0; kt < nkt; ++kt) {
+            const TileD d = make_tile<NOISE>(kt, a);
+            if (!d.noise) continue;
+            const int jl = tid & 63, ql = tid >> 6;
+            const unsigned long long gj = gj0 + jl;
+            const uint4x r = philox4x32_10((uint32_t)gj, (uint32_t)(gj >> 32), (unsigned)(d.r0 / 4 + ql), a.step, a.seed_lo, a.seed_hi);
+            float z[4];
+            normal4(r, z);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sX[(size_t)(kt * 16 + 4 * ql + e) * U2S_BN + jl] = z[e];
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (faulted) return;
+
+    acc_t acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0;
+    const float* xb = sX + lh * U2S_BN + 32 * cb + li;
+    const char* wb = sW + rb * 1024 + lane * 16;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (HKF && kt == a.kt1) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] *= cres;
+        }
+        const f4 a0 = *reinterpret_cast<const f4*>(wb + (size_t)kt * 4096);
+        const f4 a1 = *reinterpret_cast<const f4*>(wb + (size_t)kt * 4096 + 2048);
+        const float* xk = xb + (size_t)kt * 16 * U2S_BN;
+        float b[8];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) b[v] = xk[2 * v * U2S_BN];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[v], b[v], acc, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[v], b[4 + v], acc, 0, 0, 0);
+    }
+    // data metrics of the G rows (the whole tile is resident): thread = (particle tid & 63, row group tid >> 6)
+    float mq_e = 0.f, mq_r = 0.f;
+    if (do_metrics) {
+        const float* xm = sX + (size_t)met_t0 * 16 * U2S_BN + (tid & 63);
+        for (int rr = tid >> 6; rr < nrow_m; rr += 4) {
+            const f4 rc = *reinterpret_cast<const f4*>(sRowc + (size_t)rr * 4);
+            const float x = xm[(size_t)rr * U2S_BN];
+            const float be = x - rc[0], br = x - rc[1];
+            mq_e += rc[2] * be * be;
+            mq_r += rc[2] * br * br;
+        }
+    }
+    // epilogue: lane holds rows (e & 3) + 8 (e >> 2) + 4 lh of its block for particle 32 cb + li
+    const long long j = jt0 + 32 * cb + li;
+    float amax = 0.f;
+    if (j < a.J) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            if (i < a.out_rows) {
+                const size_t o = (size_t)i * a.J + j;
+                float v = acc[e] + sBias[i];
+                if (HKF) v *= hkf;
+                if (a.add1) v += (float)c1 * a.add1[o];
+                if (a.add2) v += (float)c2 * a.add2[o];
+                a.out[o] = v;
+                const float av = v < 0 ? -v : v;
+                amax = av > amax ? av : amax;
+            }
+        }
+    }
+    if (do_metrics) {
+        comb[(tid >> 6) * U2S_BN + (tid & 63)] = mq_e;
+        comb[4 * U2S_BN + (tid >> 6) * U2S_BN + (tid & 63)] = mq_r;
+        __syncthreads();
+        if (wave == 0) {
+            double se = 0.0, sr = 0.0;
+            if (jt0 + lane < a.J) {
+                float qe = 0, qr = 0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) { qe += comb[g * U2S_BN + lane]; qr += comb[4 * U2S_BN + g * U2S_BN + lane]; }
+                se = (double)qe * (double)qe;
+                sr = (double)qr * (double)qr;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { se += __shfl_down(se, o, 64); sr += __shfl_down(sr, o, 64); }
+            if (lane == 0) { a.metric_part[blockIdx.x * 2 + 0] = sr; a.metric_part[blockIdx.x * 2 + 1] = se; }
+        }
+        __syncthreads();
+    }
+    if (a.absmax_part) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float other = __shfl_down(amax, o, 64);
+            amax = other > amax ? other : amax;
+        }
+        if (lane == 0) comb[wave] = amax;
+        __syncthreads();
+        if (tid == 0) {
+            float m = comb[0];
+            for (int w = 1; w < U2_THREADS / 64; ++w) m = comb[w] > m ? comb[w] : m;
+            a.absmax_part[blockIdx.x] = (double)m;
+        }
+    }
+    if (a.clk != nullptr && blockIdx.x == 0 && wave == 0) {
+        const long long c1k = __builtin_amdgcn_s_memtime(), r1k = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) { a.clk[2] = c1k; a.clk[3] = r1k; }
+    }
+}
+
 bool update2_qualifies(const Engine& e, const void* U, const void* G, const void* xi, const void* Unext) {
     if (e.cfg.dtype != CESX_F32 || !e.update_v2) return false;
     if (e.J % 4 != 0 || e.J < 4 || e.ktot % U2_BK != 0) return false;
@@ -571,11 +749,29 @@ int launch_update2(Engine& e, int out_rows, const void* Wf, int ktot, const void
     a.fault = opt.fault; a.fault_seq = opt.fault_seq;
     a.hkp = opt.hkp; a.s2p = opt.s2p;
     if (opt.hkp && (!opt.s2p || nsrc != 3 || a.tri_seg != 0 || add1 || add2)) { e.err = "update: the hk-free form needs [xi | U | G] with the triangular segment first"; return CESX_EINVAL; }
+    const bool noise = kind[0] != 0 || kind[1] != 0 || kind[2] != 0;
+    if (out_rows <= 64 && a.nkt <= U2S_MAX_KT && e.J < (1ll << 26) && e.update_small) {
+        // small coefficient matrix: the whole problem of a workgroup LDS resident (update2s_kernel)
+        const int lds_s = a.nkt * 8192 + (a.nkt * U2_BK * 4 + 64 + 2 * 4 * U2S_BN) * 4;
+        dim3 grid_s((unsigned)((e.J + U2S_BN - 1) / U2S_BN));
+        auto kern = opt.hkp ? (noise ? update2s_kernel<true, true> : update2s_kernel<false, true>)
+                            : (noise ? update2s_kernel<true, false> : update2s_kernel<false, false>);
+        CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_s));
+        e.last_update_grid_x = (int)grid_s.x;
+        e.last_update_grid = (int)grid_s.x;
+        {
+            ProfScope prof(e, opt.prof, s, true);
+            a.clk = (prof.a && prof.b) ? e.d_clk : nullptr;
+            if (prof.on()) hipExtLaunchKernelGGL(kern, grid_s, dim3(U2_THREADS), (unsigned)lds_s, s, prof.a, prof.b, 0, a);
+            else hipLaunchKernelGGL(kern, grid_s, dim3(U2_THREADS), lds_s, s, a);
+        }
+        CESX_HIP(hipGetLastError());
+        return CESX_OK;
+    }
     dim3 grid((unsigned)((e.J + U2_BN - 1) / U2_BN), (unsigned)((out_rows + U2_RC - 1) / U2_RC));
     // the dispatcher gives every CU one workgroup before any CU gets its second: from there on start late
     a.stagger_from = (long long)grid.x * grid.y > e.num_cus ? e.num_cus : 0x7fffffff;
     a.stagger_n = 2;
-    const bool noise = kind[0] != 0 || kind[1] != 0 || kind[2] != 0;
     auto kern = opt.hkp ? (noise ? update2_kernel<true, true> : update2_kernel<false, true>)
                         : (noise ? update2_kernel<true, false> : update2_kernel<false, false>);
     CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

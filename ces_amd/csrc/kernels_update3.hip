@@ -267,6 +267,153 @@ void update3_kernel(const Upd3Args a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// K3 in fp64 for SMALL coefficient matrices (out_rows <= 64, ktot <= 192; see update2s_kernel in kernels_update2.hip: the
+// reference's own problem sizes, and fp64 is the drop-in class's default dtype).  update3_kernel gives each wave ONE of its
+// four row blocks there and walks 12 k-tiles through the ring: 23 us at C4.  Here a workgroup owns 64 rows x 32 particles:
+// the whole [U; G; xi] tile (ktot x 32 doubles <= 48 KiB) is LDS resident -- every DMA issued up front, one wait, one
+// barrier --, wave w keeps ALL A fragments of row block w in registers (24 16-byte loads from the fragment-major image)
+// and owns two 16 x 16 blocks.  Same image (wd_index) and arguments as update3_kernel; chosen by the shape alone.
+// ---------------------------------------------------------------------------
+constexpr int U3S_BN = 32;
+constexpr int U3S_MAX_KT = 12;
+__global__ __launch_bounds__(U3_THREADS)
+void update3s_kernel(const Upd3Args a) {
+    using d4 = double __attribute__((ext_vector_type(4)));
+    using d2 = double __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nkt = a.nkt;
+    // [ X: ktot rows x 32 particles (256 B per row) | rowc ktot x 32 B | bias 64 | comb 2 x 8 x 32 ]
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
+    const double* const sX = reinterpret_cast<const double*>(smem);
+    double* const sRowc = reinterpret_cast<double*>(smem + (size_t)nkt * 4096);
+    double* const sBias = sRowc + (size_t)nkt * U3_BK * 4;
+    double* const comb = sBias + 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lr = lane >> 4;
+    const long long jt0 = (long long)blockIdx.x * U3S_BN;
+    // every DMA first: piece px = 4 rows x 32 particles; lane = (row lane >> 4, 16-byte chunk lane & 15)
+    long long colc = jt0 + 2 * (lane & 15);
+    if (colc > a.J - 2) colc = a.J - 2;
+    for (int px = wave; px < nkt * 4; px += 4) {
+        const int t = px >> 2;
+        const int b1 = t >= a.kt1 ? 1 : 0, b2 = t >= a.kt2 ? 1 : 0;
+        const int r0 = (t - (b1 * a.kt1 + b2 * (a.kt2 - a.kt1))) * U3_BK;
+        const int rows = a.rows0 + b1 * (a.rows1 - a.rows0) + b2 * (a.rows2 - a.rows1);
+        const long long p0 = (long long)a.src0, p1 = (long long)a.src1, p2 = (long long)a.src2;
+        const double* base = (const double*)(p0 + b1 * (p1 - p0) + b2 * (p2 - p1));
+        int row = r0 + (px & 3) * 4 + (lane >> 4);
+        row = row < rows ? row : rows - 1;          // padded rows meet zero columns of W
+        glds16(base + (size_t)row * a.J + colc, lds0 + px * 1024);
+    }
+    // A fragments of row block `wave`, every k-tile: two 16-byte loads per tile (k-steps 0,1 and 2,3)
+    d2 af[U3S_MAX_KT][2];
+    const double* const wbase = a.Wd + lane * 2 + (size_t)wave * 256;          // 256 doubles per (rb, kt)
+#pragma unroll
+    for (int t = 0; t < U3S_MAX_KT; ++t) {
+        const int tt = t < nkt ? t : nkt - 1;
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) af[t][sp] = *reinterpret_cast<const d2*>(wbase + (size_t)tt * 16 * 256 + sp * 128);
+    }
+    const bool faulted = a.fault != nullptr && __hip_atomic_load(a.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.fault_seq;
+    if (a.clk != nullptr && blockIdx.x == 0 && wave == 0) {
+        const long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) { a.clk[0] = c0; a.clk[1] = r0; }
+    }
+    const double c1 = a.add1 ? (a.c1p ? *a.c1p * a.c1i : a.c1i) : 0.0;
+    const double c2 = a.add2 ? (a.c2p ? *a.c2p * a.c2i : a.c2i) : 0.0;
+    const bool do_metrics = a.metric_part != nullptr;
+    const int met_t0 = a.metric_seg == 0 ? 0 : a.metric_seg == 1 ? a.kt1 : a.kt2;
+    const int met_t1 = a.metric_seg == 0 ? (a.kt1 < nkt ? a.kt1 : nkt) : a.metric_seg == 1 ? (a.kt2 < nkt ? a.kt2 : nkt) : nkt;
+    const int nrow_m = do_metrics ? (met_t1 - met_t0) * U3_BK : 0;
+    for (int i = tid; i < nrow_m * 4; i += U3_THREADS) sRowc[i] = a.rowc[i];
+    if (tid < 64) sBias[tid] = (a.bias && tid < a.out_rows) ? a.bias[tid] : 0.0;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (faulted) return;
+
+    d4 acc[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[c][e] = 0;
+    const double* xb = sX + (size_t)lr * U3S_BN + li;
+#pragma unroll
+    for (int t = 0; t < U3S_MAX_KT; ++t) {
+        if (t < nkt) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const double* xk = xb + (size_t)(t * 16 + 4 * s) * U3S_BN;
+                const double av = af[t][s >> 1][s & 1];
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, xk[0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, xk[16], acc[1], 0, 0, 0);
+            }
+        }
+    }
+    // data metrics of the G rows: thread = (particle tid & 31, row group tid >> 5)
+    double mq_e = 0.0, mq_r = 0.0;
+    if (do_metrics) {
+        const double* xm = sX + (size_t)met_t0 * 16 * U3S_BN + (tid & 31);
+        for (int rr = tid >> 5; rr < nrow_m; rr += 8) {
+            const double* rc = sRowc + (size_t)rr * 4;
+            const double x = xm[(size_t)rr * U3S_BN];
+            const double be = x - rc[0], br = x - rc[1];
+            mq_e += rc[2] * be * be;
+            mq_r += rc[2] * br * br;
+        }
+    }
+    // epilogue: lane holds rows lr + 4 e of row block `wave` for particles 16 c + li
+    double amax = 0.0;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const long long j = jt0 + 16 * c + li;
+        if (j < a.J) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = wave * 16 + lr + 4 * e;
+                if (i < a.out_rows) {
+                    const size_t o = (size_t)i * a.J + j;
+                    double v = acc[c][e] + sBias[i];
+                    if (a.add1) v += c1 * a.add1[o];
+                    if (a.add2) v += c2 * a.add2[o];
+                    a.out[o] = v;
+                    amax = fmax(amax, fabs(v));
+                }
+            }
+        }
+    }
+    if (do_metrics) {
+        comb[(tid >> 5) * U3S_BN + (tid & 31)] = mq_e;
+        comb[8 * U3S_BN + (tid >> 5) * U3S_BN + (tid & 31)] = mq_r;
+        __syncthreads();
+        if (wave == 0) {
+            double se = 0.0, sr = 0.0;
+            if (lane < U3S_BN && jt0 + lane < a.J) {
+                double qe = 0, qr = 0;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) { qe += comb[g * U3S_BN + lane]; qr += comb[8 * U3S_BN + g * U3S_BN + lane]; }
+                se = qe * qe;
+                sr = qr * qr;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { se += __shfl_down(se, o, 64); sr += __shfl_down(sr, o, 64); }
+            if (lane == 0) { a.metric_part[blockIdx.x * 2 + 0] = sr; a.metric_part[blockIdx.x * 2 + 1] = se; }
+        }
+        __syncthreads();
+    }
+    if (a.absmax_part) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = fmax(amax, __shfl_down(amax, o, 64));
+        if (lane == 0) comb[wave] = amax;
+        __syncthreads();
+        if (tid == 0) a.absmax_part[blockIdx.x] = fmax(fmax(comb[0], comb[1]), fmax(comb[2], comb[3]));
+    }
+    if (a.clk != nullptr && blockIdx.x == 0 && wave == 0) {
+        const long long c1k = __builtin_amdgcn_s_memtime(), r1k = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) { a.clk[2] = c1k; a.clk[3] = r1k; }
+    }
+}
+
 // returns CESX_OK, an error, or -1 when the launch does not qualify (caller falls back to update_kernel)
 int launch_update3(Engine& e, int out_rows, const void* Wd, int ktot, const void* bias,
                    const UpdateSrc* src, int nsrc,
@@ -305,6 +452,22 @@ int launch_update3(Engine& e, int out_rows, const void* Wd, int ktot, const void
     a.metric_part = metrics ? e.d_metric_part : nullptr;
     a.metric_seg = opt.metric_seg;
     a.fault = opt.fault; a.fault_seq = opt.fault_seq;
+    if (out_rows <= 64 && a.nkt <= U3S_MAX_KT && e.update_small) {
+        // small coefficient matrix: the whole tile of a workgroup LDS resident, W in registers (update3s_kernel)
+        const int lds_s = a.nkt * 4096 + (a.nkt * U3_BK * 4 + 64 + 2 * 8 * U3S_BN) * 8;
+        dim3 grid_s((unsigned)((e.J + U3S_BN - 1) / U3S_BN));
+        CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(update3s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_s));
+        e.last_update_grid_x = (int)grid_s.x;
+        e.last_update_grid = (int)grid_s.x;
+        {
+            ProfScope prof(e, opt.prof, s, true);
+            a.clk = (prof.a && prof.b) ? e.d_clk : nullptr;
+            if (prof.on()) hipExtLaunchKernelGGL(update3s_kernel, grid_s, dim3(U3_THREADS), (unsigned)lds_s, s, prof.a, prof.b, 0, a);
+            else hipLaunchKernelGGL(update3s_kernel, grid_s, dim3(U3_THREADS), lds_s, s, a);
+        }
+        CESX_HIP(hipGetLastError());
+        return CESX_OK;
+    }
     dim3 grid((unsigned)((e.J + U3_BN - 1) / U3_BN), (unsigned)((out_rows + U3_RC - 1) / U3_RC));
     CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(update3_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));

@@ -7,7 +7,7 @@ fn = sorted(glob.glob(d + "/*/*_kernel_trace.csv") + glob.glob(d + "/*_kernel_tr
 rows = list(csv.DictReader(open(fn)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 def short(n): return n.replace("void ", "").replace("cesx::", "").split("<")[0].split("(")[0]
-k3 = [i for i, r in enumerate(rows) if "update2_kernel" in r["Kernel_Name"] or "update3_kernel" in r["Kernel_Name"]]
+k3 = [i for i, r in enumerate(rows) if "update2_kernel" in r["Kernel_Name"] or "update2s_kernel" in r["Kernel_Name"] or "update3_kernel" in r["Kernel_Name"]]
 if not k3:
     k3 = [i for i, r in enumerate(rows) if "update_kernel" in r["Kernel_Name"]]
 i0, i1 = k3[-2 - nst] + 1, k3[-2] + 3
