@@ -633,6 +633,39 @@ def test_update_kernels_v1_v2_match(eng_mod, monkeypatch, update, shape, dtype, 
     assert outs[1][1:] == pytest.approx(outs[0][1:], rel=tol)
 
 
+@pytest.mark.parametrize("dtype,tol", [("float32", 1e-5), ("float64", 1e-12)])
+@pytest.mark.parametrize("update,prefetch", [("aldi", True), ("aldi", False), ("eks", True), ("aldi_constant", True)])
+@pytest.mark.parametrize("shape", [(64, 50, 8192), (40, 24, 200), (16, 150, 1000), (33, 17, 260)])
+def test_small_update_kernels_match_the_tiled_ones(eng_mod, monkeypatch, update, prefetch, shape, dtype, tol):
+    """K3 for coefficient matrices of at most 64 rows and 192 columns (update2s_kernel / update3s_kernel: the workgroup's
+    whole tile LDS resident -- the reference's own problem sizes, examples/scripts/darcy-flow.py:97-105) against the tiled
+    LDS-DMA kernels (CESX_UPDATE_SMALL=0) on the same step: ragged J (not a multiple of the 64 / 32 particles of a
+    workgroup), p < 64, the widest G segment that still qualifies (n = 150), the noise block read from memory and
+    (fp32) drawn in the kernel, the hk-free and the assembled coefficient images, both passes of `aldi_constant`."""
+    p, n, J = shape
+    d = _synthetic(p, n, J, seed=23)
+    if not prefetch:
+        monkeypatch.setenv("CESX_NO_NOISE_PREFETCH", "1")
+    outs = []
+    for small in ("1", "0"):
+        monkeypatch.setenv("CESX_UPDATE_SMALL", small)
+        eng = eng_mod.Engine(p, n, J, dtype=dtype, seed=5)
+        eng.set_problem(d["y"], d["Gamma"], d["mu"], d["sigma"], d["ustar"])
+        U, chain = eng.to_device(d["U0"]), []
+        G = eng.to_device(d["G"])
+        t_last = 0.0
+        for i in range(2):
+            prm = eng_mod.step_params(update=update, step_index=4 + i, first_step=(i == 0), t_len=i, t_last=t_last)
+            U = eng.step(prm, U, G, xi=None, recenter=(i == 0))
+            res = eng.result()
+            t_last = res.t_new
+            chain.append((res.hk, res.bias_data, res.self_bias_data))
+        outs.append((U.cpu().numpy(), chain))
+    assert rel_err(outs[1][0], outs[0][0]) < 20 * tol          # (two steps: the second one starts from the first one's rounding)
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert a == pytest.approx(b, rel=20 * tol)
+
+
 def test_comm_overlap_stream_path_matches(eng_mod, monkeypatch):
     """ShardedUpdate with the head all-reduce + chol(C) on a second stream (the multi-GPU path,
     forced here on one rank) gives bit-identical steps to the in-order path."""
