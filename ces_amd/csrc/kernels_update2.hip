@@ -553,7 +553,23 @@ void update2s_kernel(const Upd2Args a) {
     const int li = lane & 31, lh = lane >> 5;
     const long long jt0 = (long long)blockIdx.x * U2S_BN;
     const int rb = wave & 1, cb = wave >> 1;
-    // every DMA first (into LDS only: harmless should the launch turn out to be faulted) ...
+    // What the workgroup reads into REGISTERS goes first (the fault word, hk, the row constants, the bias), then every DMA:
+    // one batch in flight, one wait -- a load issued behind the DMAs would be waited for with them (vmcnt retires in order),
+    // and five dependent round trips in front of the MFMAs were a third of this kernel's first version.
+    // (a polled join of the side stream that ran out in front of this launch: W is stale, the output stays as it was)
+    unsigned long long fword = 0;
+    if (a.fault != nullptr) fword = __hip_atomic_load(a.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double hk = 1.0, s2 = 1.0;
+    if (HKF) { hk = *a.hkp; s2 = *a.s2p; }
+    const double c1v = a.add1 && a.c1p ? *a.c1p : 1.0, c2v = a.add2 && a.c2p ? *a.c2p : 1.0;
+    const bool do_metrics = a.metric_part != nullptr;
+    const int met_t0 = a.metric_seg == 0 ? 0 : a.metric_seg == 1 ? a.kt1 : a.kt2;
+    const int met_t1 = a.metric_seg == 0 ? (a.kt1 < nkt ? a.kt1 : nkt) : a.metric_seg == 1 ? (a.kt2 < nkt ? a.kt2 : nkt) : nkt;
+    const int nrow_m = do_metrics ? (met_t1 - met_t0) * U2_BK : 0;          // <= 192 rows: at most 3 floats of rowc per thread
+    float rcv[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) rcv[q] = tid + q * U2_THREADS < nrow_m * 4 ? a.rowc[tid + q * U2_THREADS] : 0.f;
+    const float biasv = (a.bias && tid < a.out_rows && tid < 64) ? a.bias[tid] : 0.f;
     // W: piece pw = (kt, g, rb') -> image piece (kt * 16 + g * 8 + rb')
     for (int pw = wave; pw < nkt * 4; pw += 4) {
         const int kt = pw >> 2, g = (pw >> 1) & 1, rbp = pw & 1;
@@ -569,27 +585,10 @@ void update2s_kernel(const Upd2Args a) {
         row = row < d.rows ? row : d.rows - 1;          // padded rows meet zero columns of W
         glds16(d.base + (size_t)row * a.J + colc, ldsx + px * 1024);
     }
-    // ... then, in their shadow, everything else the workgroup reads from memory
-    // (a polled join of the side stream that ran out in front of this launch: W is stale, the output stays as it was)
-    const bool faulted = a.fault != nullptr && __hip_atomic_load(a.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.fault_seq;
     if (a.clk != nullptr && blockIdx.x == 0 && wave == 0) {
         const long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
         if (lane == 0) { a.clk[0] = c0; a.clk[1] = r0; }
     }
-    float hkf = 1.f, cres = 1.f;
-    if (HKF) {
-        const double hk = *a.hkp;
-        hkf = (float)hk;
-        cres = (float)(*a.s2p / hk);
-    }
-    const double c1 = a.add1 ? (a.c1p ? *a.c1p * a.c1i : a.c1i) : 0.0;
-    const double c2 = a.add2 ? (a.c2p ? *a.c2p * a.c2i : a.c2i) : 0.0;
-    const bool do_metrics = a.metric_part != nullptr;
-    const int met_t0 = a.metric_seg == 0 ? 0 : a.metric_seg == 1 ? a.kt1 : a.kt2;
-    const int met_t1 = a.metric_seg == 0 ? (a.kt1 < nkt ? a.kt1 : nkt) : a.metric_seg == 1 ? (a.kt2 < nkt ? a.kt2 : nkt) : nkt;
-    const int nrow_m = do_metrics ? (met_t1 - met_t0) * U2_BK : 0;
-    for (int i = tid; i < nrow_m * 4; i += U2_THREADS) sRowc[i] = a.rowc[i];
-    if (tid < 64) sBias[tid] = (a.bias && tid < a.out_rows) ? a.bias[tid] : 0.f;
     if (NOISE) {
         // xi rows by Philox4x32-10 + Box-Muller: item = (row quad of the tile, particle), the counters of update2_kernel
         const unsigned long long gj0 = (unsigned long long)(a.j_offset + jt0);
@@ -605,6 +604,13 @@ void update2s_kernel(const Upd2Args a) {
             for (int e = 0; e < 4; ++e) sX[(size_t)(kt * 16 + 4 * ql + e) * U2S_BN + jl] = z[e];
         }
     }
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        if (tid + q * U2_THREADS < nrow_m * 4) sRowc[tid + q * U2_THREADS] = rcv[q];
+    if (tid < 64) sBias[tid] = biasv;
+    const bool faulted = a.fault != nullptr && fword == a.fault_seq;
+    const float hkf = (float)hk, cres = (float)(s2 / hk);
+    const double c1 = a.add1 ? c1v * a.c1i : 0.0, c2 = a.add2 ? c2v * a.c2i : 0.0;
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (faulted) return;
 
@@ -613,21 +619,30 @@ void update2s_kernel(const Upd2Args a) {
     for (int e = 0; e < 16; ++e) acc[e] = 0;
     const float* xb = sX + lh * U2S_BN + 32 * cb + li;
     const char* wb = sW + rb * 1024 + lane * 16;
+    // operands of tile kt + 1 are read before the MFMAs of tile kt (one wave per SIMD: nothing else covers the LDS latency)
+    f4 a0 = *reinterpret_cast<const f4*>(wb), a1 = *reinterpret_cast<const f4*>(wb + 2048);
+    float b[8];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) b[v] = xb[2 * v * U2S_BN];
     for (int kt = 0; kt < nkt; ++kt) {
         if (HKF && kt == a.kt1) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] *= cres;
         }
-        const f4 a0 = *reinterpret_cast<const f4*>(wb + (size_t)kt * 4096);
-        const f4 a1 = *reinterpret_cast<const f4*>(wb + (size_t)kt * 4096 + 2048);
-        const float* xk = xb + (size_t)kt * 16 * U2S_BN;
-        float b[8];
+        const int kn = kt + 1 < nkt ? kt + 1 : kt;
+        const f4 n0 = *reinterpret_cast<const f4*>(wb + (size_t)kn * 4096);
+        const f4 n1 = *reinterpret_cast<const f4*>(wb + (size_t)kn * 4096 + 2048);
+        const float* xk = xb + (size_t)kn * 16 * U2S_BN;
+        float nb[8];
 #pragma unroll
-        for (int v = 0; v < 8; ++v) b[v] = xk[2 * v * U2S_BN];
+        for (int v = 0; v < 8; ++v) nb[v] = xk[2 * v * U2S_BN];
 #pragma unroll
         for (int v = 0; v < 4; ++v) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[v], b[v], acc, 0, 0, 0);
 #pragma unroll
         for (int v = 0; v < 4; ++v) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[v], b[4 + v], acc, 0, 0, 0);
+        a0 = n0; a1 = n1;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) b[v] = nb[v];
     }
     // data metrics of the G rows (the whole tile is resident): thread = (particle tid & 63, row group tid >> 6)
     float mq_e = 0.f, mq_r = 0.f;

@@ -293,7 +293,29 @@ void update3s_kernel(const Upd3Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lr = lane >> 4;
     const long long jt0 = (long long)blockIdx.x * U3S_BN;
-    // every DMA first: piece px = 4 rows x 32 particles; lane = (row lane >> 4, 16-byte chunk lane & 15)
+    // what the workgroup reads into REGISTERS goes first (fault word, scalars, row constants, bias, the A fragments), then
+    // every DMA: one batch in flight, one wait (see update2s_kernel)
+    unsigned long long fword = 0;
+    if (a.fault != nullptr) fword = __hip_atomic_load(a.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double c1v = a.add1 && a.c1p ? *a.c1p : 1.0, c2v = a.add2 && a.c2p ? *a.c2p : 1.0;
+    const bool do_metrics = a.metric_part != nullptr;
+    const int met_t0 = a.metric_seg == 0 ? 0 : a.metric_seg == 1 ? a.kt1 : a.kt2;
+    const int met_t1 = a.metric_seg == 0 ? (a.kt1 < nkt ? a.kt1 : nkt) : a.metric_seg == 1 ? (a.kt2 < nkt ? a.kt2 : nkt) : nkt;
+    const int nrow_m = do_metrics ? (met_t1 - met_t0) * U3_BK : 0;          // <= 192 rows: at most 3 doubles of rowc per thread
+    double rcv[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) rcv[q] = tid + q * U3_THREADS < nrow_m * 4 ? a.rowc[tid + q * U3_THREADS] : 0.0;
+    const double biasv = (a.bias && tid < a.out_rows && tid < 64) ? a.bias[tid] : 0.0;
+    // A fragments of row block `wave`, every k-tile: two 16-byte loads per tile (k-steps 0,1 and 2,3)
+    d2 af[U3S_MAX_KT][2];
+    const double* const wbase = a.Wd + lane * 2 + (size_t)wave * 256;          // 256 doubles per (rb, kt)
+#pragma unroll
+    for (int t = 0; t < U3S_MAX_KT; ++t) {
+        const int tt = t < nkt ? t : nkt - 1;
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) af[t][sp] = *reinterpret_cast<const d2*>(wbase + (size_t)tt * 16 * 256 + sp * 128);
+    }
+    // [U; G; xi]: piece px = 4 rows x 32 particles; lane = (row lane >> 4, 16-byte chunk lane & 15)
     long long colc = jt0 + 2 * (lane & 15);
     if (colc > a.J - 2) colc = a.J - 2;
     for (int px = wave; px < nkt * 4; px += 4) {
@@ -307,28 +329,16 @@ void update3s_kernel(const Upd3Args a) {
         row = row < rows ? row : rows - 1;          // padded rows meet zero columns of W
         glds16(base + (size_t)row * a.J + colc, lds0 + px * 1024);
     }
-    // A fragments of row block `wave`, every k-tile: two 16-byte loads per tile (k-steps 0,1 and 2,3)
-    d2 af[U3S_MAX_KT][2];
-    const double* const wbase = a.Wd + lane * 2 + (size_t)wave * 256;          // 256 doubles per (rb, kt)
-#pragma unroll
-    for (int t = 0; t < U3S_MAX_KT; ++t) {
-        const int tt = t < nkt ? t : nkt - 1;
-#pragma unroll
-        for (int sp = 0; sp < 2; ++sp) af[t][sp] = *reinterpret_cast<const d2*>(wbase + (size_t)tt * 16 * 256 + sp * 128);
-    }
-    const bool faulted = a.fault != nullptr && __hip_atomic_load(a.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.fault_seq;
     if (a.clk != nullptr && blockIdx.x == 0 && wave == 0) {
         const long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
         if (lane == 0) { a.clk[0] = c0; a.clk[1] = r0; }
     }
-    const double c1 = a.add1 ? (a.c1p ? *a.c1p * a.c1i : a.c1i) : 0.0;
-    const double c2 = a.add2 ? (a.c2p ? *a.c2p * a.c2i : a.c2i) : 0.0;
-    const bool do_metrics = a.metric_part != nullptr;
-    const int met_t0 = a.metric_seg == 0 ? 0 : a.metric_seg == 1 ? a.kt1 : a.kt2;
-    const int met_t1 = a.metric_seg == 0 ? (a.kt1 < nkt ? a.kt1 : nkt) : a.metric_seg == 1 ? (a.kt2 < nkt ? a.kt2 : nkt) : nkt;
-    const int nrow_m = do_metrics ? (met_t1 - met_t0) * U3_BK : 0;
-    for (int i = tid; i < nrow_m * 4; i += U3_THREADS) sRowc[i] = a.rowc[i];
-    if (tid < 64) sBias[tid] = (a.bias && tid < a.out_rows) ? a.bias[tid] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        if (tid + q * U3_THREADS < nrow_m * 4) sRowc[tid + q * U3_THREADS] = rcv[q];
+    if (tid < 64) sBias[tid] = biasv;
+    const bool faulted = a.fault != nullptr && fword == a.fault_seq;
+    const double c1 = a.add1 ? c1v * a.c1i : 0.0, c2 = a.add2 ? c2v * a.c2i : 0.0;
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (faulted) return;
 
@@ -338,16 +348,27 @@ void update3s_kernel(const Upd3Args a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[c][e] = 0;
     const double* xb = sX + (size_t)lr * U3S_BN + li;
+    // B operands of tile t + 1 are read before the MFMAs of tile t (the LDS latency has nothing else to hide behind)
+    double bc[4][2], bn[4][2];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { bc[s][0] = xb[(size_t)(4 * s) * U3S_BN]; bc[s][1] = xb[(size_t)(4 * s) * U3S_BN + 16]; }
 #pragma unroll
     for (int t = 0; t < U3S_MAX_KT; ++t) {
         if (t < nkt) {
+            const int tn = t + 1 < nkt ? t + 1 : t;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const double* xk = xb + (size_t)(t * 16 + 4 * s) * U3S_BN;
-                const double av = af[t][s >> 1][s & 1];
-                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, xk[0], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, xk[16], acc[1], 0, 0, 0);
+                const double* xk = xb + (size_t)(tn * 16 + 4 * s) * U3S_BN;
+                bn[s][0] = xk[0]; bn[s][1] = xk[16];
             }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const double av = af[t][s >> 1][s & 1];
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bc[s][0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bc[s][1], acc[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { bc[s][0] = bn[s][0]; bc[s][1] = bn[s][1]; }
         }
     }
     // data metrics of the G rows: thread = (particle tid & 31, row group tid >> 5)
