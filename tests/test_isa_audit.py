@@ -52,3 +52,13 @@ def test_the_tail_launch_of_the_benchmark_keeps_its_registers(table):
     and the step lost 4 us before anybody looked.  The dense path is its own instantiation now."""
     r = table["tail_aldi_kernel<false>"]
     assert r["Occupancy [waves/SIMD]"] == 4 and r["SGPRs Spill"] <= 4 and r["ScratchSize [bytes/lane]"] == 0
+
+
+def test_small_update_kernels_have_no_scratch_and_no_spills(table):
+    """update2s_kernel (fp32, four instantiations) / update3s_kernel (fp64): one accumulator block (two in fp64) per wave and,
+    in fp64, all 24 A-fragment pairs of the row block in registers -- 96 of its 140 VGPRs, which is why this is pinned."""
+    rows = {k: v for k, v in table.items() if k.startswith("update2s_kernel<") or k == "update3s_kernel"}
+    assert len(rows) == 5
+    for name, r in rows.items():
+        assert r["ScratchSize [bytes/lane]"] == 0 and r["SGPRs Spill"] == 0 and r["VGPRs Spill"] == 0, name
+        assert r["mfma"] > 0, name
