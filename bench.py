@@ -502,13 +502,18 @@ def variants_in_a_run(engine, p, n, J, dtype, dev_index, T=120):
     model = lineal(prob["A"])
     out, dt = {}, None
     os.environ["CESX_LINEAL_FAST"] = "0"
+    # host thread pools inside the cgroup's CPU share (a process above it is throttled, and a throttled driving thread shows as
+    # a leg at twice the time -- tools/inrun_probe.py caught exactly that), the start ensemble uploaded once, outside the timing
+    limit_host_threads(reserve=engine.Engine.copy_threads)
+    U0 = torch.as_tensor(U0, dtype={"float32": torch.float32, "float64": torch.float64}[np.dtype(dtype).name]).to(torch.device("cuda", dev_index))
     try:
         for key, kw in (("aldi_default", dict(update="aldi")), ("eks", dict(update="eks")),
                         ("time_step_constant", dict(update="aldi", time_step="constant")),
                         ("time_step_mix", dict(update="aldi", time_step="mix", spinup=1.0))):
             eng = engine.Engine(p, n, J, dtype=dtype, device=dev_index, seed=77)
             try:
-              for steps, timed in ((8, False), (T, True)):
+              el = None
+              for steps, timed in ((8, False), (T, True), (T, True)):          # (the better of two timed runs)
                 smp = ShardedSampler(eng, p, n, J)
                 smp.T = steps
                 torch.cuda.synchronize()
@@ -516,7 +521,8 @@ def variants_in_a_run(engine, p, n, J, dtype, dev_index, T=120):
                 smp.run(prob["y"], U0, model, prob["Gamma"], prob["mu"], prob["sigma"], prob["ustar"], t_tol=1e30,
                         **(dict(kw, delta_t=dt) if "time_step" in kw else kw))
                 torch.cuda.synchronize()
-                el = time.perf_counter() - t0
+                if timed:
+                    el = min(el, time.perf_counter() - t0) if el is not None else time.perf_counter() - t0
             except Exception as ex:
                 out[key] = dict(error=repr(ex), steps_done=len(smp.metrics["t"]))
                 continue
@@ -534,8 +540,8 @@ def variants_in_a_run(engine, p, n, J, dtype, dev_index, T=120):
     for r in out.values():
         if base and "ms_per_step" in r:
             r["ratio_to_default"] = round(r["ms_per_step"] / base, 3)
-    out["how"] = ("ShardedSampler.run, %d steps behind 8 untimed ones: forward map on the device, full Gram, update, feedback; "
-                  "includes one upload of U0" % T)
+    out["how"] = ("ShardedSampler.run, %d steps behind 8 untimed ones (the better of two runs): forward map on the device, full Gram, "
+                  "update, feedback; the start ensemble is resident" % T)
     return out
 
 
