@@ -1,2 +1,4 @@
 cd $GRAFT_REPO_ROOT && export TMPDIR=/tmp && mkdir -p gpurun_out &&
-python tools/variants_only.py eks time_step_constant > gpurun_out/r5_variants14.txt 2>&1; cat gpurun_out/r5_variants14.txt
+python bench.py > gpurun_out/r05_bench_final.json 2> gpurun_out/r05_bench_final.err; tail -c 600 gpurun_out/r05_bench_final.json;
+python bench.py --config C5 --no-extras > gpurun_out/r05_c5_bench_final.json 2> gpurun_out/r05_c5_bench_final.err; tail -c 300 gpurun_out/r05_c5_bench_final.json;
+python tools/soak_long.py > gpurun_out/r05_soak2.txt 2>&1; tail -5 gpurun_out/r05_soak2.txt
