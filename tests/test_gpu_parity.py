@@ -295,6 +295,47 @@ def test_spectral_rule_lambda_max_by_repeated_squaring(eng_mod, kind):
     assert res.hk == pytest.approx(1.0 / lam, rel=1e-9)
 
 
+@pytest.mark.parametrize("update,ts", [("eks", None), ("aldi", "constant")])
+def test_warm_start_that_does_not_converge_falls_back_to_the_factorisation(eng_mod, monkeypatch, update, ts):
+    """The sweeps of a warm start are sized from the LAST step's start (two or three inside a run).  When the ensemble then
+    jumps -- another ensemble altogether, another shape of its covariance --, the previous inverse is either too far off to be tried
+    or the few sweeps leave a residual above 1e-10: the closing residual launch says so and the factorisation chain runs.
+    Every step of such a chain equals the always-factoring one (CESX_NS_WARM=0) to 1e-9, whichever way its inverse went."""
+    p, n, J = 96, 80, 4096
+    d = _synthetic(p, n, J, seed=17, dense=True)
+    d["sigma"] = 1e-3 * d["sigma"]          # (a prior as tight as hk C: the EKS rule's Sigma + hk C then follows the ensemble)
+    rngj = np.random.default_rng(99)
+    # the jump: unrelated to the chain, its spread between a tenth and twenty times the chain's from one parameter to the next
+    Uj = d["ustar"] + np.exp(rngj.uniform(np.log(0.05), np.log(10.0), (p, 1))) * rngj.standard_normal((p, J))
+    kw = dict(time_step=ts, delta_t=0.02, spinup=0.0)
+
+    def chain():
+        eng = eng_mod.Engine(p, n, J, dtype="float64")
+        eng.set_problem(d["y"], d["Gamma"], d["mu"], d["sigma"], d["ustar"])
+        U, t_last, outs, warm = d["U0"], 0.0, [], []
+        rng = np.random.default_rng(5)
+        for i in range(7):
+            if i == 4:
+                U = Uj
+            G = d["A"] @ U + 0.05 * np.sin(d["A"] @ U)
+            xi = rng.standard_normal((p, J))
+            prm = eng_mod.step_params(update=update, first_step=(i == 0), t_len=min(i, 1), t_last=t_last, step_index=i, **kw)
+            out = eng.step(prm, U, G, xi=xi).cpu().numpy().astype(np.float64)
+            res = eng.result()
+            warm.append(eng.warm_inverse())
+            outs.append((out, res.hk, res.bias_data))
+            U, t_last = U + 0.1 * (out - U), res.t_new
+        return outs, warm
+    monkeypatch.setenv("CESX_NS_WARM", "0")
+    ref, w0 = chain()
+    monkeypatch.delenv("CESX_NS_WARM")
+    got, w1 = chain()
+    assert w0 == [0] * 7
+    assert w1[0] == 0 and w1[2:4] == [1, 1] and w1[4] == 0, w1      # cold, warm ..., the jump factors (the steps behind it either way)
+    for (a, ha, ba), (b, hb, bb) in zip(got, ref):
+        assert rel_err(a, b) < 1e-9 and abs(ha - hb) <= 1e-12 * abs(hb) and abs(ba - bb) <= 1e-9 * abs(bb)
+
+
 @pytest.mark.parametrize("update,ts", [("eks", None), ("aldi", "constant"), ("eks", "constant"), ("aldi", "mix")])
 def test_warm_started_spd_inverses_equal_the_factored_ones(eng_mod, monkeypatch, update, ts):
     """The hk-dependent SPD inverses of K2 ((Sigma + hk C)^-1 of the EKS rule, (hk C_gg + Gamma)^-1 of the recomputed gain) start
