@@ -676,12 +676,12 @@ def test_update_kernels_v1_v2_match(eng_mod, monkeypatch, update, shape, dtype, 
 
 @pytest.mark.parametrize("dtype,tol", [("float32", 1e-5), ("float64", 1e-12)])
 @pytest.mark.parametrize("update,prefetch", [("aldi", True), ("aldi", False), ("eks", True), ("aldi_constant", True)])
-@pytest.mark.parametrize("shape", [(64, 50, 8192), (40, 24, 200), (16, 150, 1000), (33, 17, 260)])
+@pytest.mark.parametrize("shape", [(64, 50, 8192), (40, 24, 200), (16, 150, 1000), (33, 17, 260), (64, 64, 512)])
 def test_small_update_kernels_match_the_tiled_ones(eng_mod, monkeypatch, update, prefetch, shape, dtype, tol):
     """K3 for coefficient matrices of at most 64 rows and 192 columns (update2s_kernel / update3s_kernel: the workgroup's
     whole tile LDS resident -- the reference's own problem sizes, examples/scripts/darcy-flow.py:97-105) against the tiled
     LDS-DMA kernels (CESX_UPDATE_SMALL=0) on the same step: ragged J (not a multiple of the 64 / 32 particles of a
-    workgroup), p < 64, the widest G segment that still qualifies (n = 150), the noise block read from memory and
+    workgroup), p < 64, the widest G segment that still qualifies (n = 150), the largest image that does (64 x 192), the noise block read from memory and
     (fp32) drawn in the kernel, the hk-free and the assembled coefficient images, both passes of `aldi_constant`."""
     p, n, J = shape
     d = _synthetic(p, n, J, seed=23)
