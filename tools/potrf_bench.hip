@@ -2,8 +2,8 @@
 #include "../ces_amd/csrc/kernels_dense.hip"
 #include <cstdio>
 namespace cesx { int launch_noise(Engine&, uint64_t, void*, hipStream_t) { return 0; } }
-#ifndef SLOTS
-#define SLOTS 17
+#ifndef PB_SLOTS      // -DPB_SLOTS=2 / 5 / 10 / 17: the instantiation for n <= 64 / 128 / 192 / 256
+#define PB_SLOTS 17
 #endif
 #include <vector>
 #include <random>
@@ -17,21 +17,21 @@ int main(int argc, char** argv) {
     double *dA, *dL, *dLp; int* st;
     hipMalloc(&dA, n*n*8); hipMalloc(&dL, n*n*8); hipMalloc(&dLp, np*np*8); hipMalloc(&st, 4);
     hipMemcpy(dA, A.data(), n*n*8, hipMemcpyHostToDevice); hipMemset(st, 0, 4);
-    const int npmax = SLOTS <= 2 ? 64 : SLOTS <= 5 ? 128 : SLOTS <= 10 ? 192 : 256;
+    const int npmax = PB_SLOTS <= 2 ? 64 : PB_SLOTS <= 5 ? 128 : PB_SLOTS <= 10 ? 192 : 256;
     size_t lds = (size_t)3 * 8 * (2 * npmax + 4) * 8;
-    auto kern = cesx::potrf_reg_kernel<SLOTS>;
+    auto kern = cesx::potrf_reg_kernel<PB_SLOTS>;
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     long long* dbg; hipMalloc(&dbg, 8 * 80); hipMemset(dbg, 0, 8 * 80);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(kern, dim3(1), dim3(cesx::PRT), lds, 0, n, np, dA, dLp, st, (long long*)nullptr, 0, 0, (const double*)nullptr, (const double*)nullptr, 0, (unsigned long long*)nullptr, 0ull, (float*)nullptr, 0, 0);
+    for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(kern, dim3(1), dim3(cesx::PRT), lds, 0, n, np, dA, dLp, st, (long long*)nullptr, 0, 0, (const double*)nullptr, (const double*)nullptr, 0, (unsigned long long*)nullptr, 0ull, (float*)nullptr, 0, 0, (const int*)nullptr);
     hipEventRecord(e0);
-    for (int it = 0; it < 10; ++it) hipLaunchKernelGGL(kern, dim3(1), dim3(cesx::PRT), lds, 0, n, np, dA, dLp, st, (long long*)nullptr, 0, 0, (const double*)nullptr, (const double*)nullptr, 0, (unsigned long long*)nullptr, 0ull, (float*)nullptr, 0, 0);
+    for (int it = 0; it < 10; ++it) hipLaunchKernelGGL(kern, dim3(1), dim3(cesx::PRT), lds, 0, n, np, dA, dLp, st, (long long*)nullptr, 0, 0, (const double*)nullptr, (const double*)nullptr, 0, (unsigned long long*)nullptr, 0ull, (float*)nullptr, 0, 0, (const int*)nullptr);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     std::vector<double> L((size_t)n * n); hipMemcpy2D(L.data(), n*8, dLp, np*8, n*8, n, hipMemcpyDeviceToHost);
     double err = 0; for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) { double s = 0; for (int k = 0; k <= j; ++k) s += L[i*n+k]*L[j*n+k]; err = fmax(err, fabs(s - A[i*n+j])); }
     int hst; hipMemcpy(&hst, st, 4, hipMemcpyDeviceToHost);
-    hipLaunchKernelGGL(kern, dim3(1), dim3(cesx::PRT), lds, 0, n, np, dA, dLp, st, dbg, 0, 0, (const double*)nullptr, (const double*)nullptr, 0, (unsigned long long*)nullptr, 0ull, (float*)nullptr, 0, 0);
+    hipLaunchKernelGGL(kern, dim3(1), dim3(cesx::PRT), lds, 0, n, np, dA, dLp, st, dbg, 0, 0, (const double*)nullptr, (const double*)nullptr, 0, (unsigned long long*)nullptr, 0ull, (float*)nullptr, 0, 0, (const int*)nullptr);
     long long hd[5]; hipMemcpy(hd, dbg, 40, hipMemcpyDeviceToHost);
     { long long pp[72]; hipMemcpy(pp, dbg + 8, 72 * 8, hipMemcpyDeviceToHost); printf("per panel (factor, trailing) cycles:"); for (int k = 0; k < np / 8; k += 1) printf(" %lld/%lld", pp[2 * k], pp[2 * k + 1]); printf("\n"); }
     printf("cycles (wave 0): init %lld | factor %lld barrier %lld | trailing %lld barrier %lld\n", hd[0], hd[1], hd[2], hd[3], hd[4]);
