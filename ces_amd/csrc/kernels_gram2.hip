@@ -59,8 +59,22 @@ constexpr int G2_SLOT_IMM = 60 * 1024;                   // ... of launches whos
 #ifndef G2_ABL      // timing ablations (tools/gram2_bench.hip); results are wrong when set
 #define G2_ABL 0
 #endif
-#ifndef G2_SHIFT_AT
-#define G2_SHIFT_AT 1
+// After which of its blocks a wave waits for its DMA pieces of the next tile and shifts them (see `shift_at` in the kernel;
+// NBW = behind its last block, < 0 = staggered by wave class).  tools/gram2_bench.hip -DG2_SHIFT_AT=k, round 5, us first + second
+// launch:   f32 (C2 shape, NBW = 4)  1: 48.2 + 115.9 | 2: 48.2 + 116.3 | 3: 48.5 + 116.0 | 4: 47.8 + 116.6   (noise)      -> 1
+//           f64 (C5 shape, NBW = 8)  1: 155 + 503 | 2: 153 + 481 | 4: 154 + 488 | 6: 152 + 479 | 8: 149 + 466 | staggered 158 + 498,
+//                                    staggered the other way round (oldest waves last) 162 + 510                                  -> 8
+// An f64 block is 4 MFMAs: behind its first block a wave's pieces, issued one MFMA group earlier, have had ~0.4 us to land
+// and the wave stalls on them; an f32 block is 16 MFMAs and the pieces are there.
+#ifdef G2_SHIFT_AT
+#define G2_SHIFT_AT_F32 G2_SHIFT_AT
+#define G2_SHIFT_AT_F64 G2_SHIFT_AT
+#endif
+#ifndef G2_SHIFT_AT_F32
+#define G2_SHIFT_AT_F32 1
+#endif
+#ifndef G2_SHIFT_AT_F64
+#define G2_SHIFT_AT_F64 8
 #endif
 #ifndef G2_OPT      // dev A/B switches (tools/gram2_bench.hip): 1 = next tile's DMA issued behind the first MFMA group,
 #define G2_OPT 15   // 2 = row sums only where the type reports them, 4 = scalar DMA addressing, 8 = a block's partial sums stored
@@ -323,7 +337,8 @@ void gram2_kernel(const T* __restrict__ U, const T* __restrict__ G, const T* __r
     // waves 0-3 run ahead and wait at the tile's barrier while 12-15 still multiply, so a shift pass placed
     // early in EVERY wave's own instruction stream lies in the middle of the tile in wall time for all but the
     // oldest (whose wait for the DMA is covered by the others' MFMAs); placed last it is exposed for the youngest.
-    const int shift_at = __builtin_amdgcn_readfirstlane(G2_SHIFT_AT < 0 ? ((wave >> 2) + 1) * NBW / 4 : G2_SHIFT_AT);
+    constexpr int SAT = F32 ? G2_SHIFT_AT_F32 : G2_SHIFT_AT_F64;
+    const int shift_at = __builtin_amdgcn_readfirstlane(SAT < 0 ? ((wave >> 2) + 1) * NBW / 4 : SAT > NBW ? NBW : SAT);
     if (nt > 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef G2_CLOCKS
