@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcesx.so")
-SOURCES = ["engine.hip", "kernels_stats.hip", "kernels_gram.hip", "kernels_gram2.hip", "kernels_dense.hip", "kernels_update.hip", "kernels_update2.hip", "kernels_update3.hip", "kernels_calib.hip", "comm.hip"]
+SOURCES = ["engine.hip", "kernels_stats.hip", "kernels_gram.hip", "kernels_gram2.hip", "kernels_dense.hip", "kernels_update.hip", "kernels_update2.hip", "kernels_update3.hip", "kernels_update4.hip", "kernels_calib.hip", "comm.hip"]
 HEADERS = [os.path.join(CSRC, "cesx_internal.h"), os.path.join(os.path.dirname(HERE), "include", "cesx.h")]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

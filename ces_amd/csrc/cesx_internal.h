@@ -404,6 +404,14 @@ struct Engine {
     bool update_small = true;      // CESX_UPDATE_SMALL=0: update2_kernel also for out_rows <= 64 (dev A/B)
     bool side_img = false;         // the factorisation in flight stores L into d_Wq (launch_chol_async)
     bool last_hkfree = false;      // the last launch_dense took the path: the update launch reads d_Wq in the order [xi; U; G]
+    // ---- K3 through the Cholesky factor (round 6; kernels_update4.hip) ----
+    // With a diagonal Sigma, C Sigma^{-1} (U - mu) = L (L^T Sigma^{-1} U) - M mu: two triangular products instead of the dense M U.
+    // d_Wq then holds the CHAINED image (wc_index_L / _Lt / _K): the factorisation stores every panel twice (L, and transposed and
+    // scaled), the tail launch stores -K, nothing stores a I - M.  Decided by the problem and the shape alone (cesx_set_problem):
+    // every call flow of a problem runs the same kernels.
+    bool chain = false;            // d_Wq is in the chained layout and the hk-free step launches update4_kernel
+    bool chain_ok = true;          // CESX_CHAIN=0: the hk-free form of round 4 (update2_kernel<., true>) also where the chained one qualifies
+    void* d_xi_tmp = nullptr;      // [p][J] a noise block drawn right in front of update4_kernel when none was prefetched or injected
     void* d_Wfwd = nullptr;        // forward-map staging [npad][kp]
     void* d_Wfwd_f = nullptr;      // the same map in the fragment-major order of the LDS-DMA update kernels (cesx_forward_set_lineal)
     void* d_bfwd = nullptr;        // [rpad] its offset b
@@ -530,6 +538,28 @@ __host__ __device__ inline size_t wf_index(int i, int k, int nkt) {
     const int kt = k >> 4, kk = k & 15, m = kk >> 1, lh = kk & 1, g = m >> 2, v = m & 3;
     return ((((size_t)y * nkt + kt) * 16 + g * 8 + rb) * 64 + lh * 32 + li) * 4 + v;
 }
+// ---- the "chained" coefficient image of kernels_update4.hip (K3 through the Cholesky factor) ----
+// (18 + ng) tiles of 16 pieces (g, b) of 64 lanes x 4 floats.  k order inside a 16-column tile: lane (lh, m) of piece (g, b)
+// holds columns 8 g + 4 lh + v, v = 0..3 -- the accumulator row order of v_mfma_f32_32x32x2_f32 (wf_index keeps 2 (4 g + v) + lh).
+__host__ __device__ inline size_t wc_slot(int t, int b, int m, int kl) {          // tile t, row block b, row m of it, column kl (0..15) of the tile
+    const int g = kl >> 3, lh = (kl >> 2) & 1, v = kl & 3;
+    return ((((size_t)t * 16 + g * 8 + b) * 64) + lh * 32 + m) * 4 + v;
+}
+// L[i][j], i >= j: column block cb = j / 32 of the lower factor sits in tiles 2 (8 - cb) + h, rows b >= cb
+__host__ __device__ inline size_t wc_index_L(int i, int j) {
+    return wc_slot(2 * (8 - (j >> 5)) + ((j >> 4) & 1), i >> 5, i & 31, j & 15);
+}
+// -(L^T Sigma^{-1})[r][k] = -L[k][r] / Sigma_kk, k >= r: column block kb = k / 32 sits in tiles 2 (7 - kb) + h, rows b <= kb
+__host__ __device__ inline size_t wc_index_Lt(int r, int k) {
+    return wc_slot(2 * (7 - (k >> 5)) + ((k >> 4) & 1), r >> 5, r & 31, k & 15);
+}
+// -K[i][c]: tiles 18 + c / 16
+__host__ __device__ inline size_t wc_index_K(int i, int c) {
+    return wc_slot(18 + (c >> 4), i >> 5, i & 31, c & 15);
+}
+// kernels_update4.hip: CESX_OK, an error, or -1 when the launch does not qualify
+int launch_update4(Engine& e, const void* U, const void* G, const void* xi, void* out, bool metrics, const UpdateOpt& opt, hipStream_t s);
+bool update4_shape_ok(const Engine& e);
 // kernels_update3.hip (fp64 LDS-DMA update): CESX_OK, an error, or -1 when the launch does not qualify
 int launch_update3(Engine& e, int out_rows, const void* Wd, int ktot, const void* bias,
                    const UpdateSrc* src, int nsrc,

@@ -143,6 +143,20 @@ int run_update_main(Engine& e, const cesx_step_params& prm, const void* U, const
     opt.prof = 1;
     opt.wf = e.d_Wf;
     if (e.last_join_polled) { opt.fault = e.d_cholflag + 1; opt.fault_seq = e.chol_seq; }
+    if (e.last_hkfree && e.chain) {
+        // K3 through the Cholesky factor (kernels_update4.hip): the chained image, xi from memory -- a block that was neither
+        // injected nor drawn ahead is drawn here, into an engine buffer, by the kernel that draws the prefetched ones
+        if (!xi) {
+            if (!e.d_xi_tmp) CESX_HIP(hipMalloc(&e.d_xi_tmp, (size_t)e.p * (size_t)e.J * e.esz));
+            TRY(launch_noise(e, prm.step_index, e.d_xi_tmp, s));
+            xi = e.d_xi_tmp;
+        }
+        opt.hkp = &e.d_scal->hk;
+        opt.s2p = &e.d_scal->sqrt2hk;
+        int rc4 = launch_update4(e, U, G, xi, Unext, true, opt, s);
+        e.last_metric_parts = e.last_update_grid_x;
+        return rc4;
+    }
     if (e.last_hkfree) {
         // the coefficient image without the time step (launch_dense): [L | a I - M + I/hk | -K] against [xi; U; G]
         src[0] = UpdateSrc{xi, e.p, xi ? 0 : 1, 1};
@@ -251,6 +265,7 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
     if (const char* fv = std::getenv("CESX_FUSE_CENTER")) { e.fuse_center_ok = fv[0] != '0'; e.fuse_center_auto = false; }
     if (const char* pv = std::getenv("CESX_POLL_JOIN")) e.poll_join_ok = pv[0] != '0';
     if (const char* hv = std::getenv("CESX_HKFREE")) e.hkfree_ok = hv[0] != '0';
+    if (const char* cv = std::getenv("CESX_CHAIN")) e.chain_ok = cv[0] != '0';
     if (const char* sv = std::getenv("CESX_UPDATE_SMALL")) e.update_small = sv[0] != '0';
     if (const char* dv = std::getenv("CESX_TEST_DROP_CHOL_SIGNAL")) e.test_drop_signal_at = (unsigned long long)std::max(0, std::atoi(dv));
     if (const char* tv = std::getenv("CESX_POLL_TIMEOUT_MS")) e.poll_ticks = (unsigned long long)std::max(1, std::atoi(tv)) * 100000ull;
@@ -332,7 +347,9 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
         DM(t, (size_t)e.rpad * e.ktot * e.esz); e.d_W = t;
         DM(t, (size_t)e.rpad * e.ktot * e.esz); e.d_Wf = t;
         DM(t, (size_t)e.rpad * e.esz); e.d_bias = t;
-        if (cfg->dtype == CESX_F32) { DM(t, (size_t)e.rpad * e.ktot * 4); e.d_Wq = t; }
+        if (cfg->dtype == CESX_F32) {          // (the chained layout of kernels_update4.hip: 18 + kn / 16 tiles of 16 KiB)
+            DM(t, std::max((size_t)e.rpad * e.ktot * 4, (size_t)(18 + e.kn / 16) * 16384)); e.d_Wq = t;
+        }
         DM(t, (size_t)e.rpad * e.kp * e.esz); e.d_Wfwd = t;
         DM(t, (size_t)e.rpad * e.kp * e.esz); e.d_Wfwd_f = t;
         DM(t, (size_t)e.rpad * e.esz); e.d_bfwd = t;
@@ -436,6 +453,7 @@ void cesx_destroy(cesx_handle h) {
     if (e.comm) (void)cesx_comm_destroy(h);
     for (void* q : e.d_xi)
         if (q) (void)hipFree(q);
+    if (e.d_xi_tmp) (void)hipFree(e.d_xi_tmp);
     delete &e;
 }
 
@@ -493,6 +511,16 @@ int cesx_set_problem(cesx_handle h, const double* y, const double* Gamma, const 
     TRY(upload(e, e.d_mu, mu, p * 8)); TRY(upload(e, e.d_ustar, ustar, p * 8));
     TRY(upload(e, e.d_Sigma, Sigma, (size_t)p * p * 8)); TRY(upload(e, e.d_Sinv, inv.data(), (size_t)p * p * 8));
     TRY(upload(e, e.d_sw, sw.data(), p * 8));
+    {
+        // K3 through the Cholesky factor where the problem and the shape allow (cesx_internal.h, Engine::chain).  The two layouts
+        // of d_Wq share no writer's footprint: a change of layout starts from a zeroed image, with nothing of the engine in flight
+        const bool chain = e.chain_ok && e.hkfree_ok && e.diag_sigma && update4_shape_ok(e);
+        if (chain != e.chain && e.d_Wq) {
+            CESX_HIP(hipDeviceSynchronize());
+            CESX_HIP(hipMemset(e.d_Wq, 0, std::max((size_t)e.rpad * e.ktot * 4, (size_t)(18 + e.kn / 16) * 16384)));
+        }
+        e.chain = chain;
+    }
     // a new problem: the warm starts of K2's SPD inverses (kernels_dense.hip, spd_inverse) start cold
     if (e.d_ns_x[0][0]) {
         for (int k = 0; k < 2; ++k) { CESX_HIP(hipMemset(e.d_ns_x[0][k], 0, (size_t)n * n * 8)); CESX_HIP(hipMemset(e.d_ns_x[1][k], 0, (size_t)p * p * 8)); }

@@ -374,7 +374,10 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
                       // the fragment-major coefficient image of the hk-free update (Engine::d_Wq, wf_index): a row's 8 panel
                       // entries are two 16-byte pieces of it (even / odd columns = the two k sub-blocks of the MFMA operand)
                       float* __restrict__ wq = nullptr, int wq_nkt = 0, int wq_kp = 0,
-                      const int* __restrict__ skip = nullptr) {      // *skip != 0: nothing to do (spd_inverse's warm start converged)
+                      const int* __restrict__ skip = nullptr,        // *skip != 0: nothing to do (spd_inverse's warm start converged)
+                      // wq_sinv != nullptr: wq is the CHAINED image of kernels_update4.hip (wc_index_L / wc_index_Lt): the panel goes into
+                      // it twice -- as L, and transposed with its rows scaled by -1 / Sigma_kk (the diagonal prior covariance's inverse)
+                      const double* __restrict__ wq_sinv = nullptr) {
     if (skip != nullptr && *skip != 0) return;
     if (lda == 0) lda = n;
     if (ldl == 0) ldl = np;
@@ -456,9 +459,12 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
     // centring fused into the load: the row sums go through LDS (one global load per matrix entry instead of
     // three: the dependent sa_i / sa_j loads made this one workgroup's load phase 20 us longer), the raw entries are
     // already on their way into the tile registers
-    double* s_sa = PnT + 3 * QNB * LDT;                   // [np] (launched with NPMAX doubles more when cen_sa is set)
+    double* s_sa = PnT + 3 * QNB * LDT;                   // [np] (launched with 2 x NPMAX doubles more when cen_sa or wq_sinv is set)
+    double* s_sinv = s_sa + NPMAX;                        // [np] -1 / Sigma_kk (chained image), zero from row n on
     if (cen_sa != nullptr)
         for (int i = threadIdx.x; i < n; i += PRT) s_sa[i] = cen_sa[i];
+    if (wq_sinv != nullptr)
+        for (int i = threadIdx.x; i < NPMAX; i += PRT) s_sinv[i] = i < n ? -wq_sinv[i] : 0.0;
     __syncthreads();                                      // (the zero fill above, the row sums)
     if (cen_sa != nullptr) {
 #pragma clang loop unroll(full)
@@ -525,8 +531,13 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
             }
             if (wq != nullptr && kb + r < n && kb < wq_kp) {
                 typedef float f4w __attribute__((ext_vector_type(4)));
-                *reinterpret_cast<f4w*>(wq + wf_index(kb + r, kb, wq_nkt)) = f4w{(float)x[0], (float)x[2], (float)x[4], (float)x[6]};
-                *reinterpret_cast<f4w*>(wq + wf_index(kb + r, kb + 1, wq_nkt)) = f4w{(float)x[1], (float)x[3], (float)x[5], (float)x[7]};
+                if (wq_sinv != nullptr) {
+                    *reinterpret_cast<f4w*>(wq + wc_index_L(kb + r, kb)) = f4w{(float)x[0], (float)x[1], (float)x[2], (float)x[3]};
+                    *reinterpret_cast<f4w*>(wq + wc_index_L(kb + r, kb + 4)) = f4w{(float)x[4], (float)x[5], (float)x[6], (float)x[7]};
+                } else {
+                    *reinterpret_cast<f4w*>(wq + wf_index(kb + r, kb, wq_nkt)) = f4w{(float)x[0], (float)x[2], (float)x[4], (float)x[6]};
+                    *reinterpret_cast<f4w*>(wq + wf_index(kb + r, kb + 1, wq_nkt)) = f4w{(float)x[1], (float)x[3], (float)x[5], (float)x[7]};
+                }
             }
         }
         if (tid < QNB) {                                   // the factored diagonal block itself
@@ -542,14 +553,31 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
                 float z[QNB];
 #pragma clang loop unroll(full)
                 for (int j = 0; j < QNB; ++j) z[j] = j <= tid ? (float)d[j] : 0.f;
-                *reinterpret_cast<f4w*>(wq + wf_index(kb + tid, kb, wq_nkt)) = f4w{z[0], z[2], z[4], z[6]};
-                *reinterpret_cast<f4w*>(wq + wf_index(kb + tid, kb + 1, wq_nkt)) = f4w{z[1], z[3], z[5], z[7]};
+                if (wq_sinv != nullptr) {
+                    *reinterpret_cast<f4w*>(wq + wc_index_L(kb + tid, kb)) = f4w{z[0], z[1], z[2], z[3]};
+                    *reinterpret_cast<f4w*>(wq + wc_index_L(kb + tid, kb + 4)) = f4w{z[4], z[5], z[6], z[7]};
+                } else {
+                    *reinterpret_cast<f4w*>(wq + wf_index(kb + tid, kb, wq_nkt)) = f4w{z[0], z[2], z[4], z[6]};
+                    *reinterpret_cast<f4w*>(wq + wf_index(kb + tid, kb + 1, wq_nkt)) = f4w{z[1], z[3], z[5], z[7]};
+                }
             }
         }
         // (raw barriers in this loop: __syncthreads() also waits for the global STORES of the panel -- vmcnt(0) -- and the
         //  16 - 24 KB a panel writes leave one CU at ~8 B/clk; nothing in the loop reads global memory)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         PH(2)
+        if (wq_sinv != nullptr && wq != nullptr && kb < wq_kp) {
+            // the panel transposed, from its k-major LDS image: thread = (column kb + j, rows kb + 4 c .. + 3) -> one 16-byte piece of
+            // -(L^T Sigma^{-1})[kb + j][kb + 4 c ..] (entries above the diagonal of the 8 x 8 block are stored as the zeros they are)
+            typedef float f4w __attribute__((ext_vector_type(4)));
+            const int j = tid & 7, c4 = (tid >> 3) * 4;
+            if (c4 < m && kb + c4 < n && kb + j < n) {
+                const double* src = cur + j * LDT + c4;
+                const double* sv = s_sinv + kb + c4;
+                *reinterpret_cast<f4w*>(wq + wc_index_Lt(kb + j, kb + c4)) =
+                    f4w{(float)(src[0] * sv[0]), (float)(src[1] * sv[1]), (float)(src[2] * sv[2]), (float)(src[3] * sv[3])};
+            }
+        }
         // (d) rank-8 update of the tiles whose columns lie right of the panel (two MFMAs per
         //     tile: A = -L21 rows of the tile, B = L21 rows of the tile's columns); the tile
         //     that holds the next panel's columns is updated too, then published
@@ -1041,7 +1069,10 @@ void tail_aldi_kernel(MomView mv, cesx_step_params prm, const double* shift, con
                       float* wq, int nkt, int kp, int kn, float* __restrict__ bias, float* shiftT, double* shift64,
                       float* __restrict__ rowc, unsigned* ticket,
                       const unsigned long long* join, unsigned long long join_want, unsigned long long* fault,
-                      unsigned long long join_ticks) {
+                      unsigned long long join_ticks,
+                      // chain: wq is the chained image of kernels_update4.hip (K3 through the Cholesky factor): -K goes to its G tiles
+                      // (wc_index_K), a I - M and the diagonal are not part of it (M only feeds b' and the next shift here)
+                      int chain) {
     static_assert(DT == NPB, "one partial per thread");
     __shared__ double red[DT / 64];
     __shared__ int s_flag;
@@ -1115,7 +1146,7 @@ void tail_aldi_kernel(MomView mv, cesx_step_params prm, const double* shift, con
                 else {
                     if (self_u) Cm[(size_t)i * p + c] = c_;
                     if (self_u || DSIG) Mm[(size_t)i * p + c] = m_;
-                    if (i != c) wq[wf_index(i, kp + c, nkt)] = (float)(-m_);
+                    if (i != c && !chain) wq[wf_index(i, kp + c, nkt)] = (float)(-m_);
                 }
                 v2 = m_ * mu[c];
                 v3 = m_ * (shift[c] + sa[c] / N);
@@ -1128,7 +1159,7 @@ void tail_aldi_kernel(MomView mv, cesx_step_params prm, const double* shift, con
                 else {
                     Cug[k] = cug;
                     K[k] = kk;
-                    wq[wf_index(i, 2 * kp + c, nkt)] = (float)(-kk);
+                    wq[chain ? wc_index_K(i, c) : wf_index(i, 2 * kp + c, nkt)] = (float)(-kk);
                 }
                 v0 = kk * y[c];
                 v1 = kk * (shift[p + c] + sb[c] / N);
@@ -1203,13 +1234,13 @@ void tail_aldi_kernel(MomView mv, cesx_step_params prm, const double* shift, con
         if (c < p) {
             if (self_u) Cm[(size_t)i * p + c] = d_c;
             if (self_u || DSIG) Mm[(size_t)i * p + c] = d_m;
-            if (i != c) wq[wf_index(i, kp + c, nkt)] = (float)(-d_m);
+            if (i != c && !chain) wq[wf_index(i, kp + c, nkt)] = (float)(-d_m);
         }
         if (c < n) {
             const size_t k = (size_t)i * n + c;
             Cug[k] = d_cug;
             K[k] = d_kk;
-            wq[wf_index(i, 2 * kp + c, nkt)] = (float)(-d_kk);
+            wq[chain ? wc_index_K(i, c) : wf_index(i, 2 * kp + c, nkt)] = (float)(-d_kk);
         }
     }
     __syncthreads();
@@ -1265,7 +1296,7 @@ void tail_aldi_kernel(MomView mv, cesx_step_params prm, const double* shift, con
         const float st = (float)(ub + (-hk * (mu_ - mm) - hk * (kg - ky)));
         shiftT[i] = st;
         shift64[i] = (double)st;
-        wq[wf_index(i, kp + i, nkt)] = (float)(db + 1.0 / hk);
+        if (!chain) wq[wf_index(i, kp + i, nkt)] = (float)(db + 1.0 / hk);
     }
     for (int i = tid; i < n; i += DT) {
         const float st = (float)(shift[p + i] + sb[i] / N);
@@ -1402,16 +1433,17 @@ static int potrf_reg_launch(Engine& e, hipStream_t s, int n, int np, const doubl
                             PotrfCen cen = PotrfCen(),
                             unsigned long long* done = nullptr, unsigned long long done_val = 0, float* wq = nullptr) {
     constexpr int NPMAX = SLOTS <= 2 ? 64 : SLOTS <= 5 ? 128 : SLOTS <= 10 ? 192 : 256;
-    const size_t lds = (size_t)3 * QNB * (2 * NPMAX + 4) * 8 + (cen.sa ? (size_t)NPMAX * 8 : 0);      // panel x 2, its negative (each k-row behind NPMAX zeros), the row sums of a fused centring
+    const double* wq_sinv = (wq != nullptr && e.chain) ? (const double*)e.d_sw : (const double*)nullptr;      // the chained image (kernels_update4.hip)
+    const size_t lds = (size_t)3 * QNB * (2 * NPMAX + 4) * 8 + ((cen.sa || wq_sinv) ? (size_t)2 * NPMAX * 8 : 0);      // panel x 2, its negative (each k-row behind NPMAX zeros), the row sums of a fused centring, -1 / Sigma_kk
     CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_reg_kernel<SLOTS>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (stop)
         hipExtLaunchKernelGGL(potrf_reg_kernel<SLOTS>, dim3(1), dim3(PRT), (unsigned)lds, s, nullptr, stop, 0, n, np, A, Lp,
                               &e.d_scal->status, (long long*)nullptr, lda, ldl, cen.sa, cen.N, cen.unbiased, done, done_val,
-                              wq, e.ktot / 16, e.kp, e.gate);
+                              wq, e.ktot / 16, e.kp, e.gate, wq_sinv);
     else
     hipLaunchKernelGGL(potrf_reg_kernel<SLOTS>, dim3(1), dim3(PRT), lds, s, n, np, A, Lp, &e.d_scal->status, (long long*)nullptr,
-                       lda, ldl, cen.sa, cen.N, cen.unbiased, done, done_val, wq, e.ktot / 16, e.kp, e.gate);
+                       lda, ldl, cen.sa, cen.N, cen.unbiased, done, done_val, wq, e.ktot / 16, e.kp, e.gate, wq_sinv);
     CESX_HIP(hipGetLastError());
     return CESX_OK;
 }
@@ -1922,7 +1954,7 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
                            e.d_ubar, e.d_C, e.d_M, (float*)e.d_Wq, e.ktot / 16, e.kp,
                            e.kn, (float*)e.d_bias, (float*)e.d_shiftT, e.d_shift64, (float*)e.d_rowc,
                            e.d_ticket, polled ? (const unsigned long long*)e.d_cholflag : (const unsigned long long*)nullptr,
-                           (unsigned long long)e.chol_seq, e.d_cholflag + 1, e.poll_ticks);
+                           (unsigned long long)e.chol_seq, e.d_cholflag + 1, e.poll_ticks, e.chain ? 1 : 0);
         CESX_HIP(hipGetLastError());
         e.last_join_polled = polled;
         if (early) {
