@@ -292,16 +292,33 @@ def e2e_block(engine, prob, p, n, J, dtype, update, dev_index):
     return out
 
 
-def flops_executed(p, n, J, dtype):
+def flops_executed(p, n, J, dtype, form=1):
     """MFMA flops a step really issues (what SQ_VALU_MFMA_BUSY_CYCLES counts), next to the algorithmic ones of SURVEY.md
     8(d): K1 computes whole 32 x 32 (fp32) / 16 x 16 (fp64) blocks of the lower triangle of Z Z^T -- the diagonal blocks'
     upper halves are computed and thrown away --, K3 skips the zero blocks of its lower-triangular sqrt(2hk) L segment at
-    the granularity of a row block (32 / 16 rows): 2 p J (p + n) + p J (p + row block)."""
+    the granularity of a row block (32 / 16 rows): 2 p J (p + n) + p J (p + row block).  form 2 (cesx_debug_update_form:
+    K3 through the Cholesky factor, round 6): TWO block-triangular products + the dense K G: (nb (nb + 1) + nb ng / 2)
+    products of 32 x 32 x 32 per 32 particles, nb = ceil(p / 32), ng = ceil(n / 16)."""
     tile = 32 if np.dtype(dtype) == np.dtype(np.float32) else 16
     nbr = -(-(p + n) // tile)
     k1 = 2.0 * (nbr * (nbr + 1) // 2) * tile * tile * J
     k3 = 2.0 * p * J * (p + n) + 1.0 * p * J * (p + tile)
+    if form == 2:
+        nb, ng = -(-p // 32), -(-n // 16)
+        k3 = 2.0 * 32 ** 3 * (nb * (nb + 1) + nb * ng / 2.0) * (J / 32.0)
     return k1, k3
+
+
+def k3_flops_algorithmic(p, n, J, form=1):
+    """K3's algorithmic flops per launch.  SURVEY.md 8(d) prices the fused update GEMM at 2 p (2p + n) per particle -- the dense
+    C Sigma^{-1} U product (2 p^2), the gain term (2 p n) and the dense-counted L xi (2 p^2).  Through the Cholesky factor (form 2)
+    the same update is L (sqrt(2/hk) xi - L^T Sigma^{-1} U): two TRIANGULAR products, p (p + 1) flops each, and the gain term --
+    2 p (p + 1) + 2 p n per particle.  Pricing the faster kernel with the survey's larger count would put it above the peak
+    (25.8 GFLOP in 0.155 ms = 166 TF of a 157-TF pipe); the line therefore prices what the algorithm now needs and carries
+    the survey's figure beside it (roofline.kernels[K3].flops_survey_8d)."""
+    if form == 2:
+        return (2.0 * p * (p + 1) + 2.0 * p * n) * J
+    return 2.0 * p * (2 * p + n) * J
 
 
 def engine_leg(engine, name, p, n, J, dtype, steps, dev_index, prewarm_s=0.6, update="aldi", time_step=None,
@@ -368,8 +385,9 @@ def engine_leg(engine, name, p, n, J, dtype, steps, dev_index, prewarm_s=0.6, up
     g_ms, g_cnt = eng.profile_read(0)
     u_ms, u_cnt = eng.profile_read(1)
     peak = MFMA_PEAK_TF[np.dtype(dtype).name]
-    k1f, k3f = float(p + n) ** 2 * J, 2.0 * p * (2 * p + n) * J
-    k1x, k3x = flops_executed(p, n, J, dtype)
+    form = eng.update_form()
+    k1f, k3f = float(p + n) ** 2 * J, k3_flops_algorithmic(p, n, J, form)
+    k1x, k3x = flops_executed(p, n, J, dtype, form)
     kern = {"gram_kernel(K1)": dict(avg_launch_ms=round(g_ms, 4), launches_per_step=g_cnt,
                                     tflops=round(k1f / (g_ms * 1e-3) / 1e12, 2) if g_ms > 0 else None,
                                     frac=round(k1f / (g_ms * 1e-3) / 1e12 / peak, 4) if g_ms > 0 else None,
@@ -377,7 +395,8 @@ def engine_leg(engine, name, p, n, J, dtype, steps, dev_index, prewarm_s=0.6, up
             "update_kernel(K3)": dict(avg_launch_ms=round(u_ms, 4), launches_per_step=u_cnt,
                                       tflops=round(k3f / (u_ms * 1e-3) / 1e12, 2) if u_ms > 0 else None,
                                       frac=round(k3f / (u_ms * 1e-3) / 1e12 / peak, 4) if u_ms > 0 else None,
-                                      frac_executed=round(k3x / (u_ms * 1e-3) / 1e12 / peak, 4) if u_ms > 0 else None)}
+                                      frac_executed=round(k3x / (u_ms * 1e-3) / 1e12 / peak, 4) if u_ms > 0 else None,
+                                      update_form=form)}
     esz = np.dtype(dtype).itemsize
     rec = dict(workload="%s: J=%d, d=p=%d, n_obs=%d, %s, update=%s, time_step=%s, %s Gamma, %s Sigma, synthetic linear-Gaussian "
                         "inputs resident in HBM, on-device noise, engine only"
@@ -906,6 +925,7 @@ def main():
     gap_ms = pre_gap                                            # end of the second Gram launch -> start of K3 (untimed sample)
     k3_clock = eng.profile_clock() if prof["steps"] else None
     calib_tf, calib_ghz = eng.calibrate_mfma(5.0)
+    k3_form = eng.update_form()          # 0 assembled / 1 hk-free / 2 through the Cholesky factor (include/cesx.h)
     sclk_probe["at"] = args.warmup + args.steps + 16
     run_steps(args.warmup + args.steps, 32)     # (untimed: the same steps again, the sysfs clock read while they run)
     plat.sync()
@@ -939,10 +959,10 @@ def main():
         # per step: K1 is two launches (U x U blocks, then the rest beside the Cholesky), K3 one
         # (two for aldi_constant) -- the durations of a step's launches are summed
         "gram_kernel(K1)": dict(ms=gram_ms / nprof, flops=float(p + n) ** 2 * J, launches=gram_cnt / nprof),
-        "update_kernel(K3)": dict(ms=upd_ms / nprof, flops=2.0 * p * (2 * p + n) * J, launches=upd_cnt / nprof),
+        "update_kernel(K3)": dict(ms=upd_ms / nprof, flops=k3_flops_algorithmic(p, n, J, k3_form), launches=upd_cnt / nprof),
     }
     # ... and what the matrix pipe really issues (triangular-aware, block-granular: flops_executed)
-    kern["gram_kernel(K1)"]["flops_executed"], kern["update_kernel(K3)"]["flops_executed"] = flops_executed(p, n, J, args.dtype)
+    kern["gram_kernel(K1)"]["flops_executed"], kern["update_kernel(K3)"]["flops_executed"] = flops_executed(p, n, J, args.dtype, k3_form)
     for k in kern.values():
         k["tflops"] = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
         k["tflops_executed"] = k["flops_executed"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
@@ -974,7 +994,7 @@ def main():
                 traffic_tab = {}
         except Exception as ex:
             traffic_stale, traffic_tab = "traffic.json could not be checked against the kernel sources (%r): refused" % (ex,), {}
-    k3name = "update2_kernel" if dname == "float32" else ("update3_kernel" if "update3_kernel" in traffic_tab else "update_kernel")
+    k3name = "update4_kernel" if k3_form == 2 else "update2_kernel" if dname == "float32" else ("update3_kernel" if "update3_kernel" in traffic_tab else "update_kernel")
     tkey = {"gram_kernel(K1)": "gram_kernel", "update_kernel(K3)": k3name}
     traffic = traffic_tab.get(tkey[dom])
     step_s = elapsed / args.steps
@@ -1010,6 +1030,10 @@ def main():
                     kernels={k: dict(avg_launch_ms=round(v["ms"], 4), launches_per_step=v["launches"],
                                      tflops=round(v["tflops"], 2), frac=round(v["tflops"] / peak, 4),
                                      flops=v["flops"], flops_executed=v["flops_executed"],
+                                     **({"flops_survey_8d": 2.0 * p * (2 * p + n) * J, "update_form": k3_form,
+                                         "flops_note": "K3 through the Cholesky factor: the algorithm needs 2 p (p + 1) + 2 p n flops per "
+                                                       "particle (two triangular products + the gain term), not SURVEY 8(d)'s 2 p (2p + n)"}
+                                        if k == "update_kernel(K3)" and k3_form == 2 else {}),
                                      frac_executed=round(v["tflops_executed"] / peak, 4),
                                      mfma_util=mfma_util_tab.get(tkey[k]),
                                      sampled=where[k],

@@ -851,6 +851,12 @@ int cesx_result(cesx_handle h, cesx_step_result* out) {
 
 unsigned long long cesx_debug_poll_recoveries(cesx_handle h) { return h ? reinterpret_cast<Engine*>(h)->poll_recoveries : 0; }
 
+int cesx_debug_update_form(cesx_handle h) {
+    if (!h) return -1;
+    const Engine& e = *reinterpret_cast<Engine*>(h);
+    return !e.last_hkfree ? 0 : e.chain ? 2 : 1;
+}
+
 int cesx_debug_warm_inverse(cesx_handle h) {
     if (!h) return -1;
     Engine& e = *reinterpret_cast<Engine*>(h);

@@ -355,7 +355,7 @@ __device__ __forceinline__ double rsqrt_nr(double a) {
     return y;
 }
 
-template <int SLOTS>
+template <int SLOTS, bool CHAIN = false>      // CHAIN: wq is the chained image of kernels_update4.hip (an instantiation of its own: <17> keeps its registers)
 __global__ __launch_bounds__(PRT, 2)
 void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __restrict__ Lp, int* status,
                       long long* dbg = nullptr,     // dbg: per-phase cycle counts (tools/potrf_bench only)
@@ -463,7 +463,7 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
     double* s_sinv = s_sa + NPMAX;                        // [np] -1 / Sigma_kk (chained image), zero from row n on
     if (cen_sa != nullptr)
         for (int i = threadIdx.x; i < n; i += PRT) s_sa[i] = cen_sa[i];
-    if (wq_sinv != nullptr)
+    if (CHAIN)
         for (int i = threadIdx.x; i < NPMAX; i += PRT) s_sinv[i] = i < n ? -wq_sinv[i] : 0.0;
     __syncthreads();                                      // (the zero fill above, the row sums)
     if (cen_sa != nullptr) {
@@ -531,7 +531,7 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
             }
             if (wq != nullptr && kb + r < n && kb < wq_kp) {
                 typedef float f4w __attribute__((ext_vector_type(4)));
-                if (wq_sinv != nullptr) {
+                if (CHAIN) {
                     *reinterpret_cast<f4w*>(wq + wc_index_L(kb + r, kb)) = f4w{(float)x[0], (float)x[1], (float)x[2], (float)x[3]};
                     *reinterpret_cast<f4w*>(wq + wc_index_L(kb + r, kb + 4)) = f4w{(float)x[4], (float)x[5], (float)x[6], (float)x[7]};
                 } else {
@@ -553,7 +553,7 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
                 float z[QNB];
 #pragma clang loop unroll(full)
                 for (int j = 0; j < QNB; ++j) z[j] = j <= tid ? (float)d[j] : 0.f;
-                if (wq_sinv != nullptr) {
+                if (CHAIN) {
                     *reinterpret_cast<f4w*>(wq + wc_index_L(kb + tid, kb)) = f4w{z[0], z[1], z[2], z[3]};
                     *reinterpret_cast<f4w*>(wq + wc_index_L(kb + tid, kb + 4)) = f4w{z[4], z[5], z[6], z[7]};
                 } else {
@@ -566,7 +566,7 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
         //  16 - 24 KB a panel writes leave one CU at ~8 B/clk; nothing in the loop reads global memory)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         PH(2)
-        if (wq_sinv != nullptr && wq != nullptr && kb < wq_kp) {
+        if (CHAIN && wq != nullptr && kb < wq_kp) {
             // the panel transposed, from its k-major LDS image: thread = (column kb + j, rows kb + 4 c .. + 3) -> one 16-byte piece of
             // -(L^T Sigma^{-1})[kb + j][kb + 4 c ..] (entries above the diagonal of the 8 x 8 block are stored as the zeros they are)
             typedef float f4w __attribute__((ext_vector_type(4)));
@@ -1051,8 +1051,8 @@ void finish_aldi_kernel(MomView mv, cesx_step_params prm, const double* part, Sc
 // Nothing of the step is written when the poll runs out (the update launch checks the same fault word).
 // Launched with NPB workgroups of DT threads.
 // ---------------------------------------------------------------------------
-template <bool DSIG>        // DSIG: a dense prior covariance (its own instantiation: the benchmark's keeps its registers -- 121 VGPRs, 4 spilled SGPRs)
-__global__ __launch_bounds__(DT)
+template <bool DSIG, bool CHAIN = false>        // DSIG: a dense prior covariance (its own instantiation: the benchmark's keeps its registers -- 121 VGPRs, 4 spilled SGPRs)
+__global__ __launch_bounds__(DT)                 // CHAIN: wq is the chained image of kernels_update4.hip: -K goes to its G tiles (wc_index_K), a I - M and the
 void tail_aldi_kernel(MomView mv, cesx_step_params prm, const double* shift, const double* __restrict__ y,
                       const double* __restrict__ gw, double* __restrict__ gbar, double* __restrict__ mvec,
                       double* __restrict__ dg, double* __restrict__ Cug, double* __restrict__ See,
@@ -1069,10 +1069,8 @@ void tail_aldi_kernel(MomView mv, cesx_step_params prm, const double* shift, con
                       float* wq, int nkt, int kp, int kn, float* __restrict__ bias, float* shiftT, double* shift64,
                       float* __restrict__ rowc, unsigned* ticket,
                       const unsigned long long* join, unsigned long long join_want, unsigned long long* fault,
-                      unsigned long long join_ticks,
-                      // chain: wq is the chained image of kernels_update4.hip (K3 through the Cholesky factor): -K goes to its G tiles
-                      // (wc_index_K), a I - M and the diagonal are not part of it (M only feeds b' and the next shift here)
-                      int chain) {
+                      unsigned long long join_ticks) {      // diagonal are not part of it (M only feeds b' and the next shift here)
+    constexpr bool chain = CHAIN;
     static_assert(DT == NPB, "one partial per thread");
     __shared__ double red[DT / 64];
     __shared__ int s_flag;
@@ -1435,14 +1433,16 @@ static int potrf_reg_launch(Engine& e, hipStream_t s, int n, int np, const doubl
     constexpr int NPMAX = SLOTS <= 2 ? 64 : SLOTS <= 5 ? 128 : SLOTS <= 10 ? 192 : 256;
     const double* wq_sinv = (wq != nullptr && e.chain) ? (const double*)e.d_sw : (const double*)nullptr;      // the chained image (kernels_update4.hip)
     const size_t lds = (size_t)3 * QNB * (2 * NPMAX + 4) * 8 + ((cen.sa || wq_sinv) ? (size_t)2 * NPMAX * 8 : 0);      // panel x 2, its negative (each k-row behind NPMAX zeros), the row sums of a fused centring, -1 / Sigma_kk
-    CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_reg_kernel<SLOTS>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    auto kern = potrf_reg_kernel<SLOTS, false>;
+    if constexpr (SLOTS == 17) { if (wq_sinv) kern = potrf_reg_kernel<SLOTS, true>; }      // (Engine::chain implies 224 < p <= 256)
+    else if (wq_sinv) { e.err = "potrf: the chained image needs 224 < p <= 256"; return CESX_EINVAL; }
+    CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (stop)
-        hipExtLaunchKernelGGL(potrf_reg_kernel<SLOTS>, dim3(1), dim3(PRT), (unsigned)lds, s, nullptr, stop, 0, n, np, A, Lp,
+        hipExtLaunchKernelGGL(kern, dim3(1), dim3(PRT), (unsigned)lds, s, nullptr, stop, 0, n, np, A, Lp,
                               &e.d_scal->status, (long long*)nullptr, lda, ldl, cen.sa, cen.N, cen.unbiased, done, done_val,
                               wq, e.ktot / 16, e.kp, e.gate, wq_sinv);
     else
-    hipLaunchKernelGGL(potrf_reg_kernel<SLOTS>, dim3(1), dim3(PRT), lds, s, n, np, A, Lp, &e.d_scal->status, (long long*)nullptr,
+    hipLaunchKernelGGL(kern, dim3(1), dim3(PRT), lds, s, n, np, A, Lp, &e.d_scal->status, (long long*)nullptr,
                        lda, ldl, cen.sa, cen.N, cen.unbiased, done, done_val, wq, e.ktot / 16, e.kp, e.gate, wq_sinv);
     CESX_HIP(hipGetLastError());
     return CESX_OK;
@@ -1946,7 +1946,7 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
             CESX_HIP(hipGetLastError());
             if ((rc = potrf(e, s, p, e.d_C, e.d_L, nullptr, nullptr, 0, (float*)e.d_Wq))) return rc;
         } else if (!polled) CESX_HIP(hipStreamWaitEvent(s, e.ev_b, 0));
-        auto tail_kern = e.diag_sigma ? tail_aldi_kernel<false> : tail_aldi_kernel<true>;
+        auto tail_kern = !e.diag_sigma ? tail_aldi_kernel<true, false> : e.chain ? tail_aldi_kernel<false, true> : tail_aldi_kernel<false, false>;
         hipLaunchKernelGGL(tail_kern, dim3(NPB), dim3(DT), 0, s, mv, prm, (const double*)e.d_shift64, (const double*)e.d_y,
                            (const double*)e.d_gw, e.d_gbar, e.d_m, e.d_dg, e.d_Cug, e.d_See, e.d_Srr, e.d_K, e.d_part, e.d_scal,
                            e.d_lag, e.d_mv, mx, (const double*)e.d_sw, e.diag_sigma ? (const double*)nullptr : (const double*)e.d_Sinv,
@@ -1954,7 +1954,7 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
                            e.d_ubar, e.d_C, e.d_M, (float*)e.d_Wq, e.ktot / 16, e.kp,
                            e.kn, (float*)e.d_bias, (float*)e.d_shiftT, e.d_shift64, (float*)e.d_rowc,
                            e.d_ticket, polled ? (const unsigned long long*)e.d_cholflag : (const unsigned long long*)nullptr,
-                           (unsigned long long)e.chol_seq, e.d_cholflag + 1, e.poll_ticks, e.chain ? 1 : 0);
+                           (unsigned long long)e.chol_seq, e.d_cholflag + 1, e.poll_ticks);
         CESX_HIP(hipGetLastError());
         e.last_join_polled = polled;
         if (early) {

@@ -28,7 +28,7 @@ EXPORTS = ("cesx_abi_version", "cesx_create", "cesx_destroy", "cesx_last_error",
            "cesx_prefetch_noise", "cesx_forward_set_lineal", "cesx_forward_apply", "cesx_moments_uu_chol", "cesx_debug_poll_recoveries", "cesx_comm_unique_id", "cesx_comm_init", "cesx_comm_destroy", "cesx_comm_nranks",
            "cesx_comm_stats", "cesx_allreduce_head", "cesx_allreduce_tail", "cesx_allreduce_whole", "cesx_allreduce_sum", "cesx_allreduce_max", "cesx_moments_uu_handover", "cesx_debug_gram_plan",
            "cesx_profile_clock", "cesx_calibrate_mfma", "cesx_profile_gap", "cesx_moments_rest_lineal", "cesx_copy_cols_async",
-           "cesx_debug_warm_inverse")
+           "cesx_debug_warm_inverse", "cesx_debug_update_form")
 
 
 class Config(C.Structure):
@@ -146,6 +146,7 @@ def load_library(path=None):
     lib.cesx_debug_poll_recoveries.argtypes = [vp]
     lib.cesx_debug_poll_recoveries.restype = C.c_ulonglong
     lib.cesx_debug_warm_inverse.argtypes = [vp]
+    lib.cesx_debug_update_form.argtypes = [vp]
     lib.cesx_forward_lineal.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.cesx_forward_set_lineal.argtypes = [vp, vp, vp, vp]
     lib.cesx_forward_apply.argtypes = [vp, vp, vp, vp]
@@ -674,6 +675,11 @@ class Engine:
     def warm_inverse(self):
         """1 when the last hk-dependent SPD inverse of a step came from the warm start (cesx_debug_warm_inverse)."""
         return int(self.lib.cesx_debug_warm_inverse(self._h))
+
+    def update_form(self):
+        """Form of the update GEMM the last step launched: 0 assembled, 1 hk-free, 2 through the Cholesky factor
+        (cesx_debug_update_form)."""
+        return int(self.lib.cesx_debug_update_form(self._h))
 
     def poll_recoveries(self):
         """Steps whose polled join of the side stream ran out and that cesx_result re-ran (include/cesx.h)."""

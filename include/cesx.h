@@ -206,6 +206,15 @@ unsigned long long cesx_debug_poll_recoveries(cesx_handle h);
    cesx_debug_warm_inverse: 1 when the last such inverse of this handle was taken from the warm start, else 0.  Synchronises. */
 int cesx_debug_warm_inverse(cesx_handle h);
 
+/* Which form of the update GEMM (ces/calibrate.py:443-447, :484-488, :515-527) the last cesx_apply / cesx_step of this handle
+   launched:  0  the assembled coefficient matrix W = [(1 + hk a) I - hk C Sigma^{-1} | -hk K | sqrt(2 hk) L] (every rule, dtype, shape);
+              1  ALDI, default time step, fp32: the same matrix with hk kept out of it (the factorisation stores L into the image);
+              2  as 1 for a diagonal Sigma and 224 < p <= 256, through the Cholesky factor: C Sigma^{-1} (U - mu) =
+                 L (L^T Sigma^{-1} U) - C Sigma^{-1} mu with C = L L^T as factored (:476-478) -- two triangular products instead of
+                 the dense one, the intermediate kept in MFMA accumulator registers (CESX_CHAIN=0 keeps form 1).
+   The form is chosen by the problem (cesx_set_problem) and the shape alone, never by the call flow.  -1: no handle. */
+int cesx_debug_update_form(cesx_handle h);
+
 /* ---- split entry points (multi-device, testing) ----------------------- */
 
 /* Length in doubles of the packed moment buffer that is summed across devices:

@@ -45,6 +45,9 @@ class _Engine(FakeEngine):
     def calibrate_mfma(self, ms):
         return 100.0, 2.0
 
+    def update_form(self):
+        return 0
+
 
 class _Module:
     Engine = _Engine

@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 @pytest.fixture(scope="module")
 def table():
     import isa_audit
-    t = isa_audit.collect(["kernels_gram2.hip", "kernels_update2.hip", "kernels_update3.hip", "kernels_dense.hip"])
+    t = isa_audit.collect(["kernels_gram2.hip", "kernels_update2.hip", "kernels_update3.hip", "kernels_update4.hip", "kernels_dense.hip"])
     names = isa_audit.demangle(sorted(t))
     return {re.sub(r"\(.*", "", names[k]).replace("cesx::", "").replace("void ", ""): v for k, v in t.items()}
 
@@ -50,8 +50,27 @@ def test_the_tail_launch_of_the_benchmark_keeps_its_registers(table):
     """tail_aldi_kernel<false> sits between the second reduce and K3 on the benchmark's critical path (12 - 16 us, latency
     bound).  Round 5's first dense-Sigma version of it shared the instantiation: 157 VGPRs, 98 spilled SGPRs, occupancy 3 --
     and the step lost 4 us before anybody looked.  The dense path is its own instantiation now."""
-    r = table["tail_aldi_kernel<false>"]
-    assert r["Occupancy [waves/SIMD]"] == 4 and r["SGPRs Spill"] <= 4 and r["ScratchSize [bytes/lane]"] == 0
+    for name in ("tail_aldi_kernel<false, false>", "tail_aldi_kernel<false, true>"):      # (..., true: the chained image of update4_kernel)
+        r = table[name]
+        assert r["Occupancy [waves/SIMD]"] == 4 and r["SGPRs Spill"] <= 4 and r["ScratchSize [bytes/lane]"] == 0, name
+
+
+def test_the_chained_update_kernel_keeps_ten_blocks_in_registers(table):
+    """update4_kernel (round 6: K3 through the Cholesky factor) holds 10 accumulator blocks (160 VGPRs) + fragments per wave at
+    two workgroups per CU; every accumulator index must fold to a constant in its unrolled tiles -- an array that does not
+    ends up in scratch.  18 triangular tiles + one G tile in the loop, 64 MFMAs each."""
+    r = table["update4_kernel"]
+    assert r["ScratchSize [bytes/lane]"] == 0 and r["SGPRs Spill"] == 0 and r["VGPRs Spill"] == 0
+    assert r["Occupancy [waves/SIMD]"] == 2 and r["scratch_total"] == 0 and r["spill_in_loop"] == 0
+    assert r["mfma"] == 19 * 64 and r["mfma_in_loop"] == 64
+
+
+def test_the_factorisation_that_writes_the_chained_image_costs_no_more_spills(table):
+    """potrf_reg_kernel<17, true> stores every panel twice (L, and transposed and scaled by -1 / Sigma): its own instantiation,
+    so that the plain one keeps its registers; neither may grow past the round-5 counts."""
+    for name in ("potrf_reg_kernel<17, false>", "potrf_reg_kernel<17, true>"):
+        r = table[name]
+        assert r["ScratchSize [bytes/lane]"] == 0 and r["SGPRs Spill"] <= 52 and r["spill_in_loop"] <= 71, name
 
 
 def test_small_update_kernels_have_no_scratch_and_no_spills(table):

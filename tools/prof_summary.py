@@ -48,7 +48,7 @@ def traffic_per_step(summary):
     benchmark's pre-warm is time-based, so the passes hold DIFFERENT numbers of steps: each counter is normalised by
     the steps of ITS pass (= the launches of the one-per-step update kernel in that pass)."""
     steps = {}
-    for k3 in ("update2_kernel", "update3_kernel", "metric_final_kernel"):      # one launch per step
+    for k3 in ("update4_kernel", "update2_kernel", "update3_kernel", "metric_final_kernel"):      # one launch per step
         if k3 in summary and "FETCH_SIZE" in summary[k3] and "WRITE_SIZE" in summary[k3]:
             steps = {c: summary[k3][c]["launches"] for c in ("FETCH_SIZE", "WRITE_SIZE")}
             break
@@ -66,7 +66,7 @@ def mfma_util_per_kernel(summary):
     (GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 x 1024 SIMDs), totals over all launches of the kernel in their passes
     normalised per step like the traffic (a step's two Gram launches count together)."""
     steps = {}
-    for k3 in ("update2_kernel", "update3_kernel", "metric_final_kernel"):
+    for k3 in ("update4_kernel", "update2_kernel", "update3_kernel", "metric_final_kernel"):
         if k3 in summary and "SQ_VALU_MFMA_BUSY_CYCLES" in summary[k3] and "GRBM_GUI_ACTIVE" in summary[k3]:
             steps = {c: summary[k3][c]["launches"] for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE")}
             break
@@ -113,7 +113,7 @@ def main():
         rows.sort(key=lambda r: int(r["Start_Timestamp"]))
         # a step ends with its update kernel (the metric finalisation of a single-device run rides on the next step's
         # U x U reduce launch); show the last complete one plus the next step's first launches
-        last = [i for i, r in enumerate(rows) if "update2_kernel" in r["Kernel_Name"] or "update3_kernel" in r["Kernel_Name"]]
+        last = [i for i, r in enumerate(rows) if any(k in r["Kernel_Name"] for k in ("update4_kernel", "update2_kernel", "update3_kernel"))]
         if len(last) < 4:
             last = [i for i, r in enumerate(rows) if "metric_final_kernel" in r["Kernel_Name"]]
         i0, i1 = last[-4] + 1, min(last[-3] + 2, len(rows) - 1)
