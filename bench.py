@@ -586,7 +586,7 @@ def sharded_helper_main():
             line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
             d = json.loads(line[-1])
             out[key] = dict(value=d["value"], ms_per_step=d["ms_per_step"], ms_per_step_median=d["ms_per_step_median"],
-                            rccl_nranks=d["rccl_nranks"], collective_mode=d["sampled_step"]["collective_mode"],
+                            rccl_nranks=d["rccl_nranks"], rccl_comms=d.get("rccl_comms"), collective_mode=d["sampled_step"]["collective_mode"],
                             collectives_per_step=d["sampled_step"]["collectives_per_step"],
                             collective_ms=d["sampled_step"]["collective_ms"],
                             gram_end_to_k3_start_ms=d["sampled_step"]["gram_end_to_k3_start_ms"],
@@ -1068,6 +1068,7 @@ def main():
                ms_per_step_max=float(np.max(per_step)),
                prewarm_steps=prewarm, prewarm_s=round(prewarm_s, 3), prewarm_window_ms=[round(w, 4) for w in win_ms],
                rccl_nranks=rccl_nranks,
+               rccl_comms=(eng.comm_count() if hasattr(eng, "comm_count") else 0),      # 2: one communicator per stream (include/cesx.h)
                clock=dict(k3_ghz=round(k3_clock, 4) if k3_clock else None,
                           k3_how="s_memtime / s_memrealtime of one wave of the last HIP-event-sampled update launch (%s)"
                                  % where["update_kernel(K3)"],

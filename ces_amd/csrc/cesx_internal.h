@@ -468,6 +468,7 @@ struct Engine {
                      } last_apply;
     // ---- RCCL communicator of a sharded ensemble (comm.hip; nullptr: none) ----
     void* comm = nullptr;
+    void* comm_side = nullptr;     // the side stream's own communicator (ncclCommSplit of `comm`; nullptr: both streams share `comm`)
     int comm_nranks = 0, comm_rank = 0;
     unsigned long long comm_calls = 0, comm_doubles = 0;
     int last_update_grid_x = 0, last_update_grid = 0, last_metric_parts = 0;

@@ -9,6 +9,7 @@
 // already holds a copy (PyTorch ships its own) keeps using that one -- RTLD_NOLOAD first.
 #include "cesx_internal.h"
 #include <dlfcn.h>
+#include <cstdlib>
 #include <cstring>
 
 namespace {
@@ -21,6 +22,7 @@ struct Rccl {
     result_t (*GetUniqueId)(unique_id*) = nullptr;
     result_t (*CommInitRank)(comm_t*, int, unique_id, int) = nullptr;
     result_t (*CommDestroy)(comm_t) = nullptr;
+    result_t (*CommSplit)(comm_t, int, int, comm_t*, void*) = nullptr;      // optional (NCCL >= 2.18): a second communicator without a second id
     result_t (*AllReduce)(const void*, void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(result_t) = nullptr;
     void* lib = nullptr;
@@ -50,6 +52,7 @@ void rccl_load(Rccl& r) {
     r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
     r.ok = r.err.empty();
+    r.CommSplit = reinterpret_cast<decltype(r.CommSplit)>(dlsym(r.lib, "ncclCommSplit"));
 }
 
 constexpr int NCCL_DOUBLE = 8, NCCL_SUM = 0, NCCL_MAX = 2;      // ncclDataType_t / ncclRedOp_t (rccl.h)
@@ -68,7 +71,13 @@ int all_reduce(cesx_handle h, double* buf, size_t count, int op, void* stream, c
     if (count == 0) return CESX_OK;
     int prev = -1;
     if (hipGetDevice(&prev) == hipSuccess && prev != e.cfg.device) (void)hipSetDevice(e.cfg.device);
-    const int res = rccl().AllReduce(buf, buf, count, NCCL_DOUBLE, op, e.comm, (hipStream_t)stream);
+    // One communicator per stream: a collective issued on the engine's side stream (the head of the moment buffer, beside the
+    // second Gram launch) goes through the side communicator, everything else through the main one.  RCCL orders the
+    // collectives of ONE communicator -- issued from two streams they are chained by its own cross-stream events, the head
+    // of step i + 1 behind the tail of step i -- and two ranks that interleave the two streams differently would wait for
+    // each other; two communicators are independent of each other by construction.
+    Rccl::comm_t c = ((hipStream_t)stream == e.side && e.comm_side) ? e.comm_side : e.comm;
+    const int res = rccl().AllReduce(buf, buf, count, NCCL_DOUBLE, op, c, (hipStream_t)stream);
     if (prev >= 0 && prev != e.cfg.device) (void)hipSetDevice(prev);
     ++e.comm_calls;
     e.comm_doubles += count;
@@ -107,9 +116,16 @@ int cesx_comm_init(cesx_handle h, int nranks, int rank, const void* unique_id) {
     std::memcpy(id.internal, unique_id, CESX_COMM_ID_BYTES);
     Rccl::comm_t c = nullptr;
     const int res = r.CommInitRank(&c, nranks, id, rank);
+    // the side stream's communicator: split off the first one (the same ranks, the same order; a collective call, every rank
+    // makes it here).  CESX_COMM_SPLIT=0, or a library without ncclCommSplit: both streams share the one communicator
+    Rccl::comm_t c2 = nullptr;
+    int res2 = 0;
+    const char* sv = std::getenv("CESX_COMM_SPLIT");
+    if (res == 0 && r.CommSplit && !(sv && sv[0] == '0')) res2 = r.CommSplit(c, 0, rank, &c2, nullptr);
     if (prev >= 0 && prev != e.cfg.device) (void)hipSetDevice(prev);
     if (res != 0) return fail(e, "ncclCommInitRank", res);
-    e.comm = c; e.comm_nranks = nranks; e.comm_rank = rank;
+    if (res2 != 0) c2 = nullptr;      // (ncclCommSplit is collective: it fails on every rank or on none -- all then share the one communicator; cesx_comm_count says so)
+    e.comm = c; e.comm_side = c2; e.comm_nranks = nranks; e.comm_rank = rank;
     return CESX_OK;
 }
 
@@ -117,12 +133,19 @@ int cesx_comm_destroy(cesx_handle h) {
     if (!h) return CESX_EINVAL;
     cesx::Engine& e = *reinterpret_cast<cesx::Engine*>(h);
     if (!e.comm) return CESX_OK;
+    if (e.comm_side) (void)rccl().CommDestroy(e.comm_side);
     const int res = rccl().CommDestroy(e.comm);
-    e.comm = nullptr; e.comm_nranks = 0; e.comm_rank = 0;
+    e.comm = nullptr; e.comm_side = nullptr; e.comm_nranks = 0; e.comm_rank = 0;
     return res == 0 ? CESX_OK : fail(e, "ncclCommDestroy", res);
 }
 
 int cesx_comm_nranks(cesx_handle h) { return h ? reinterpret_cast<cesx::Engine*>(h)->comm_nranks : 0; }
+
+int cesx_comm_count(cesx_handle h) {
+    if (!h) return 0;
+    const cesx::Engine& e = *reinterpret_cast<cesx::Engine*>(h);
+    return (e.comm ? 1 : 0) + (e.comm_side ? 1 : 0);
+}
 
 int cesx_comm_stats(cesx_handle h, unsigned long long* calls, unsigned long long* doubles) {
     if (!h) return CESX_EINVAL;

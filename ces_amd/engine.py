@@ -28,7 +28,7 @@ EXPORTS = ("cesx_abi_version", "cesx_create", "cesx_destroy", "cesx_last_error",
            "cesx_prefetch_noise", "cesx_forward_set_lineal", "cesx_forward_apply", "cesx_moments_uu_chol", "cesx_debug_poll_recoveries", "cesx_comm_unique_id", "cesx_comm_init", "cesx_comm_destroy", "cesx_comm_nranks",
            "cesx_comm_stats", "cesx_allreduce_head", "cesx_allreduce_tail", "cesx_allreduce_whole", "cesx_allreduce_sum", "cesx_allreduce_max", "cesx_moments_uu_handover", "cesx_debug_gram_plan",
            "cesx_profile_clock", "cesx_calibrate_mfma", "cesx_profile_gap", "cesx_moments_rest_lineal", "cesx_copy_cols_async",
-           "cesx_debug_warm_inverse", "cesx_debug_update_form")
+           "cesx_debug_warm_inverse", "cesx_debug_update_form", "cesx_comm_count")
 
 
 class Config(C.Structure):
@@ -138,6 +138,7 @@ def load_library(path=None):
     lib.cesx_comm_init.argtypes = [vp, i32, i32, vp]
     lib.cesx_comm_destroy.argtypes = [vp]
     lib.cesx_comm_nranks.argtypes = [vp]
+    lib.cesx_comm_count.argtypes = [vp]
     lib.cesx_comm_stats.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     for name in ("cesx_allreduce_head", "cesx_allreduce_tail", "cesx_allreduce_whole"):
         getattr(lib, name).argtypes = [vp, vp, vp]
@@ -651,6 +652,10 @@ class Engine:
 
     def comm_nranks(self):
         return int(self.lib.cesx_comm_nranks(self._h))
+
+    def comm_count(self):
+        """Communicators the engine holds: 2 = one per stream (main + side), 1 = shared, 0 = none (cesx_comm_count)."""
+        return int(self.lib.cesx_comm_count(self._h))
 
     def comm_stats(self):
         """(all-reduces issued through the engine's communicator so far, their total payload in doubles)."""

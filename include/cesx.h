@@ -276,6 +276,10 @@ int cesx_comm_unique_id(void* id_out);
 int cesx_comm_init(cesx_handle h, int nranks, int rank, const void* unique_id);
 int cesx_comm_destroy(cesx_handle h);
 int cesx_comm_nranks(cesx_handle h);                                  /* 0: no communicator */
+/* Communicators this handle holds: cesx_comm_init makes TWO where the library has ncclCommSplit -- collectives issued on the
+   engine's side stream (cesx_side_stream: the head, beside the second Gram launch) go through the second one, so that no
+   communicator is ever used from two streams (CESX_COMM_SPLIT=0: one, shared).  0 / 1 / 2. */
+int cesx_comm_count(cesx_handle h);
 int cesx_comm_stats(cesx_handle h, unsigned long long* calls, unsigned long long* doubles);   /* all-reduces issued so far, their payload */
 int cesx_allreduce_head(cesx_handle h, double* mom_dev, void* stream);
 int cesx_allreduce_tail(cesx_handle h, double* mom_dev, void* stream);

@@ -47,7 +47,8 @@ def rccl_one_rank():
     dist.destroy_process_group()
 
 
-def _chain(engine, d, update, p, n, J, steps, monkeypatch, collectives, counter, single=False, native=False, stats=None):
+def _chain(engine, d, update, p, n, J, steps, monkeypatch, collectives, counter, single=False, native=False, stats=None,
+           time_step=None, forms=None):
     import torch.distributed as dist
     from ces_amd.dist import ShardedUpdate
     if collectives:
@@ -72,9 +73,12 @@ def _chain(engine, d, update, p, n, J, steps, monkeypatch, collectives, counter,
     t_last, chain = 0.0, []
     for i in range(steps):
         G = eng.forward_lineal(d["A"], U)
-        prm = engine.step_params(update=update, first_step=(i == 0), t_len=min(i, 1), t_last=t_last, step_index=i)
+        prm = engine.step_params(update=update, time_step=time_step, first_step=(i == 0), t_len=min(i, 1), t_last=t_last,
+                                 step_index=i)
         U = sh.step(prm, U, G, xi=None, recenter=(i == 0))
         res = sh.result()
+        if forms is not None:
+            forms.append(eng.update_form())
         t_last = res.t_new
         chain.append((res.hk, res.t_new, res.bias_data, res.self_bias_data, res.lag_bias_data))
     monkeypatch.setattr(dist, "all_reduce", real)
@@ -95,6 +99,26 @@ def test_one_rank_rccl_path_is_bit_identical(rccl_one_rank, monkeypatch, update)
     nuu, nall = 1 + p + p * p, 1 + p + n + p * p + p * n + n * n + 2
     per_step = [nuu, nall - nuu] + ([1] if update == "aldi_constant" else [])
     assert calls_rccl == [1 + p + n] + per_step * steps    # centring shift once, then head + tail (+ max) per step
+    assert np.array_equal(ref[0], got[0])
+    assert ref[1] == got[1]
+
+
+@pytest.mark.parametrize("update,time_step", [("aldi", None), ("eks", None), ("aldi", "constant"), ("aldi", "spectral"),
+                                              ("eks", "spectral"), ("aldi", "mix")])
+def test_one_rank_rccl_path_through_every_rule(rccl_one_rank, monkeypatch, update, time_step):
+    """The sharded sequence (hand-over, head all-reduce + chol(C) on the side stream through the side communicator, tail
+    all-reduce on the caller's stream through the main one, event join) for the rules whose K2 is NOT the default ALDI tail:
+    the SPD inverses of `eks` and of the recomputed gain, lambda_max by repeated squaring -- and, at p = 256 with the
+    default step, K3 through the Cholesky factor (update form 2).  Bit-identical to the same chain without collectives."""
+    from ces_amd import engine
+    p, n, J, steps = 256, 96, 4096, 4
+    d = _problem(p, n, J)
+    st, forms_a, forms_b = [], [], []
+    ref = _chain(engine, d, update, p, n, J, steps, monkeypatch, False, [], time_step=time_step, forms=forms_a)
+    got = _chain(engine, d, update, p, n, J, steps, monkeypatch, True, [], native=True, stats=st, time_step=time_step, forms=forms_b)
+    nuu, nall = 1 + p + p * p, 1 + p + n + p * p + p * n + n * n + 2
+    assert st[0][2] == 1 + 2 * steps and st[0][3] == (1 + p + n) + nall * steps
+    assert forms_a == forms_b == [2 if (update, time_step) == ("aldi", None) else 0] * steps
     assert np.array_equal(ref[0], got[0])
     assert ref[1] == got[1]
 
@@ -137,6 +161,7 @@ def test_comm_entry_points_check_their_arguments(rccl_one_rank):
     assert len(uid) == 128 and eng.comm_nranks() == 0
     eng.comm_init(1, 0, uid)
     assert eng.comm_nranks() == 1
+    assert eng.comm_count() == 2          # one communicator per stream (main + side): round 6
     with pytest.raises(engine.CesxError, match="already has a communicator"):
         eng.comm_init(1, 0, uid)
     t[:] = 3.0
@@ -146,7 +171,7 @@ def test_comm_entry_points_check_their_arguments(rccl_one_rank):
     assert float(t.min()) == 3.0 and eng.comm_stats() == (2, eng.moments_len() + 5)
     eng.comm_destroy()
     eng.comm_destroy()
-    assert eng.comm_nranks() == 0
+    assert eng.comm_nranks() == 0 and eng.comm_count() == 0
 
 
 @pytest.mark.parametrize("update", ["aldi", "aldi_constant"])
