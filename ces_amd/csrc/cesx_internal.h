@@ -411,6 +411,9 @@ struct Engine {
     // every call flow of a problem runs the same kernels.
     bool chain = false;            // d_Wq is in the chained layout and the hk-free step launches update4_kernel
     bool chain_ok = true;          // CESX_CHAIN=0: the hk-free form of round 4 (update2_kernel<., true>) also where the chained one qualifies
+    bool skip_L_hint = false;      // set by the callers of the factorisation: the step it belongs to is (expected to be) a chained one
+    bool L_stale = false;          // the last factorisation wrote the chained image only: d_L does not hold its factor (refresh_factor)
+    int dev_noise = 0;             // CESX_DEV_NOISE (dev A/B, timing only): "skip" (-1) draws nothing; <bytes>: LDS per workgroup of the noise draw
     void* d_xi_tmp = nullptr;      // [p][J] a noise block drawn right in front of update4_kernel when none was prefetched or injected
     void* d_Wfwd = nullptr;        // forward-map staging [npad][kp]
     void* d_Wfwd_f = nullptr;      // the same map in the fragment-major order of the LDS-DMA update kernels (cesx_forward_set_lineal)
@@ -505,6 +508,7 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
 // strictly lower priority than the side stream (a numerically greater one).
 bool stream_below_side(Engine& e, hipStream_t s);
 int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s, bool ev_a_bound = false);
+int refresh_factor(Engine& e, hipStream_t s);
 // whether an update launch [xi; U; G] -> Unext of this engine qualifies for the LDS-DMA fp32 kernel (kernels_update2.hip)
 bool update2_qualifies(const Engine& e, const void* U, const void* G, const void* xi, const void* Unext);
 struct UpdateOpt {

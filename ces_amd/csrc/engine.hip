@@ -266,6 +266,7 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
     if (const char* pv = std::getenv("CESX_POLL_JOIN")) e.poll_join_ok = pv[0] != '0';
     if (const char* hv = std::getenv("CESX_HKFREE")) e.hkfree_ok = hv[0] != '0';
     if (const char* cv = std::getenv("CESX_CHAIN")) e.chain_ok = cv[0] != '0';
+    if (const char* nv = std::getenv("CESX_DEV_NOISE")) e.dev_noise = nv[0] == 's' ? -1 : std::max(0, std::atoi(nv));
     if (const char* sv = std::getenv("CESX_UPDATE_SMALL")) e.update_small = sv[0] != '0';
     if (const char* dv = std::getenv("CESX_TEST_DROP_CHOL_SIGNAL")) e.test_drop_signal_at = (unsigned long long)std::max(0, std::atoi(dv));
     if (const char* tv = std::getenv("CESX_POLL_TIMEOUT_MS")) e.poll_ticks = (unsigned long long)std::max(1, std::atoi(tv)) * 100000ull;
@@ -1091,6 +1092,10 @@ int cesx_debug_dense(cesx_handle h, double* ubar, double* gbar, double* C, doubl
     SET_DEVICE(e);
     FLUSH(e);
     CESX_HIP(hipDeviceSynchronize());
+    if (L && e.L_stale) {          // K3 through the Cholesky factor: the step kept L in its coefficient image only; factor C again
+        TRY(refresh_factor(e, nullptr));
+        CESX_HIP(hipDeviceSynchronize());
+    }
     const size_t p = e.p, n = e.n;
     if (ubar) CESX_HIP(hipMemcpy(ubar, e.d_ubar, p * 8, hipMemcpyDeviceToHost));
     if (gbar) {

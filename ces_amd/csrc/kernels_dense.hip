@@ -355,7 +355,8 @@ __device__ __forceinline__ double rsqrt_nr(double a) {
     return y;
 }
 
-template <int SLOTS, bool CHAIN = false>      // CHAIN: wq is the chained image of kernels_update4.hip (an instantiation of its own: <17> keeps its registers)
+template <int SLOTS, int CHAINV = 0>      // CHAINV: wq is the chained image of kernels_update4.hip (instantiations of their own: <17> keeps its registers);
+                                           // 1: the fp64 factor is written back too, 2: the image only
 __global__ __launch_bounds__(PRT, 2)
 void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __restrict__ Lp, int* status,
                       long long* dbg = nullptr,     // dbg: per-phase cycle counts (tools/potrf_bench only)
@@ -378,6 +379,7 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
                       // wq_sinv != nullptr: wq is the CHAINED image of kernels_update4.hip (wc_index_L / wc_index_Lt): the panel goes into
                       // it twice -- as L, and transposed with its rows scaled by -1 / Sigma_kk (the diagonal prior covariance's inverse)
                       const double* __restrict__ wq_sinv = nullptr) {
+    constexpr bool CHAIN = CHAINV != 0, WRITE_L = CHAINV != 2;
     if (skip != nullptr && *skip != 0) return;
     if (lda == 0) lda = n;
     if (ldl == 0) ldl = np;
@@ -485,12 +487,49 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
     __syncthreads();
     PH(0)
 
+    // CHAIN: a finished panel goes into the chained image twice -- as L (wc_index_L) and transposed, its rows scaled by
+    // -1 / Sigma_kk (wc_index_Lt) -- from its k-major LDS image, by waves 4..7: they hold no row of the factor phase (b), (c)
+    // and share their SIMDs with waves 0..3, whose latency chains leave the issue slots free.  One panel BEHIND: the panel
+    // factored in iteration k - 1 still sits in the other buffer during (b), (c) of iteration k (publish writes it in (d)).
+    // 1024 sixteen-byte pieces per panel, four per thread.  (Stored by the row threads themselves the two images cost the
+    // factorisation 7 - 10 us of 98, tools/potrf_bench.)
+    auto image_pass = [&](int kbp, const double* buf) {
+        typedef float f4w __attribute__((ext_vector_type(4)));
+        const int mp = np - kbp, t4 = tid - PRT / 2;
+#pragma clang loop unroll(full)
+        for (int it = 0; it < 4; ++it) {
+            const int item = t4 + (PRT / 2) * it;
+            if (item < 2 * NPMAX) {                       // L[kbp + row][kbp + 4 half .. + 3]
+                const int row = item >> 1, half = item & 1;
+                if (row < mp && kbp + row < n) {
+                    const double* src = buf + 4 * half * LDT + row;
+                    *reinterpret_cast<f4w*>(wq + wc_index_L(kbp + row, kbp + 4 * half)) =
+                        f4w{(float)src[0], (float)src[LDT], (float)src[2 * LDT], (float)src[3 * LDT]};
+                }
+            } else {                                      // -(L^T Sigma^{-1})[kbp + j][kbp + 4 c .. + 3] (zeros above the 8 x 8 block's diagonal)
+                const int it2 = item - 2 * NPMAX, j = it2 & 7, c4 = (it2 >> 3) * 4;
+                if (c4 < mp && kbp + c4 < n && kbp + j < n) {
+                    const double* src = buf + j * LDT + c4;
+                    const double* sv = s_sinv + kbp + c4;
+                    *reinterpret_cast<f4w*>(wq + wc_index_Lt(kbp + j, kbp + c4)) =
+                        f4w{(float)(src[0] * sv[0]), (float)(src[1] * sv[1]), (float)(src[2] * sv[2]), (float)(src[3] * sv[3])};
+                }
+            }
+        }
+    };
+    static_assert(!CHAIN || (NPMAX == 256 && PRT == 512), "image_pass: 1024 pieces over waves 4..7");
     for (int kb = 0; kb < np; kb += QNB) {
         double* cur = PnT + ((kb / QNB) & 1) * QNB * LDT + Z0;            // (data origin: relative row 0)
         double* nxt = PnT + (((kb / QNB) & 1) ^ 1) * QNB * LDT;
         double* neg = NnT + Z0;
         const int m = np - kb;
         kb_dbg = kb;
+        if (CHAIN && wave >= 4) {
+            // (waves 4..7 hold no row of (b), (c) -- rows QNB + tid < m <= 256: the previous panel's image instead of their
+            //  redundant copy of (b).  Without an image to write, dropping that copy alone changed nothing: 99.1 against 97.0 - 97.9 us)
+            if (wq != nullptr && kb > 0 && kb - QNB < wq_kp) image_pass(kb - QNB, nxt + Z0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else {
         // (b) 8 x 8 diagonal block, redundantly per wave
         double d[QNB];
 #pragma clang loop unroll(full)
@@ -522,19 +561,19 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
                 for (int k = 0; k < j; ++k) sacc -= x[k] * readlane_d(d[k], j);      // L11[j][k]
                 x[j] = sacc * rinv[j];
             }
+            // (CHAINV == 2: the fp64 factor is NOT written back -- the image is all a chained step reads, and the one
+            //  CU's store path (~18 B/clk marginal) is what the image stores cost: 97.9 us without an image, 108.2 with both images
+            //  AND the factor, tools/potrf_bench; whoever reads Engine::d_L afterwards re-factors C first, Engine::L_stale)
             double* dst = Lp + (size_t)(kb + r) * ldl + kb;
 #pragma clang loop unroll(full)
             for (int j = 0; j < QNB; ++j) {
                 cur[j * LDT + r] = x[j];
                 neg[j * LDT + r] = -x[j];
-                dst[j] = x[j];
+                if (WRITE_L) dst[j] = x[j];
             }
             if (wq != nullptr && kb + r < n && kb < wq_kp) {
                 typedef float f4w __attribute__((ext_vector_type(4)));
-                if (CHAIN) {
-                    *reinterpret_cast<f4w*>(wq + wc_index_L(kb + r, kb)) = f4w{(float)x[0], (float)x[1], (float)x[2], (float)x[3]};
-                    *reinterpret_cast<f4w*>(wq + wc_index_L(kb + r, kb + 4)) = f4w{(float)x[4], (float)x[5], (float)x[6], (float)x[7]};
-                } else {
+                if (!CHAIN) {          // (CHAIN: both images are written by the waves that hold no row, one panel behind: image_pass)
                     *reinterpret_cast<f4w*>(wq + wf_index(kb + r, kb, wq_nkt)) = f4w{(float)x[0], (float)x[2], (float)x[4], (float)x[6]};
                     *reinterpret_cast<f4w*>(wq + wf_index(kb + r, kb + 1, wq_nkt)) = f4w{(float)x[1], (float)x[3], (float)x[5], (float)x[7]};
                 }
@@ -546,17 +585,14 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
             for (int j = 0; j < QNB; ++j) {
                 const double v = j <= tid ? d[j] : 0.0;
                 cur[j * LDT + tid] = v;
-                dst[j] = v;
+                if (WRITE_L) dst[j] = v;
             }
             if (wq != nullptr && kb + tid < n && kb < wq_kp) {
                 typedef float f4w __attribute__((ext_vector_type(4)));
                 float z[QNB];
 #pragma clang loop unroll(full)
                 for (int j = 0; j < QNB; ++j) z[j] = j <= tid ? (float)d[j] : 0.f;
-                if (CHAIN) {
-                    *reinterpret_cast<f4w*>(wq + wc_index_L(kb + tid, kb)) = f4w{z[0], z[1], z[2], z[3]};
-                    *reinterpret_cast<f4w*>(wq + wc_index_L(kb + tid, kb + 4)) = f4w{z[4], z[5], z[6], z[7]};
-                } else {
+                if (!CHAIN) {
                     *reinterpret_cast<f4w*>(wq + wf_index(kb + tid, kb, wq_nkt)) = f4w{z[0], z[2], z[4], z[6]};
                     *reinterpret_cast<f4w*>(wq + wf_index(kb + tid, kb + 1, wq_nkt)) = f4w{z[1], z[3], z[5], z[7]};
                 }
@@ -565,19 +601,8 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
         // (raw barriers in this loop: __syncthreads() also waits for the global STORES of the panel -- vmcnt(0) -- and the
         //  16 - 24 KB a panel writes leave one CU at ~8 B/clk; nothing in the loop reads global memory)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        PH(2)
-        if (CHAIN && wq != nullptr && kb < wq_kp) {
-            // the panel transposed, from its k-major LDS image: thread = (column kb + j, rows kb + 4 c .. + 3) -> one 16-byte piece of
-            // -(L^T Sigma^{-1})[kb + j][kb + 4 c ..] (entries above the diagonal of the 8 x 8 block are stored as the zeros they are)
-            typedef float f4w __attribute__((ext_vector_type(4)));
-            const int j = tid & 7, c4 = (tid >> 3) * 4;
-            if (c4 < m && kb + c4 < n && kb + j < n) {
-                const double* src = cur + j * LDT + c4;
-                const double* sv = s_sinv + kb + c4;
-                *reinterpret_cast<f4w*>(wq + wc_index_Lt(kb + j, kb + c4)) =
-                    f4w{(float)(src[0] * sv[0]), (float)(src[1] * sv[1]), (float)(src[2] * sv[2]), (float)(src[3] * sv[3])};
-            }
         }
+        PH(2)
         // (d) rank-8 update of the tiles whose columns lie right of the panel (two MFMAs per
         //     tile: A = -L21 rows of the tile, B = L21 rows of the tile's columns); the tile
         //     that holds the next panel's columns is updated too, then published
@@ -622,6 +647,8 @@ void potrf_reg_kernel(int n, int np, const double* __restrict__ A, double* __res
     }
 #undef TROW
 #undef TCOL
+    if (CHAIN && wave >= 4 && wq != nullptr && np - QNB < wq_kp)          // the last panel's image
+        image_pass(np - QNB, PnT + (((np - QNB) / QNB) & 1) * QNB * LDT + Z0);
     if (dbg && tid == 0)
         for (int i = 0; i < 5; ++i) dbg[i] = tph[i];
 #undef PH
@@ -1433,8 +1460,12 @@ static int potrf_reg_launch(Engine& e, hipStream_t s, int n, int np, const doubl
     constexpr int NPMAX = SLOTS <= 2 ? 64 : SLOTS <= 5 ? 128 : SLOTS <= 10 ? 192 : 256;
     const double* wq_sinv = (wq != nullptr && e.chain) ? (const double*)e.d_sw : (const double*)nullptr;      // the chained image (kernels_update4.hip)
     const size_t lds = (size_t)3 * QNB * (2 * NPMAX + 4) * 8 + ((cen.sa || wq_sinv) ? (size_t)2 * NPMAX * 8 : 0);      // panel x 2, its negative (each k-row behind NPMAX zeros), the row sums of a fused centring, -1 / Sigma_kk
-    auto kern = potrf_reg_kernel<SLOTS, false>;
-    if constexpr (SLOTS == 17) { if (wq_sinv) kern = potrf_reg_kernel<SLOTS, true>; }      // (Engine::chain implies 224 < p <= 256)
+    auto kern = potrf_reg_kernel<SLOTS, 0>;
+    // the chained image is all a chained step reads: the fp64 factor is written back only when the step may turn out NOT to be one
+    // (Engine::skip_L_hint: the caller knows, or the previous step was chained -- a wrong guess costs one in-line factorisation)
+    const bool skip_L = wq_sinv != nullptr && Lp == e.d_L && e.skip_L_hint;
+    if (Lp == e.d_L) e.L_stale = skip_L;
+    if constexpr (SLOTS == 17) { if (wq_sinv) kern = skip_L ? potrf_reg_kernel<SLOTS, 2> : potrf_reg_kernel<SLOTS, 1>; }      // (Engine::chain implies 224 < p <= 256)
     else if (wq_sinv) { e.err = "potrf: the chained image needs 224 < p <= 256"; return CESX_EINVAL; }
     CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (stop)
@@ -1891,6 +1922,13 @@ static int assemble(Engine& e, hipStream_t s, int mode, int ktot, double sw) {
     return CESX_OK;
 }
 
+// the fp64 factor of the last step's covariance, for callers that read Engine::d_L (cesx_debug_dense): the chained factorisation
+// keeps it in the image only
+int refresh_factor(Engine& e, hipStream_t s) {
+    if (!e.L_stale) return CESX_OK;
+    return potrf(e, s, e.p, e.d_C, e.d_L);
+}
+
 // phase 0: everything for eks / aldi.  phase 1: aldi_constant drift coefficients.
 // phase 2: aldi_constant noise coefficients after hk is known.
 bool stream_below_side(Engine& e, hipStream_t s) {
@@ -1936,6 +1974,7 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
         // (no factorisation in flight: in line, the same kernels the side stream would have run -- with CESX_FUSE_CENTER=1 the
         //  factorisation forms C while it loads S_aa and the tail launch forms the rest of the U part itself)
         const int self_u = (early ? e.chol_fused_center : (e.fuse_center_ok || (e.fuse_center_auto && e.gram_b_short))) ? 1 : 0;
+        e.skip_L_hint = true;          // (an in-line factorisation of a step that IS hk-free)
         if (!early && self_u) {
             PotrfCen cen{mv.mom + e.ml.sa(), mv.mom, unbiased};
             if ((rc = potrf_reg_any(e, s, p, potrf_ld(p), mv.mom + e.ml.Saa(), e.d_L, p, 0, nullptr, cen, nullptr, 0, (float*)e.d_Wq))) return rc;
@@ -1972,7 +2011,7 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
     // step, diagonal Gamma / Sigma, one device), and only for the one-kernel factorisation that signals.
     const bool can_poll = fused_finish && prm.time_step == CESX_TS_DEFAULT && early && !e.chol_fused_center && e.poll_join_ok &&
         e.chol_signals && e.diag_sigma && e.J == e.Jg && s != e.side && stream_below_side(e, s);
-    const bool polled = can_poll;
+    const bool polled = can_poll && !(early && e.L_stale);      // (a factor that must be re-formed in line: joined with the event)
     hipLaunchKernelGGL(center_kernel, dim3(NPB), dim3(DT), 0, s, mv, e.d_shift64, e.d_y, e.d_ustar,
                        (const double*)e.d_gw,
                        e.diag_sigma ? e.d_sw : (const double*)nullptr, unbiased, what, e.d_ubar, e.d_gbar,
@@ -1985,6 +2024,9 @@ int launch_dense(Engine& e, const cesx_step_params& prm, const double* mom, int 
         if ((rc = potrf(e, s, p, e.d_C, e.d_L))) return rc;
     if (early) {
         if (!polled) CESX_HIP(hipStreamWaitEvent(s, e.ev_b, 0));
+        // the factorisation in flight expected a chained step and kept L in the image only (the time-step rule changed, or the
+        // ensembles of this call do not qualify): factor C again, in line
+        if (e.L_stale && (rc = refresh_factor(e, s))) return rc;
         // (polled: no queue-level wait was issued, but the launches behind are ordered behind chol(C) all the same -- the
         //  poll ended on its word, or it ran out and they leave the step untouched (the update launch checks the same
         //  fault word).  A noise block drawn BEFORE this chol(C) on the side stream is therefore complete: take_noise
@@ -2105,6 +2147,7 @@ int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s, b
         potrf_ld(p) <= 256;
     e.chol_fused_center = potrf_ld(p) <= 256 && (e.fuse_center_ok || (e.fuse_center_auto && img && e.gram_b_short));
     e.side_img = false;
+    e.skip_L_hint = e.last_hkfree;      // (whether THIS step is hk-free is decided in cesx_apply: expect what the last one was)
     if (e.chol_fused_center) {
         e.side_img = img;
         // p <= 256 (one register-resident factorisation): the covariance is formed while the kernel loads the raw
