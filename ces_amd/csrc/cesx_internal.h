@@ -411,6 +411,7 @@ struct Engine {
     // every call flow of a problem runs the same kernels.
     bool chain = false;            // d_Wq is in the chained layout and the hk-free step launches update4_kernel
     bool chain_ok = true;          // CESX_CHAIN=0: the hk-free form of round 4 (update2_kernel<., true>) also where the chained one qualifies
+    int k3_stagger = 2;            // update4_kernel: the second workgroup of a CU starts this many s_sleep(100) late (CESX_K3_STAGGER, dev A/B)
     bool skip_L_hint = false;      // set by the callers of the factorisation: the step it belongs to is (expected to be) a chained one
     bool L_stale = false;          // the last factorisation wrote the chained image only: d_L does not hold its factor (refresh_factor)
     int dev_noise = 0;             // CESX_DEV_NOISE (dev A/B, timing only): "skip" (-1) draws nothing; <bytes>: LDS per workgroup of the noise draw

@@ -266,6 +266,7 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
     if (const char* pv = std::getenv("CESX_POLL_JOIN")) e.poll_join_ok = pv[0] != '0';
     if (const char* hv = std::getenv("CESX_HKFREE")) e.hkfree_ok = hv[0] != '0';
     if (const char* cv = std::getenv("CESX_CHAIN")) e.chain_ok = cv[0] != '0';
+    if (const char* kv = std::getenv("CESX_K3_STAGGER")) e.k3_stagger = std::max(0, std::min(64, std::atoi(kv)));
     if (const char* nv = std::getenv("CESX_DEV_NOISE")) e.dev_noise = nv[0] == 's' ? -1 : std::max(0, std::atoi(nv));
     if (const char* sv = std::getenv("CESX_UPDATE_SMALL")) e.update_small = sv[0] != '0';
     if (const char* dv = std::getenv("CESX_TEST_DROP_CHOL_SIGNAL")) e.test_drop_signal_at = (unsigned long long)std::max(0, std::atoi(dv));

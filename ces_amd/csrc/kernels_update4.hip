@@ -100,6 +100,9 @@ void update4_kernel(const Upd4Args a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
+#ifdef U4_CLOCKS
+    const long long ck0 = clock64(), wk0 = wall_clock64();
+#endif
     if (a.clk != nullptr && blockIdx.x == 0 && wave == 0) {
         const long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
         if (lane == 0) { a.clk[0] = c0; a.clk[1] = r0; }
@@ -184,10 +187,6 @@ void update4_kernel(const Upd4Args a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) { uf[e] = 0; ufn[e] = 0; xr[0][e] = 0; xr[1][e] = 0; }
 
-    if (do_metrics)
-        for (int i = tid; i < ng * 64; i += U4_THREADS) sRowc[i] = a.rowc[i];
-    sBias[tid] = a.bias[tid];
-
     // coefficient fragment of block step (tile slot sl, group g, block b)
     auto read_a = [&](float* dst, int sl, int g, int b) __attribute__((always_inline)) {
         const f4 v = *reinterpret_cast<const f4*>(smem + sl * U4_ASLOT + (g * 8 + b) * 1024 + lane * 16);
@@ -208,11 +207,18 @@ void update4_kernel(const Upd4Args a) {
     // ---- prologue: tiles 0 and 1 in flight, tile 0 landed ----
     issue_a(0, 0, 0); issue_x(0, 0); issue_xi(0, xr[0], 0); issue_xi(0, xr[0], 1); issue_a(0, 0, 1);
     issue_a(1, 1, 0); issue_x(1, 1); issue_xi(1, xr[1], 0); issue_xi(1, xr[1], 1); issue_a(1, 1, 1);
+    // (the row constants and the bias BEHIND the first tiles' loads: one round trip to memory in front of the first MFMA, not two)
+    if (do_metrics)
+        for (int i = tid; i < ng * 64; i += U4_THREADS) sRowc[i] = a.rowc[i];
+    sBias[tid] = a.bias[tid];
     u4_barrier<(U4_ABL & 3) ? 0 : 14>();
     u4_tie8(xr[0]);
     read_a(af[0], 0, 0, 0); read_a(af[1], 0, 0, 1); read_a(af[2], 0, 0, 2);
     read_x(uf, 0);
 
+#ifdef U4_CLOCKS
+    const long long ck1 = clock64();
+#endif
     // ---- the two triangular products: tiles 0 .. 17, fully unrolled (the accumulators change roles) ----
     auto tri_tile = [&](auto tc) __attribute__((always_inline)) {
         constexpr int T = decltype(tc)::value;
@@ -269,6 +275,9 @@ void update4_kernel(const Upd4Args a) {
     };
     u4_unroll(tri_tile, std::make_integer_sequence<int, U4_TRI>{});
 
+#ifdef U4_CLOCKS
+    const long long ck2 = clock64();
+#endif
     // ---- - K G: ng dense tiles; the data metrics ride on the G fragments ----
     f2 mq = {0.f, 0.f};          // {sum w (g - gbar)^2, sum w (g - y)^2} over this lane's rows of its particle
     int sl = 0;                  // ring slot of tile 18 + gt: (18 + gt) % 3 = gt % 3
@@ -315,6 +324,9 @@ void update4_kernel(const Upd4Args a) {
     // (the last tile's barrier had nothing in flight; one more so that the ring can be reused)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
+#ifdef U4_CLOCKS
+    const long long ck3 = clock64();
+#endif
     // ---- epilogue: U_next = hk (sum + b'); lane holds rows 32 b + 8 (e >> 2) + 4 lh + (e & 3) of particle colp ----
     if (col_ok) {
         float* const ob = a.out + colp;
@@ -353,6 +365,18 @@ void update4_kernel(const Upd4Args a) {
         const long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
         if (lane == 0) { a.clk[2] = c1; a.clk[3] = r1; }
     }
+#ifdef U4_CLOCKS
+    {   // dev instrumentation (tools/update4_bench.hip): cycles of wave 0's phases, wall-clock ticks (100 MHz) of the workgroup
+        const long long ck4 = clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const long long ck5 = clock64();
+        if (tid == 0 && a.metric_part) {
+            double* m = a.metric_part + 16384 + (size_t)blockIdx.x * 8;
+            m[0] = (double)(ck1 - ck0); m[1] = (double)(ck2 - ck1); m[2] = (double)(ck3 - ck2); m[3] = (double)(ck4 - ck3);
+            m[4] = (double)(ck5 - ck4); m[5] = (double)(wall_clock64() - wk0); m[6] = (double)(wk0 % 1000000);
+        }
+    }
+#endif
 }
 
 // the shapes the chained form takes (decided once per problem, cesx_set_problem): fp32, eight 32-row blocks, a G segment whose
@@ -379,7 +403,7 @@ int launch_update4(Engine& e, const void* U, const void* G, const void* xi, void
     dim3 grid((unsigned)((e.J + U4_BN - 1) / U4_BN));
     // the dispatcher gives every CU one workgroup before any CU gets its second: from there on start late
     a.stagger_from = (long long)grid.x > e.num_cus ? e.num_cus : 0x7fffffff;
-    a.stagger_n = 2;
+    a.stagger_n = e.k3_stagger;
     CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(update4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     e.last_update_grid_x = (int)grid.x;
     e.last_update_grid = (int)grid.x;

@@ -41,7 +41,7 @@ int main(int argc, char** argv) {
     float *U, *G, *X, *Wc, *dbias, *out, *rowc; double *mpart, *scal;
     CK(hipMalloc(&U, (size_t)p * J * 4)); CK(hipMalloc(&G, (size_t)n * J * 4)); CK(hipMalloc(&X, (size_t)p * J * 4));
     CK(hipMalloc(&out, (size_t)p * J * 4)); CK(hipMalloc(&Wc, img.size() * 4)); CK(hipMalloc(&dbias, 1024));
-    CK(hipMalloc(&rowc, kn * 16)); CK(hipMalloc(&mpart, 8192 * 16)); CK(hipMalloc(&scal, 64));
+    CK(hipMalloc(&rowc, kn * 16)); CK(hipMalloc(&mpart, (16384 + 8192 * 8) * 8)); CK(hipMalloc(&scal, 64));
     std::vector<float> hU((size_t)p * J), hG((size_t)n * J), hX((size_t)p * J);
     for (size_t i = 0; i < hU.size(); ++i) hU[i] = (float)((i * 2654435761u) % 2001) / 1000.f - 1.f;
     for (size_t i = 0; i < hG.size(); ++i) hG[i] = (float)((i * 40503u + 17) % 1999) / 1000.f - 1.f;
@@ -118,6 +118,16 @@ int main(int argc, char** argv) {
         printf("update4: %.1f us/launch (%.1f TF executed of %.2f GFLOP)\n", ms * 50.0, (2.0 * 32 * 32 * 32 * (72 + 4.0 * ng) * (J / 32.0)) / (ms * 5e-5) / 1e12,
                2.0 * 32 * 32 * 32 * (72 + 4.0 * ng) * (J / 32.0) / 1e9);
     }
+#ifdef U4_CLOCKS
+    {
+        std::vector<double> m((size_t)grid.x * 8);
+        CK(hipMemcpy(m.data(), mpart + 16384, m.size() * 8, hipMemcpyDeviceToHost));
+        double s[6] = {0, 0, 0, 0, 0, 0}, w0 = 1e30, w1 = 0;
+        for (unsigned i = 0; i < grid.x; ++i) { for (int k = 0; k < 6; ++k) s[k] += m[8 * i + k]; w0 = fmin(w0, m[8 * i + 6]); w1 = fmax(w1, m[8 * i + 6] + m[8 * i + 5]); }
+        printf("wave 0, mean over workgroups: prologue %.0f | triangular tiles %.0f (%.0f per tile) | G tiles %.0f (%.0f per tile) | store issue %.0f | until acknowledged %.0f cycles; workgroup wall %.2f us; first start -> last end %.2f us\n",
+               s[0] / grid.x, s[1] / grid.x, s[1] / grid.x / 18, s[2] / grid.x, s[2] / grid.x / ng, s[3] / grid.x, s[4] / grid.x, s[5] / grid.x / 100.0, (w1 - w0) / 100.0);
+    }
+#endif
     // the hk-free update2 launch at the same shape (timing only: a random fragment-major image)
     if (p == 256 && J % 128 == 0) {
         const int kp = 256, ktot = 2 * kp + kn, nkt = ktot / 16;
