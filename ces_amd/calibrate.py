@@ -349,14 +349,16 @@ class sampling(enka):
         fast = sh.lineal_fast_ok(model)       # linear map on the device: G's moments follow from U's (no second Gram launch)
         G_next = None
 
+        from .utils import hook_takes_out
+        takes_out = hook_takes_out(model.forward_device)
+
         def fwd(u, out=None):                 # (``out``: a redo after a re-run step refreshes G in place, ShardedUpdate.result)
             if out is None:
                 return model.forward_device(eng, u)
-            try:
+            if takes_out:
                 return model.forward_device(eng, u, out=out)
-            except TypeError:                 # a hook without ``out=``
-                out.copy_(model.forward_device(eng, u))
-                return out
+            out.copy_(model.forward_device(eng, u))          # a hook without ``out=``
+            return out
         for i in range(self.T):
             if trace and (i % stride == 0):                        # :356-358 (a copy: the device buffers are reused)
                 self.Uall.append(U0 if i == 0 and isinstance(U0, np.ndarray) else eng.to_host(U))

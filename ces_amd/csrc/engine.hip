@@ -473,11 +473,15 @@ int cesx_set_problem(cesx_handle h, const double* y, const double* Gamma, const 
     host_spd_inverse(n, Li, inv);
     // Dense Gamma: the engine works in whitened data coordinates (cesx_internal.h, Engine::whiten) -- y~ = L^{-1} y,
     // Gamma~ = I, and G~ = L^{-1} G formed once per step by the update kernel's own code (whitened_G below)
-    e.whiten = !is_diagonal(n, Gamma);
+    // (nothing of the engine's state is committed before every allocation and upload below has succeeded: a failure leaves
+    //  the handle WITHOUT a problem -- cesx_moments* / cesx_apply then return CESX_ESTATE -- instead of half of the new one)
+    const bool whiten = !is_diagonal(n, Gamma);
+    e.problem_set = false;
+    e.whiten = false;
     e.gw_src = nullptr;
     std::vector<double> gw(n), yi(y, y + n), Gi(Gamma, Gamma + (size_t)n * n);
     for (int i = 0; i < n; ++i) gw[i] = 1.0 / Gamma[(size_t)i * n + i];
-    if (e.whiten) {
+    if (whiten) {
         e.h_LG = L; e.h_Li = Li;
         for (int i = 0; i < n; ++i) {
             double t = 0.0;
@@ -496,9 +500,11 @@ int cesx_set_problem(cesx_handle h, const double* y, const double* Gamma, const 
                 rm[(size_t)i * e.kn + k] = v;
                 fm[e.cfg.dtype == CESX_F32 ? wf_index(i, k, nkt) : wd_index(i, k, nkt)] = v;
             }
-        if (!e.d_Wwh) { char* t; int rc; if ((rc = dmalloc(e, &t, len * e.esz))) return rc; e.d_Wwh = t; if ((rc = dmalloc(e, &t, len * e.esz))) return rc; e.d_Wwh_f = t; }
-        TRY(upload_T(e, e.d_Wwh, rm.data(), len)); TRY(upload_T(e, e.d_Wwh_f, fm.data(), len));
+        // (each buffer checked on its own: a second call finds what an earlier, failed one did allocate)
+        if (!e.d_Wwh) { char* t; int rc; if ((rc = dmalloc(e, &t, len * e.esz))) return rc; e.d_Wwh = t; }
+        if (!e.d_Wwh_f) { char* t; int rc; if ((rc = dmalloc(e, &t, len * e.esz))) return rc; e.d_Wwh_f = t; }
         if (!e.d_Gw) CESX_HIP(hipMalloc(&e.d_Gw, (size_t)n * (size_t)e.J * e.esz));
+        TRY(upload_T(e, e.d_Wwh, rm.data(), len)); TRY(upload_T(e, e.d_Wwh_f, fm.data(), len));
     }
     TRY(upload(e, e.d_y, yi.data(), n * 8)); TRY(upload(e, e.d_Gamma, Gi.data(), (size_t)n * n * 8));
     TRY(upload(e, e.d_gw, gw.data(), n * 8));
@@ -527,6 +533,8 @@ int cesx_set_problem(cesx_handle h, const double* y, const double* Gamma, const 
     if (e.d_ns_x[0][0]) {
         for (int k = 0; k < 2; ++k) { CESX_HIP(hipMemset(e.d_ns_x[0][k], 0, (size_t)n * n * 8)); CESX_HIP(hipMemset(e.d_ns_x[1][k], 0, (size_t)p * p * 8)); }
     }
+    e.whiten = whiten;
+    e.ns_r0_last = 1e300;          // (the first warm start of the new problem is sized like a cold one)
     e.problem_set = true;
     e.shift_valid = false;
     return CESX_OK;

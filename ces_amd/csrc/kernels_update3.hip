@@ -200,25 +200,31 @@ void update3_kernel(const Upd3Args a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+    // The epilogue takes its arguments from the kernarg segment AGAIN, through an opaque copy of the segment pointer: held in SGPRs
+    // across the K loop they were 15 spilled registers (v_writelane in front of the loop, v_readlane behind it) and a nominal
+    // 36-byte stack frame (profiles/r05_resource_usage.txt); the K loop itself keeps what it needs.
+    typedef const __attribute__((address_space(4))) Upd3Args* kargp_t;
+    kargp_t ea = (kargp_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ea));
     // epilogue: lane holds, for row (lane >> 4) + 4 e of each of its blocks, particles 4 li .. 4 li + 3
-    const double c1 = a.add1 ? (a.c1p ? *a.c1p * a.c1i : a.c1i) : 0.0;
-    const double c2 = a.add2 ? (a.c2p ? *a.c2p * a.c2i : a.c2i) : 0.0;
+    const double c1 = ea->add1 ? (ea->c1p ? *ea->c1p * ea->c1i : ea->c1i) : 0.0;
+    const double c2 = ea->add2 ? (ea->c2p ? *ea->c2p * ea->c2i : ea->c2i) : 0.0;
     const long long j = jt0 + 4 * li;
     double amax = 0.0;
-    if (j < a.J) {
+    if (j < ea->J) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int i = rc0 + rbk[r] * 16 + lr + 4 * e;
-                if (i < a.out_rows) {
-                    const double bi = a.bias ? a.bias[i] : 0.0;
-                    const size_t o = (size_t)i * a.J + j;
+                if (i < ea->out_rows) {
+                    const double bi = ea->bias ? ea->bias[i] : 0.0;
+                    const size_t o = (size_t)i * ea->J + j;
                     d2 v0 = {acc[r][0][e] + bi, acc[r][1][e] + bi}, v1 = {acc[r][2][e] + bi, acc[r][3][e] + bi};
-                    if (a.add1) { v0 += c1 * *reinterpret_cast<const d2*>(a.add1 + o); v1 += c1 * *reinterpret_cast<const d2*>(a.add1 + o + 2); }
-                    if (a.add2) { v0 += c2 * *reinterpret_cast<const d2*>(a.add2 + o); v1 += c2 * *reinterpret_cast<const d2*>(a.add2 + o + 2); }
-                    *reinterpret_cast<d2*>(a.out + o) = v0;
-                    *reinterpret_cast<d2*>(a.out + o + 2) = v1;
+                    if (ea->add1) { v0 += c1 * *reinterpret_cast<const d2*>(ea->add1 + o); v1 += c1 * *reinterpret_cast<const d2*>(ea->add1 + o + 2); }
+                    if (ea->add2) { v0 += c2 * *reinterpret_cast<const d2*>(ea->add2 + o); v1 += c2 * *reinterpret_cast<const d2*>(ea->add2 + o + 2); }
+                    *reinterpret_cast<d2*>(ea->out + o) = v0;
+                    *reinterpret_cast<d2*>(ea->out + o + 2) = v1;
                     amax = fmax(amax, fmax(fmax(fabs(v0[0]), fabs(v0[1])), fmax(fabs(v1[0]), fabs(v1[1]))));
                 }
             }
@@ -236,7 +242,7 @@ void update3_kernel(const Upd3Args a) {
         }
         __syncthreads();
         double se = 0.0, sr = 0.0;
-        if (tid < U3_BN && jt0 + tid < a.J) {
+        if (tid < U3_BN && jt0 + tid < ea->J) {
             double qe = 0, qr = 0;
 #pragma unroll
             for (int g = 0; g < 16; ++g) { qe += comb[g * U3_BN + tid]; qr += comb[16 * U3_BN + g * U3_BN + tid]; }
@@ -247,23 +253,23 @@ void update3_kernel(const Upd3Args a) {
         for (int o = 32; o > 0; o >>= 1) { se += __shfl_down(se, o, 64); sr += __shfl_down(sr, o, 64); }
         __syncthreads();
         if (tid == 0) {                                            // (tid < 64: only wave 0 holds particles)
-            a.metric_part[blockIdx.x * 2 + 0] = sr;
-            a.metric_part[blockIdx.x * 2 + 1] = se;
+            ea->metric_part[blockIdx.x * 2 + 0] = sr;
+            ea->metric_part[blockIdx.x * 2 + 1] = se;
         }
         __syncthreads();
     }
-    if (a.absmax_part) {
+    if (ea->absmax_part) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amax = fmax(amax, __shfl_down(amax, o, 64));
         __syncthreads();
         double* red = reinterpret_cast<double*>(smem);
         if (lane == 0) red[wave] = amax;
         __syncthreads();
-        if (tid == 0) a.absmax_part[blockIdx.y * gridDim.x + blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        if (tid == 0) ea->absmax_part[blockIdx.y * gridDim.x + blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
     }
-    if (a.clk != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0) {
+    if (ea->clk != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0) {
         const long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-        if (lane == 0) { a.clk[2] = c1; a.clk[3] = r1; }
+        if (lane == 0) { ea->clk[2] = c1; ea->clk[3] = r1; }
     }
 }
 

@@ -322,11 +322,11 @@ class ShardedSampler:
         if hasattr(model, "forward_device"):
             if out is None:
                 return model.forward_device(self.engine, U)
-            try:
+            from .utils import hook_takes_out
+            if hook_takes_out(model.forward_device):
                 return model.forward_device(self.engine, U, out=out)
-            except TypeError:                                       # a hook without ``out=``
-                out.copy_(model.forward_device(self.engine, U))
-                return out
+            out.copy_(model.forward_device(self.engine, U))         # a hook without ``out=``
+            return out
         Uh = U.cpu().numpy().astype(np.float64)
         Gh = np.stack([np.asarray(model(u)) for u in Uh.T], axis=1)
         G = self.engine.to_device(Gh[: self.n_obs])

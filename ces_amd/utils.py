@@ -89,3 +89,15 @@ def __getattr__(name):
         return getattr(models, name)
     except AttributeError:
         raise AttributeError("module %r has no attribute %r" % (__name__, name)) from None
+
+
+def hook_takes_out(hook):
+    """Whether a model's ``forward_device(engine, U[, out=])`` hook accepts ``out=`` -- decided from its signature, once, not by
+    catching ``TypeError`` around the call (a ``TypeError`` raised INSIDE a hook that does take ``out=`` would be swallowed and the
+    forward map evaluated a second time through the copy fallback)."""
+    import inspect
+    try:
+        prm = inspect.signature(hook).parameters
+    except (TypeError, ValueError):
+        return False
+    return "out" in prm or any(q.kind is inspect.Parameter.VAR_KEYWORD for q in prm.values())

@@ -143,7 +143,14 @@ int  cesx_abi_version(void);
    engine forms G~ = L^{-1} G (one triangular n x n x J product on the matrix pipe, into an engine-owned n x J buffer
    allocated here) and works with y~ = L^{-1} y, Gamma~ = I -- D = (1/J) E^T Gamma^{-1} R, the data metrics, the gains
    and K (g - y) are invariant (ces/calibrate.py:429-441, :461-473), and every kernel behind it is the diagonal-Gamma
-   one.  G_dev itself is never written.  cesx_debug_dense reports gbar and K in the caller's coordinates. */
+   one.  G_dev itself is never written.  cesx_debug_dense reports gbar and K in the caller's coordinates.
+   There is ONE whitened buffer per handle: with a dense Gamma every cesx_moments* call (it whitens G into that buffer) must be
+   stream-ordered behind the previous cesx_apply of the handle (whose update kernel reads it) -- the split API's freedom to run
+   step i + 1's moments on another stream beside step i's update holds for a diagonal Gamma only.
+   Supported conditioning of a dense Gamma on an fp32 engine: the whitening product runs in the engine dtype, its rounding
+   eps32 |L^{-1}| |G| is amplified by cond(L) = sqrt(cond(Gamma)) relative to the whitened signal; tests hold cond(Gamma) <= 1e4 with
+   |gbar| / spread <= 1e2 to the fp32 bar (tests/test_gpu_parity.py::test_dense_gamma_conditioning); beyond that use an fp64 engine.
+   A call that fails (CESX_ENOTPD, an allocation) leaves the handle WITHOUT a problem: nothing is committed before everything is. */
 int cesx_set_problem(cesx_handle h, const double* y, const double* Gamma,
                      const double* mu, const double* Sigma, const double* ustar);
 
@@ -203,7 +210,12 @@ unsigned long long cesx_debug_poll_recoveries(cesx_handle h);
    when that start is close (||I - A X_prev||_F < 0.3) and accepted only when the TRUE residual of the result passes
    (||I - A X||_F < 1e-10); otherwise, and always on the first step of a problem, they are factored from scratch (Cholesky,
    triangular inverse, product).  Same inverse to ~1e-10 either way; CESX_NS_WARM=0 pins the factorisation.
-   cesx_debug_warm_inverse: 1 when the last such inverse of this handle was taken from the warm start, else 0.  Synchronises. */
+   cesx_debug_warm_inverse: 1 when the last such inverse of this handle was taken from the warm start, else 0.  Synchronises.
+   Reproducibility contract: the NUMBER of sweeps a warm start runs is sized from ||I - A X_prev||_F of the last step whose
+   result the host has read (cesx_result; reset by cesx_set_problem), and warm and cold inverses agree to ~1e-10, not to the
+   bit: chains of these rules are bit-reproducible across call flows that read results at the same cadence (every step, as
+   ces_amd's drivers and the reference's loop do -- ces/calibrate.py:387 tests t each iteration); the ranks of a sharded run
+   must read in lockstep (ShardedSampler does).  CESX_NS_WARM=0 removes the dependence. */
 int cesx_debug_warm_inverse(cesx_handle h);
 
 /* Which form of the update GEMM (ces/calibrate.py:443-447, :484-488, :515-527) the last cesx_apply / cesx_step of this handle

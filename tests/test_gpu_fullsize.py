@@ -145,8 +145,9 @@ def test_c3_eight_logical_shards_of_524288(setup):
 
 def test_c5_per_gpu_shape_fp64():
     """Config C5 as one GPU holds it: fp64, p = n_obs = 512, J = 32 768, ALDI with the on-device blocked
-    Cholesky, against the fp64 torch restatement on the device (1e-6, north star) -- plus the same problem
-    at J = 4 096 against the pinned oracle."""
+    Cholesky, against the PINNED oracle (oracle.factored_step in fp64 on the host: ~10 s at this size; ensemble, hk and
+    the data metric) and the fp64 torch restatement on the device (every metric; 1e-6, north star) -- plus the same
+    problem at J = 4 096 against the pinned oracle."""
     import torch
     from ces_amd import engine
     from oracle import ces_numpy as oc
@@ -157,7 +158,7 @@ def test_c5_per_gpu_shape_fp64():
     prob = dict(A=A, ustar=ustar, Gamma=0.01 * np.eye(n), y=(A @ ustar).ravel() + 0.1 * rng.standard_normal(n),
                 mu=np.zeros((p, 1)), sigma=100.0 * np.eye(p))
     g = torch.Generator(device="cuda").manual_seed(3)
-    for Jn, check in ((32768, "torch"), (4096, "oracle")):
+    for Jn, check in ((32768, "torch+oracle"), (4096, "oracle")):
         U = torch.as_tensor(ustar, device="cuda") + torch.randn((p, Jn), generator=g, device="cuda", dtype=torch.float64)
         G = torch.as_tensor(A, device="cuda") @ U
         xi = torch.randn((p, Jn), generator=g, device="cuda", dtype=torch.float64)
@@ -165,13 +166,14 @@ def test_c5_per_gpu_shape_fp64():
         eng.set_problem(prob["y"], prob["Gamma"], prob["mu"], prob["sigma"], prob["ustar"])
         out = eng.step(engine.step_params(update="aldi"), U, G, xi=xi)
         res = eng.result()
-        if check == "torch":
+        if "torch" in check:
             ref, hk, met = torch_factored_aldi(prob, U, G, xi)
             assert ((out - ref).abs().max() / ref.abs().max()).item() < 1e-6
             assert res.hk == pytest.approx(hk, rel=1e-9)
             for k, v in met.items():
                 assert getattr(res, k) == pytest.approx(v, rel=1e-7), k
-        else:
+            del ref
+        if "oracle" in check:
             st = oc.OracleState(p, n, Jn, prob["mu"], prob["sigma"], prob["ustar"])
             ref = oc.factored_step(st, prob["y"], U.cpu().numpy(), G.cpu().numpy(), prob["Gamma"], xi.cpu().numpy())
             assert np.max(np.abs(out.cpu().numpy() - ref)) / np.max(np.abs(ref)) < 1e-6

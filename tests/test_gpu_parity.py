@@ -226,6 +226,45 @@ def test_medium_sizes_against_oracle(eng_mod, p, n, J, dense, dtype, tol, update
     assert np.allclose(got, want, rtol=mt), (got, want)
 
 
+@pytest.mark.parametrize("cond,offset", [(1e2, 1.0), (1e4, 1e2)])
+@pytest.mark.parametrize("update", ["aldi", "eks"])
+def test_dense_gamma_conditioning(eng_mod, cond, offset, update):
+    """A dense Gamma is whitened in the ENGINE dtype (G~ = L_Gamma^{-1} G by the update kernel): on an fp32 engine the rounding of
+    that product, eps32 |L^{-1}| |G|, is amplified by sqrt(cond(Gamma)) relative to the whitened signal L^{-1} (G - gbar), and a
+    mean far from the spread (|gbar| / spread = offset) adds to it.  The supported range of include/cesx.h -- cond(Gamma) <= 1e4 with
+    |gbar| / spread <= 1e2 -- against the pinned oracle at the fp32 bar; the reference's dense Gammas are sample covariances of a few
+    observables (examples/notebooks/lorenz63.ipynb)."""
+    from oracle import ces_numpy as oc
+    p, n, J = 64, 48, 4096
+    rng = np.random.default_rng(int(cond) + 3)
+    A = rng.standard_normal((n, p)) / np.sqrt(p)
+    ustar = rng.standard_normal((p, 1))
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    ev = np.logspace(0, -np.log10(cond), n)
+    Gamma = 0.01 * (Q * ev) @ Q.T
+    Gamma = 0.5 * (Gamma + Gamma.T)
+    sigma, mu = 100.0 * np.eye(p), np.zeros((p, 1))
+    y = (A @ ustar).ravel() + 0.1 * rng.standard_normal(n)
+    U0 = ustar + 0.5 * rng.standard_normal((p, J))
+    G = A @ U0
+    spread = G.std(axis=1).mean()
+    shift = offset * spread * rng.standard_normal(n)          # a forward map with an offset: |gbar| >> the ensemble's spread
+    G = G + shift[:, None]
+    y = y + shift
+    xi = rng.standard_normal((p, J))
+    st = oc.OracleState(p, n, J, mu, sigma, ustar)
+    ref = oc.factored_step(st, y, U0, G, Gamma, xi, update=update)
+    eng = eng_mod.Engine(p, n, J, dtype="float32")
+    eng.set_problem(y, Gamma, mu, sigma, ustar)
+    out = eng.step(eng_mod.step_params(update=update), U0, G, xi=xi)
+    res = eng.result()
+    assert rel_err(out.cpu().numpy(), ref) < TOL32
+    assert res.hk == pytest.approx(st.metrics["t"][-1], rel=TOL32)
+    got = np.array([res.self_bias, res.self_bias_data, res.bias_data, res.bias])
+    want = np.array([st.metrics[k][-1] for k in ("self-bias", "self-bias-data", "bias-data", "bias")])
+    assert np.allclose(got, want, rtol=TOL32), (got, want)
+
+
 # time-step rules at the benchmark shape (ces/calibrate.py:247-260, :439-441, :470-473): the Krylov space of
 # the spectral rule is NOT exhausted at n_obs = 256 (the golden cases have n_obs <= 6), the gain recompute
 # inverts a 256 x 256 (hk C_gg + Gamma), and dense Gamma takes the general path of both

@@ -37,13 +37,16 @@ def test_gram_kernel_has_no_scratch_and_no_spills(table):
 def test_update_kernels_keep_their_loops_free_of_scratch(table):
     for name in ("update2_kernel<false, true>", "update2_kernel<false, false>", "update3_kernel"):
         r = table[name]
-        assert r["scratch_in_loop"] == 0 and r["VGPRs Spill"] == 0 or name == "update3_kernel", name
-        assert r["scratch_in_loop"] == 0, name
+        assert r["scratch_in_loop"] == 0 and r["VGPRs Spill"] == 0, name
         assert r["Occupancy [waves/SIMD]"] == 2, name      # two workgroups of four waves per CU
     # the benchmark's instantiation (every K segment from memory, hk applied at run time): the few SGPR reloads its
     # k-tile loop still has (round 5 count; the Philox instantiations, which nothing on the hot path launches, have 36 - 40)
     assert table["update2_kernel<false, true>"]["spill_in_loop"] <= 6
     assert table["update2_kernel<false, true>"]["ScratchSize [bytes/lane]"] == 0
+    # fp64 (the drop-in class's default dtype; C5): round 5 left it with a nominal 36-byte frame and 15 spilled SGPRs -- the epilogue's
+    # arguments, held across the K loop; round 6 re-reads them from the kernarg segment behind the loop
+    r3 = table["update3_kernel"]
+    assert r3["ScratchSize [bytes/lane]"] == 0 and r3["SGPRs Spill"] == 0 and r3["VGPRs Spill"] == 0 and r3["scratch_total"] == 0
 
 
 def test_the_tail_launch_of_the_benchmark_keeps_its_registers(table):
