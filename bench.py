@@ -572,7 +572,9 @@ def sharded_helper_main():
     if not sys.stdin.readline().strip():
         return                                       # parent went away / did not ask
     out = {}
-    for key, extra_env in (("head_tail", {}), ("single", {"CESX_SINGLE_ALLREDUCE": "1"})):
+    # (the third leg leaves the mode to the benchmark: 64 untimed steps in each behind the pre-warm, the faster one kept --
+    #  what the driver's N > 1 runs do; config.parallelism and sampled_step.mode_choice say which and why)
+    for key, extra_env in (("head_tail", {"CESX_SINGLE_ALLREDUCE": "0"}), ("single", {"CESX_SINGLE_ALLREDUCE": "1"}), ("auto", {})):
         env = dict(os.environ)
         env.update(CESX_FORCE_COLLECTIVES="1", CESX_BENCH_PREWARM_S="1.0", HSA_ENABLE_IPC_MODE_LEGACY="0")
         env.update(extra_env)
@@ -590,6 +592,7 @@ def sharded_helper_main():
                             collectives_per_step=d["sampled_step"]["collectives_per_step"],
                             collective_ms=d["sampled_step"]["collective_ms"],
                             gram_end_to_k3_start_ms=d["sampled_step"]["gram_end_to_k3_start_ms"],
+                            mode_choice=d["sampled_step"].get("mode_choice"),
                             parallelism=d["config"]["parallelism"])
         except Exception as ex:
             out[key] = dict(error=repr(ex))
@@ -883,6 +886,31 @@ def main():
             break
     prewarm_s = time.perf_counter() - t_pre
     t_hist[0] = 0.0
+    # Sharded runs: head + tail (two all-reduces, chol(C) beside the second Gram launch) or the north star's single all-reduce
+    # (chol(C) in line behind it)?  One rank says 0.39 against 0.52 ms/step, but one rank moves nothing over xGMI: unless
+    # CESX_SINGLE_ALLREDUCE pins it, every rank runs 64 untimed steps in each mode here (the slowest rank's time counts, all
+    # ranks see the same two numbers and take the same decision) and the faster mode is the one measured.
+    mode_choice = None
+    if (world > 1 or rehearse) and os.environ.get("CESX_SINGLE_ALLREDUCE") is None and hasattr(sh, "single_allreduce"):
+        cands = {"head_tail": sh, "single": ShardedUpdate(eng, single_allreduce=True)}
+        trial = {}
+        for name, cand in cands.items():
+            sh = cand
+            run_steps(0, 32)
+            plat.sync()
+            if world > 1:
+                dist.barrier()
+            tb = time.perf_counter()
+            run_steps(0, 64)
+            plat.sync()
+            tt = torch.tensor([(time.perf_counter() - tb) * 1e3 / 64], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            trial[name] = float(tt.item())
+        pick = min(trial, key=trial.get)
+        sh = cands[pick]
+        mode_choice = dict(picked=pick, ms_per_step={k: round(v, 4) for k, v in trial.items()},
+                           how="64 untimed steps in each mode behind the pre-warm, max over ranks; CESX_SINGLE_ALLREDUCE=0 / 1 pins one")
+        t_hist[0] = 0.0
     # the untimed samples: both MFMA kernels in one step, the gap's two events in another
     pre_k1 = pre_k3 = (0.0, 0)
     pre_gap = None
@@ -1057,11 +1085,14 @@ def main():
         par = "dp1: one GPU holds the whole ensemble, no collective is issued"
     elif sh.single_allreduce:
         par = ("particle-sharded dp%d over RCCL: ONE all-reduce(sum) of the %d-double fp64 moment buffer per step after "
-               "the complete Gram, chol(C) in line (CESX_SINGLE_ALLREDUCE=1)" % (world, eng.moments_len()))
+               "the complete Gram, chol(C) in line" % (world, eng.moments_len()))
     else:
         par = ("particle-sharded dp%d over RCCL: all-reduce(sum) of the %d-double fp64 moment buffer per step, sent in "
                "two pieces (%d-double head on the side stream beside the second Gram launch, then the rest)"
                % (world, eng.moments_len(), eng.moments_uu_len()))
+    if world > 1 or rehearse:
+        par += ("; mode measured and chosen: %s" % json.dumps(mode_choice["ms_per_step"]) if mode_choice
+                else "; mode pinned by CESX_SINGLE_ALLREDUCE=%s" % os.environ.get("CESX_SINGLE_ALLREDUCE"))
     rec = dict(metric="EKS particle-updates/sec", value=Jg * args.steps / elapsed, unit="particle-updates/s",
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * step_s,
                ms_per_step_median=float(np.median(per_step)), ms_per_step_min=float(np.min(per_step)),
@@ -1093,6 +1124,7 @@ def main():
                                  collective_mode=("none" if world == 1 and not rehearse else
                                                   "single" if sh.single_allreduce else "head+tail"),
                                  collectives_per_step=(0 if world == 1 and not rehearse else 1 if sh.single_allreduce else 2),
+                                 mode_choice=mode_choice,
                                  collective_ms={k: dict(doubles=v[0], ms=round(v[1], 4)) for k, v in coll_ms.items()},
                                  how="the interval: HIP events of an UNTIMED step of their own right before the warm-up steps "
                                      "(nothing else time-stamped in it): kernel-bound stop of the second Gram launch -> "

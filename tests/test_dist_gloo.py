@@ -234,11 +234,23 @@ def test_bench_rank_control_flow_on_two_gloo_ranks():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "tests", "bench_rehearsal.py"), "--gpus", "2", "--steps", "3",
            "--warmup", "1"]
-    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
-    assert res.returncode == 0, res.stderr[-2000:]
-    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, res.stdout[-2000:]
-    rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["value"] > 0
-    assert rec["config"]["J_global"] == 128 and rec["sampled_step"]["collectives_per_step"] == 2
-    assert rec["prewarm_steps"] == 512 and rec["scaling"] == "weak"
+    for pin in (None, "0"):
+        # (no pin: both ranks time both collective modes behind the pre-warm and keep the same, faster one -- round 6)
+        env_run = dict(env) if pin is None else dict(env, CESX_SINGLE_ALLREDUCE=pin)
+        env_run.pop("CESX_SINGLE_ALLREDUCE", None) if pin is None else None
+        res = subprocess.run(cmd, env=env_run, cwd=root, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, res.stdout[-2000:]
+        rec = json.loads(lines[0])
+        assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["value"] > 0
+        ss = rec["sampled_step"]
+        assert rec["config"]["J_global"] == 128
+        if pin is None:
+            mc = ss["mode_choice"]
+            assert set(mc["ms_per_step"]) == {"head_tail", "single"} and mc["picked"] == min(mc["ms_per_step"], key=mc["ms_per_step"].get)
+            assert ss["collectives_per_step"] == (1 if mc["picked"] == "single" else 2)
+            assert "mode measured and chosen" in rec["config"]["parallelism"]
+        else:
+            assert ss["mode_choice"] is None and ss["collectives_per_step"] == 2 and "pinned" in rec["config"]["parallelism"]
+        assert rec["prewarm_steps"] == 512 and rec["scaling"] == "weak"
