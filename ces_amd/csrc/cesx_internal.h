@@ -386,7 +386,6 @@ struct Engine {
     void* d_Wf = nullptr;          // the same matrix in the fragment-major order of kernels_update2.hip (fp32) / kernels_update3.hip (fp64)
     bool update_v2 = true;         // fp32 K3 through the LDS-DMA kernel (CESX_UPDATE_V1=1 switches back)
     int  center_u_wgs = 256;       // workgroups of the U-only centring on the side stream (see cesx_create)
-    bool ext_events = true;        // hand-over events bound to kernels' own completion signals (CESX_EXT_EVENTS=0: separate markers)
     bool gram_v2 = true;           // K1 through the LDS-DMA kernel when the shapes allow (CESX_GRAM_V1=1 switches back)
     int num_cus = 256;
     void* d_bias = nullptr;        // [rpad]
@@ -411,10 +410,8 @@ struct Engine {
     // every call flow of a problem runs the same kernels.
     bool chain = false;            // d_Wq is in the chained layout and the hk-free step launches update4_kernel
     bool chain_ok = true;          // CESX_CHAIN=0: the hk-free form of round 4 (update2_kernel<., true>) also where the chained one qualifies
-    int k3_stagger = 2;            // update4_kernel: the second workgroup of a CU starts this many s_sleep(100) late (CESX_K3_STAGGER, dev A/B)
     bool skip_L_hint = false;      // set by the callers of the factorisation: the step it belongs to is (expected to be) a chained one
     bool L_stale = false;          // the last factorisation wrote the chained image only: d_L does not hold its factor (refresh_factor)
-    int dev_noise = 0;             // CESX_DEV_NOISE (dev A/B, timing only): "skip" (-1) draws nothing; <bytes>: LDS per workgroup of the noise draw
     void* d_xi_tmp = nullptr;      // [p][J] a noise block drawn right in front of update4_kernel when none was prefetched or injected
     void* d_Wfwd = nullptr;        // forward-map staging [npad][kp]
     void* d_Wfwd_f = nullptr;      // the same map in the fragment-major order of the LDS-DMA update kernels (cesx_forward_set_lineal)
@@ -479,7 +476,7 @@ struct Engine {
     bool pending = false;
     // single-device fast path: the metric finalisation + publication of the last update rides on the next
     // U x U reduce launch (cesx_moments_uu_chol); every other entry point flushes it as a kernel of its own first
-    bool met_deferred = false, met_defer_ok = true;      // CESX_DEFER_PUBLISH=0 switches the deferral off
+    bool met_deferred = false;
     hipStream_t met_stream = nullptr;
     double* d_lag = nullptr;       // [3] {N, lagged sum q_r^2, lagged sum q_e^2} of the moment buffer of the last cesx_apply (K2 copies
                                    // them here: the deferred finalisation reads engine-owned memory, not the caller's buffer)

@@ -260,14 +260,10 @@ static int create_impl(const cesx_config* cfg, cesx_handle* out) {
     if (const char* ov = std::getenv("CESX_OVERLAP")) e.overlap_chol = ov[0] != '0';
     if (const char* uv = std::getenv("CESX_UPDATE_V1")) e.update_v2 = uv[0] == '0';
     if (const char* gv = std::getenv("CESX_GRAM_V1")) e.gram_v2 = gv[0] == '0';
-    if (const char* xv = std::getenv("CESX_EXT_EVENTS")) e.ext_events = xv[0] != '0';
-    if (const char* dv = std::getenv("CESX_DEFER_PUBLISH")) e.met_defer_ok = dv[0] != '0';
     if (const char* fv = std::getenv("CESX_FUSE_CENTER")) { e.fuse_center_ok = fv[0] != '0'; e.fuse_center_auto = false; }
     if (const char* pv = std::getenv("CESX_POLL_JOIN")) e.poll_join_ok = pv[0] != '0';
     if (const char* hv = std::getenv("CESX_HKFREE")) e.hkfree_ok = hv[0] != '0';
     if (const char* cv = std::getenv("CESX_CHAIN")) e.chain_ok = cv[0] != '0';
-    if (const char* kv = std::getenv("CESX_K3_STAGGER")) e.k3_stagger = std::max(0, std::min(64, std::atoi(kv)));
-    if (const char* nv = std::getenv("CESX_DEV_NOISE")) e.dev_noise = nv[0] == 's' ? -1 : std::max(0, std::atoi(nv));
     if (const char* sv = std::getenv("CESX_UPDATE_SMALL")) e.update_small = sv[0] != '0';
     if (const char* dv = std::getenv("CESX_TEST_DROP_CHOL_SIGNAL")) e.test_drop_signal_at = (unsigned long long)std::max(0, std::atoi(dv));
     if (const char* tv = std::getenv("CESX_POLL_TIMEOUT_MS")) e.poll_ticks = (unsigned long long)std::max(1, std::atoi(tv)) * 100000ull;
@@ -624,7 +620,7 @@ int cesx_moments_uu_handover(cesx_handle h, const void* U, const void* G, double
     TRY(moments_check(e, U, G, mom));
     SET_DEVICE(e);
     hipStream_t s = (hipStream_t)stream;
-    if (s == e.side || !e.ext_events) {      // nothing to hand over / plain markers: the caller's own ordering applies
+    if (s == e.side) {      // nothing to hand over: the caller's own ordering applies
         FLUSH(e);
         ++e.prof_step;
         WHITEN_UU(e, G, s);
@@ -645,7 +641,7 @@ int cesx_moments_uu_chol(cesx_handle h, int update, const void* U, const void* G
     if (update < 0 || update > 2) { e.err = "cesx_moments_uu_chol: bad argument"; return CESX_EINVAL; }
     SET_DEVICE(e);
     hipStream_t s = (hipStream_t)stream;
-    if (s == e.side || !e.ext_events) {
+    if (s == e.side) {
         FLUSH(e);
         ++e.prof_step;
         WHITEN_UU(e, G, s);
@@ -751,7 +747,7 @@ int cesx_apply(cesx_handle h, const cesx_step_params* prm, const double* mom, co
     TRY(run_update_main(e, *prm, U, G, xi, Unext, s));
     // (Moving this last small kernel to the side stream was tried: the event record + wait pair costs
     //  as much GPU idle time as the 7 us kernel itself.)
-    if (e.met_defer_ok && e.ext_events && e.overlap_chol) {
+    if (e.overlap_chol) {
         // the finalisation rides on the next step's U x U reduce launch (cesx_moments_uu_chol / _handover on this
         // stream) -- no one-workgroup kernel (7 us) between this update and the next Gram launch; anything else flushes it
         e.met_deferred = true; e.met_stream = s;      // (reads the engine's own d_lag, not `mom`)

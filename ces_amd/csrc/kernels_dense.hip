@@ -1636,12 +1636,6 @@ static int potrf(Engine& e, hipStream_t s, int n, const double* A, double* Lp, h
                  float* wq = nullptr) {                                                      // wq: the hk-free update's image (one-kernel factorisations)
     const int np = potrf_ld(n);
     if (np <= 256) {
-        if (stop && !e.ext_events) {
-            int rc0 = potrf_reg_any(e, s, n, np, A, Lp, 0, 0, nullptr, PotrfCen(), done, done_val, wq);
-            if (rc0) return rc0;
-            CESX_HIP(hipEventRecord(stop, s));
-            return CESX_OK;
-        }
         return potrf_reg_any(e, s, n, np, A, Lp, 0, 0, stop, PotrfCen(), done, done_val, wq);
     }
     // Blocked right-looking factorisation with 256-wide diagonal blocks (p > 256): register
@@ -2159,12 +2153,7 @@ int launch_chol_async(Engine& e, int update, const double* mom, hipStream_t s, b
         float* wq = img ? (float*)e.d_Wq : (float*)nullptr;
         // (CESX_TEST_DROP_CHOL_SIGNAL=k, tests only: the k-th factorisation does not store its word)
         unsigned long long* flag = e.test_drop_signal_at == e.chol_seq + 1 ? nullptr : e.d_cholflag;
-        if (e.ext_events) {
-            if ((rc = potrf_reg_any(e, e.side, p, np, mv.mom + e.ml.Saa(), e.d_L, p, 0, e.ev_b, cen, flag, e.chol_seq + 1, wq))) return rc;
-        } else {
-            if ((rc = potrf_reg_any(e, e.side, p, np, mv.mom + e.ml.Saa(), e.d_L, p, 0, nullptr, cen, flag, e.chol_seq + 1, wq))) return rc;
-            CESX_HIP(hipEventRecord(e.ev_b, e.side));
-        }
+        if ((rc = potrf_reg_any(e, e.side, p, np, mv.mom + e.ml.Saa(), e.d_L, p, 0, e.ev_b, cen, flag, e.chol_seq + 1, wq))) return rc;
     } else {
     e.side_img = img;
     float* wq = e.side_img ? (float*)e.d_Wq : (float*)nullptr;

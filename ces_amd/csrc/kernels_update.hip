@@ -477,15 +477,11 @@ int launch_absmax_final(Engine& e, int nparts, double* absmax_out, hipStream_t s
 }
 
 int launch_noise(Engine& e, uint64_t step_index, void* xi, hipStream_t s) {
-    // dev A/B only (timing; results are wrong): CESX_DEV_NOISE=skip draws nothing, CESX_DEV_NOISE=<bytes> gives every workgroup that much LDS
-    if (e.dev_noise < 0) return CESX_OK;
-    const unsigned dev_lds = (unsigned)e.dev_noise;
     const bool vec4 = e.J % 4 == 0 && ((uintptr_t)xi % (4 * e.esz)) == 0;
     const long long per = vec4 ? 4 : 1;
     dim3 grid((unsigned)((e.J / per + 255) / 256), (unsigned)((e.p + 3) / 4));
     auto go = [&](auto kern, auto* ptr) {
-        if (dev_lds) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dev_lds);
-        hipLaunchKernelGGL(kern, grid, dim3(256), dev_lds, s, ptr, e.p, (long long)e.J, (long long)e.cfg.j_offset,
+        hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, ptr, e.p, (long long)e.J, (long long)e.cfg.j_offset,
                            (unsigned)e.cfg.seed, (unsigned)(e.cfg.seed >> 32), (unsigned)step_index);
     };
     if (e.cfg.dtype == CESX_F32) {

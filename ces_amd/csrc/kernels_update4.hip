@@ -403,7 +403,7 @@ int launch_update4(Engine& e, const void* U, const void* G, const void* xi, void
     dim3 grid((unsigned)((e.J + U4_BN - 1) / U4_BN));
     // the dispatcher gives every CU one workgroup before any CU gets its second: from there on start late
     a.stagger_from = (long long)grid.x > e.num_cus ? e.num_cus : 0x7fffffff;
-    a.stagger_n = e.k3_stagger;
+    a.stagger_n = 2;          // (0 ... 4 x 6.4k cycles: no difference at C2, tools/ab_env.py round 6; 7: the CU's store path)
     CESX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(update4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     e.last_update_grid_x = (int)grid.x;
     e.last_update_grid = (int)grid.x;

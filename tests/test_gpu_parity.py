@@ -772,10 +772,11 @@ def test_comm_overlap_stream_path_matches(eng_mod, monkeypatch):
 
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
 def test_single_device_fast_path_variants_match(eng_mod, monkeypatch, dtype):
-    """The single-device fast path -- hand-over events bound to kernels (cesx_moments_uu_chol), the noise block drawn one
-    step ahead, the metric finalisation + publication riding on the
-    NEXT step's U x U reduce launch -- gives bit-identical chains to the plain path (separate markers, kernels and a
-    metric_final kernel per step), in a pipelined loop (begin(i+1) before result(i)) and in a step-by-step one."""
+    """The single-device fast path -- hand-over events bound to kernels (cesx_moments_uu_chol), the metric finalisation +
+    publication riding on the NEXT step's U x U reduce launch, the noise block drawn one step ahead (CESX_NOISE_LOOKAHEAD) or
+    for the current step only -- gives bit-identical chains in a pipelined loop (begin(i+1) before result(i)) and in a
+    step-by-step one (where every result read flushes the deferred publication as a kernel of its own).  (Round 6 removed the
+    CESX_EXT_EVENTS=0 / CESX_DEFER_PUBLISH=0 arms this test also used to run: no caller took them.)"""
     from ces_amd.dist import ShardedUpdate
     p, n, J = 128, 96, 8192
     d = _synthetic(p, n, J, seed=77)
@@ -784,8 +785,7 @@ def test_single_device_fast_path_variants_match(eng_mod, monkeypatch, dtype):
     #  test_hk_free_update_matches_the_assembled_form holds it to the assembled one)
     monkeypatch.setenv("CESX_HKFREE", "0")
     for fast, pipelined in ((True, True), (True, False), (False, True), (False, False)):
-        for k in ("CESX_EXT_EVENTS", "CESX_DEFER_PUBLISH", "CESX_NOISE_LOOKAHEAD"):
-            monkeypatch.setenv(k, "1" if fast else "0")
+        monkeypatch.setenv("CESX_NOISE_LOOKAHEAD", "1" if fast else "0")
         eng = eng_mod.Engine(p, n, J, dtype=dtype, seed=9)
         eng.set_problem(d["y"], d["Gamma"], d["mu"], d["sigma"], d["ustar"])
         sh = ShardedUpdate(eng)
