@@ -918,6 +918,91 @@ def test_hk_free_update_matches_the_assembled_form(eng_mod, monkeypatch, p, n, J
         assert np.array_equal(U, U1) and np.array_equal(c, c1)
 
 
+@pytest.mark.parametrize("p,n,J", [(256, 256, 8192), (250, 100, 1000), (233, 37, 4100)])
+def test_update_through_the_cholesky_factor(eng_mod, monkeypatch, p, n, J):
+    """K3 through the Cholesky factor (kernels_update4.hip; fp32, diagonal Sigma, 224 < p <= 256): C Sigma^{-1} (U - mu) =
+    L (L^T Sigma^{-1} U) - C Sigma^{-1} mu with C = L L^T as factored (ces/calibrate.py:476-478, :484-488).  Against the pinned
+    oracle with an injected block (ragged p, n and J included: the last 32-row block, the last G tile and the last workgroup
+    are partial), against the dense hk-free form (CESX_CHAIN=0) to fp32 rounding, a non-zero prior mean (the C Sigma^{-1} mu
+    term lives in the bias), the factor cesx_debug_dense reports after a step that kept it in the image only, and the block
+    the engine draws itself when none was injected or drawn ahead."""
+    from oracle import ces_numpy as oc
+    d = _synthetic(p, n, J, seed=p + n + J + 1)
+    rng = np.random.default_rng(5)
+    mu = 0.3 * rng.standard_normal((p, 1))
+    sigma = np.diag(100.0 * (1.0 + 0.5 * rng.random(p)))
+    st = oc.OracleState(p, n, J, mu, sigma, d["ustar"])
+    ref = oc.factored_step(st, d["y"], d["U0"], d["G"], d["Gamma"], d["xi"], update="aldi")
+    outs = {}
+    for chain in ("1", "0"):
+        monkeypatch.setenv("CESX_CHAIN", chain)
+        eng = eng_mod.Engine(p, n, J, dtype="float32", seed=3)
+        eng.set_problem(d["y"], d["Gamma"], mu, sigma, d["ustar"])
+        out = eng.step(eng_mod.step_params(update="aldi", step_index=4), d["U0"], d["G"], xi=d["xi"])
+        res = eng.result()
+        assert eng.update_form() == (2 if chain == "1" else 1)
+        outs[chain] = out.cpu().numpy()
+        assert rel_err(outs[chain], ref) < TOL32
+        assert res.hk == pytest.approx(st.metrics["t"][-1], rel=TOL32)
+        got = np.array([res.self_bias, res.self_bias_data, res.bias_data, res.bias])
+        want = np.array([st.metrics[k][-1] for k in ("self-bias", "self-bias-data", "bias-data", "bias")])
+        assert np.allclose(got, want, rtol=TOL32), (got, want)
+        if chain == "1":
+            dd = eng.debug_dense()            # (the chained step kept L in its image: re-factored on demand)
+            Lref = np.linalg.cholesky(dd["C"])
+            assert np.max(np.abs(dd["L"] - Lref)) <= 1e-9 * np.max(np.abs(Lref))
+            # no block injected, none drawn ahead: the engine draws the step's block itself -- the same block cesx_draw_noise gives
+            prm = eng_mod.step_params(update="aldi", step_index=9)
+            a = eng.step(prm, d["U0"], d["G"], xi=None).cpu().numpy()
+            eng.result()
+            b = eng.step(prm, d["U0"], d["G"], xi=eng.draw_noise(9)).cpu().numpy()
+            eng.result()
+            assert eng.update_form() == 2 and np.array_equal(a, b)
+    scale = np.max(np.abs(outs["0"]))
+    assert np.max(np.abs(outs["1"] - outs["0"])) <= 2e-5 * scale
+
+
+def test_a_step_that_turns_out_not_to_be_chained_refactors(eng_mod, monkeypatch):
+    """The factorisation is enqueued (cesx_chol_async, beside the second Gram launch) before the step's time-step rule is
+    known; expecting a chained step it keeps L in the coefficient image only.  When the step then takes another rule
+    (here: `spectral` and `constant` in the middle of a default-rule chain, pipelined) the assembled form needs the fp64
+    factor: launch_dense re-factors C in line (Engine::L_stale).  Same chain as an engine that never chains."""
+    from ces_amd.dist import ShardedUpdate
+    p, n, J = 256, 96, 4096
+    d = _synthetic(p, n, J, seed=77)
+    rules = [None, None, "spectral", None, "constant", None]
+
+    def chain():
+        eng = eng_mod.Engine(p, n, J, dtype="float32", seed=9)
+        eng.set_problem(d["y"], d["Gamma"], d["mu"], d["sigma"], d["ustar"])
+        sh = ShardedUpdate(eng)
+        U, G = eng.to_device(d["U0"]), eng.to_device(d["G"])
+        bufs = [eng.empty(p), eng.empty(p)]
+        t_last, outs, forms = 0.0, [], []
+        prm0 = eng_mod.step_params(update="aldi")
+        sh.begin(prm0, U, G, recenter=True, noise_step=0)
+        for i, ts in enumerate(rules):
+            prm = eng_mod.step_params(update="aldi", time_step=ts, delta_t=0.01, first_step=(i == 0), t_len=min(i, 1),
+                                      t_last=t_last, step_index=i)
+            out = sh.finish(prm, U, G, xi=None, out=bufs[i % 2])
+            if i + 1 < len(rules):
+                sh.begin(prm0, out, G, noise_step=i + 1)
+            res = sh.result()
+            forms.append(eng.update_form())
+            t_last = res.t_new
+            outs.append((out.cpu().numpy().copy(), res.hk, res.t_new))
+            U = out
+        return outs, forms
+    monkeypatch.setenv("CESX_CHAIN", "1")
+    a, fa = chain()
+    monkeypatch.setenv("CESX_CHAIN", "0")
+    b, fb = chain()
+    assert fa == [2, 2, 0, 2, 0, 2] and fb == [1, 1, 0, 1, 0, 1]
+    for (ua, hka, ta), (ub, hkb, tb) in zip(a, b):
+        assert hka == pytest.approx(hkb, rel=1e-4) and ta == pytest.approx(tb, rel=1e-4)
+        assert np.max(np.abs(ua - ub)) <= 1e-4 * np.max(np.abs(ub))
+
+
 def test_polled_join_that_runs_out_leaves_the_step_untouched_and_is_rerun(eng_mod, monkeypatch):
     """The polled join of the side stream (launch_dense) is bounded in wall time.  A factorisation that never stores its
     word (CESX_TEST_DROP_CHOL_SIGNAL: the second one) makes the poll of that step run out: the assembly and update
