@@ -1003,13 +1003,13 @@ def test_a_step_that_turns_out_not_to_be_chained_refactors(eng_mod, monkeypatch)
         assert np.max(np.abs(ua - ub)) <= 1e-4 * np.max(np.abs(ub))
 
 
-def test_polled_join_that_runs_out_leaves_the_step_untouched_and_is_rerun(eng_mod, monkeypatch):
+@pytest.mark.parametrize("p,n,J", [(128, 96, 8192), (256, 96, 4096)])      # (the second: K3 through the Cholesky factor, the image-only factorisation)
+def test_polled_join_that_runs_out_leaves_the_step_untouched_and_is_rerun(eng_mod, monkeypatch, p, n, J):
     """The polled join of the side stream (launch_dense) is bounded in wall time.  A factorisation that never stores its
     word (CESX_TEST_DROP_CHOL_SIGNAL: the second one) makes the poll of that step run out: the assembly and update
     launches write nothing, cesx_result switches the engine to the event join and re-runs the step with chol(C) in line
     -- the chain is bit-identical to one that never polled (CESX_POLL_JOIN=0); a pipelined driver is told (CESX_ESTATE)
     that the moments it enqueued behind the failed step must be redone, which ShardedUpdate.result does by itself."""
-    p, n, J = 128, 96, 8192
     d = _synthetic(p, n, J, seed=81)
     monkeypatch.setenv("CESX_POLL_JOIN", "0")
     e0, U0, c0, _ = _aldi_chain(eng_mod, d, p, n, J, "float32")
