@@ -3,7 +3,7 @@
 // streams in ces_amd/dist.py: the head on the side stream in front of chol(C), the tail on the caller's stream).
 // A C caller -- or the reference bound as in INTEGRATION.md -- runs a sharded ensemble with these entry points alone;
 // nothing here needs torch.distributed.  (one ncclAllReduce(sum) of the packed buffer per step; the
-// default splits it in head + tail of the same total payload, see DESIGN.md section 5.)
+// default splits it in head + tail of the same total payload, see DESIGN.md section 7.)
 //
 // librccl is bound at run time (dlopen / dlsym): an engine that never shards does not load it, and a process that
 // already holds a copy (PyTorch ships its own) keeps using that one -- RTLD_NOLOAD first.

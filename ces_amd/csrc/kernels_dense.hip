@@ -1439,7 +1439,7 @@ static inline dim3 g1(long long len, int bs = 256) { return dim3((unsigned)((len
 
 static int gemm(Engine& e, hipStream_t s, int m, int n, int k, double alpha, const double* A, long long a0,
                 long long a1, const double* B, long long b0, long long b1, double* C) {
-    // (small output, long k: K split over the waves of a workgroup -- a 256^3 product 20 -> see DESIGN.md; else 2 x 2 blocks per workgroup)
+    // (small output, long k: K split over the waves of a workgroup -- a 256^3 product 20 -> 8 us, NOTEBOOK.md section 3; else 2 x 2 blocks per workgroup)
     if (k >= 64 && (long long)((m + 15) / 16) * ((n + 15) / 16) <= 4096)
         hipLaunchKernelGGL(gemm_splitk_kernel, dim3((n + 15) / 16, (m + 15) / 16), dim3(DT), 0, s, m, n, k, alpha, A, a0,
                            a1, B, b0, b1, C, n, e.gate);

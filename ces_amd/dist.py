@@ -249,7 +249,7 @@ class ShardedUpdate:
         # the moment kernels FIRST (they need A and the head, not G): they are small, so the side stream's centring and
         # chol(C) find their CUs while they run, and the forward GEMM behind fills what is left.  With the GEMM first --
         # 512 workgroups, two on every CU -- the factorisation (8 waves x 256 registers: a CU to itself) started when the
-        # GEMM had drained: 0.477 against 0.457 ms/step at C2
+        # GEMM had drained: 0.477 against 0.457 ms/step at C2 (NOTEBOOK.md section 6)
         eng.moments_rest_lineal(mom)
         G = forward(U) if out is None else forward(U, out=out)
         self._mom = mom
