@@ -48,7 +48,7 @@ struct Upd4Args {
     int p, n;
     const float *U, *G, *xi;
     const float* bias;                     // b' [256]
-    long long J, j_offset;
+    long long J;
     float* out;
     const float* rowc; double* metric_part;
     const double *hkp, *s2p, *alphap;
@@ -237,7 +237,6 @@ void update4_kernel(const Upd4Args a) {
         for (int g = 0; g < 2; ++g) {
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
-                constexpr int dummy = 0; (void)dummy;
                 const int s = T * 16 + g * 8 + b;
                 // the fragment three block steps ahead (the next tile's slot once this tile's barrier is passed)
                 {
@@ -297,7 +296,7 @@ void update4_kernel(const Upd4Args a) {
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
                 const int s = g * 8 + b, s3 = s + 3;
-                if (!(U4_ABL & 4)) read_a(af[(s3 + 2 * 0) & 3], (s3 >> 4) ? sln : sl, (s3 >> 3) & 1, s3 & 7);
+                if (!(U4_ABL & 4)) read_a(af[s3 & 3], (s3 >> 4) ? sln : sl, (s3 >> 3) & 1, s3 & 7);
                 float* const fa = af[s & 3];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) O[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j], uf[4 * g + j], O[b], 0, 0, 0);
@@ -393,7 +392,7 @@ int launch_update4(Engine& e, const void* U, const void* G, const void* xi, void
     a.Wc = (const float*)e.d_Wq; a.ng = e.kn / 16; a.p = e.p; a.n = e.n;
     a.U = (const float*)U; a.G = (const float*)G; a.xi = (const float*)xi;
     a.bias = (const float*)e.d_bias;
-    a.J = e.J; a.j_offset = e.cfg.j_offset;
+    a.J = e.J;
     a.out = (float*)out;
     a.rowc = (const float*)e.d_rowc;
     a.metric_part = metrics ? e.d_metric_part : nullptr;

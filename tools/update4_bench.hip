@@ -54,7 +54,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(scal, hs, 24, hipMemcpyHostToDevice));
 
     Upd4Args a{};
-    a.Wc = Wc; a.ng = ng; a.p = p; a.n = n; a.U = U; a.G = G; a.xi = X; a.bias = dbias; a.J = J; a.j_offset = 0; a.out = out;
+    a.Wc = Wc; a.ng = ng; a.p = p; a.n = n; a.U = U; a.G = G; a.xi = X; a.bias = dbias; a.J = J; a.out = out;
     a.rowc = rowc; a.metric_part = mpart; a.hkp = scal; a.s2p = scal + 1; a.alphap = scal + 2;
     a.stagger_from = 256; a.stagger_n = 2;
     const int lds = U4_RING * (U4_ASLOT + U4_XSLOT) + kn * 16 + 1024;
